@@ -1,0 +1,435 @@
+"""CPU oracle for the nerfacc hot path -- TEST INFRASTRUCTURE ONLY.
+
+Thin numpy/ctypes front end over ``oracle/nerfacc_oracle.c`` (a plain-C
+restatement of the reference's CUDA kernels) plus numpy restatements of the
+reference's Python composites (volrend.py, pack.py, occ_grid.py sampling).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this module.  The product package ``nerfacc_amd`` never
+does: it fails loudly when its HIP library is missing.
+
+All citations are relative to /root/reference/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_HERE, "nerfacc_oracle.c")
+_BUILD = os.path.join(_HERE, "_build")
+_SO = os.path.join(_BUILD, "libnerfacc_oracle.so")
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """gcc-compile the C restatement (no FMA contraction, OpenMP)."""
+    os.makedirs(_BUILD, exist_ok=True)
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
+        cmd = ["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-shared", "-fPIC",
+               "-fvisibility=hidden", "-o", _SO + ".tmp", _SRC, "-lm"]
+        subprocess.run(cmd, check=True)
+        os.replace(_SO + ".tmp", _SO)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.orc_philox_uniform.restype = C.c_float
+        _lib.orc_philox_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        _lib.orc_max_threads.restype = C.c_int
+    return _lib
+
+
+def max_threads() -> int:
+    return int(lib().orc_max_threads())
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def _i64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int64))
+
+
+def _u8(a):
+    return np.ascontiguousarray(np.asarray(a).astype(np.uint8))
+
+
+# --------------------------------------------------------------------------- grid
+def ray_aabb_intersect(rays_o, rays_d, aabbs, near_plane=-np.inf, far_plane=np.inf, miss_value=np.inf):
+    """nerfacc/grid.py:13-51 -> cuda/csrc/grid.cu:477-519."""
+    rays_o, rays_d, aabbs = _f32(rays_o), _f32(rays_d), _f32(aabbs)
+    n, m = rays_o.shape[0], aabbs.shape[0]
+    t_mins = np.empty((n, m), np.float32)
+    t_maxs = np.empty((n, m), np.float32)
+    hits = np.empty((n, m), np.uint8)
+    lib().orc_ray_aabb_intersect(_p(rays_o), _p(rays_d), C.c_int64(n), _p(aabbs), C.c_int64(m),
+                                 C.c_float(near_plane), C.c_float(far_plane), C.c_float(miss_value),
+                                 _p(t_mins), _p(t_maxs), _p(hits))
+    return t_mins, t_maxs, hits.astype(bool)
+
+
+def sort_intersections(t_mins, t_maxs):
+    """grid.py:160-162: sort(cat([t_mins, t_maxs], -1)).  Stable (ties are
+    unspecified in the reference)."""
+    t = np.concatenate([t_mins, t_maxs], axis=-1)
+    idx = np.argsort(t, axis=-1, kind="stable").astype(np.int64)
+    return np.take_along_axis(t, idx, axis=-1), idx
+
+
+def _traverse_pass(rays_o, rays_d, rays_mask, binaries, aabbs, hits, t_sorted, t_indices,
+                   near_planes, far_planes, step_size, cone_angle, limit, first_pass, iv, sm, term):
+    n_rays = rays_o.shape[0]
+    res = np.asarray(binaries.shape[1:], dtype=np.int32)
+    lib().orc_traverse_grids_pass(
+        C.c_int64(n_rays), _p(rays_o), _p(rays_d), _p(rays_mask),
+        C.c_int32(binaries.shape[0]), _p(res), _p(binaries), _p(aabbs),
+        _p(hits), _p(t_sorted), _p(t_indices), _p(near_planes), _p(far_planes),
+        C.c_float(step_size), C.c_float(cone_angle), C.c_int32(limit), C.c_int(first_pass),
+        _p(iv.get("vals")), _p(iv.get("ray_indices")), _p(iv.get("is_left")), _p(iv.get("is_right")),
+        _p(iv.get("chunk_starts")), _p(iv.get("chunk_cnts")),
+        _p(sm.get("vals")), _p(sm.get("ray_indices")), _p(sm.get("is_valid")),
+        _p(sm.get("chunk_starts")), _p(sm.get("chunk_cnts")),
+        _p(term))
+
+
+def _alloc_from_chunk(spec, masks, valid):
+    """data_spec.hpp:86-96 memalloc_data_from_chunk (always zero-initialised here)."""
+    cnts = spec["chunk_cnts"]
+    cumsum = np.cumsum(cnts, dtype=np.int64)
+    n = int(cumsum[-1]) if cnts.size else 0
+    spec["chunk_starts"] = cumsum - cnts
+    spec["vals"] = np.zeros(n, np.float32)
+    spec["ray_indices"] = np.zeros(n, np.int64)
+    if masks:
+        spec["is_left"] = np.zeros(n, np.uint8)
+        spec["is_right"] = np.zeros(n, np.uint8)
+    if valid:
+        spec["is_valid"] = np.zeros(n, np.uint8)
+
+
+def traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes=None, far_planes=None,
+                   step_size=1e-3, cone_angle=0.0, traverse_steps_limit=None, over_allocate=False,
+                   rays_mask=None, t_sorted=None, t_indices=None, hits=None):
+    """nerfacc/grid.py:93-192 + host code cuda/csrc/grid.cu:320-474.
+
+    Returns (intervals, samples, terminate_planes); intervals/samples are dicts
+    with vals, ray_indices, packed_info, is_left/is_right or is_valid.
+    """
+    rays_o, rays_d, aabbs = _f32(rays_o), _f32(rays_d), _f32(aabbs)
+    binaries = _u8(binaries)
+    n_rays = rays_o.shape[0]
+    near_planes = np.zeros(n_rays, np.float32) if near_planes is None else _f32(near_planes)
+    far_planes = np.full(n_rays, np.inf, np.float32) if far_planes is None else _f32(far_planes)
+    mask = np.ones(n_rays, np.uint8) if rays_mask is None else _u8(rays_mask)
+    limit = -1 if traverse_steps_limit is None else int(traverse_steps_limit)
+    if over_allocate:
+        assert limit > 0
+    if t_sorted is None or t_indices is None or hits is None:
+        t_mins, t_maxs, hits = ray_aabb_intersect(rays_o, rays_d, aabbs)
+        t_sorted, t_indices = sort_intersections(t_mins, t_maxs)
+    t_sorted, t_indices, hits = _f32(t_sorted), _i64(t_indices), _u8(hits)
+
+    iv, sm = {}, {}
+    # The reference leaves terminate_planes uninitialised for rays it skips
+    # (masked rays; zero-sample rays in the fill pass).  We define those
+    # entries as the ray's near plane in over-allocate mode and as the count
+    # pass's t_last in two-pass mode.
+    term = near_planes.copy()
+    args = (rays_o, rays_d)
+    common = (binaries, aabbs, hits, t_sorted, t_indices, near_planes, far_planes,
+              float(step_size), float(cone_angle), limit)
+    if over_allocate:  # grid.cu:364-404
+        iv["chunk_cnts"] = np.full(n_rays, limit * 2, np.int64) * mask
+        _alloc_from_chunk(iv, True, False)
+        sm["chunk_cnts"] = np.full(n_rays, limit, np.int64) * mask
+        _alloc_from_chunk(sm, False, True)
+        _traverse_pass(*args, mask, *common, 0, iv, sm, term)
+        for s in (iv, sm):  # compute_chunk_start with the actual counts
+            s["chunk_starts"] = np.cumsum(s["chunk_cnts"], dtype=np.int64) - s["chunk_cnts"]
+    else:  # grid.cu:405-471 (rays_mask is ignored: nullptr)
+        iv["chunk_cnts"] = np.zeros(n_rays, np.int64)
+        sm["chunk_cnts"] = np.zeros(n_rays, np.int64)
+        _traverse_pass(*args, None, *common, 1, iv, sm, term)
+        _alloc_from_chunk(iv, True, False)
+        _alloc_from_chunk(sm, False, True)
+        _traverse_pass(*args, None, *common, 0, iv, sm, None)
+    out_iv = dict(vals=iv["vals"], ray_indices=iv["ray_indices"],
+                  packed_info=np.stack([iv["chunk_starts"], iv["chunk_cnts"]], -1),
+                  is_left=iv["is_left"].astype(bool), is_right=iv["is_right"].astype(bool))
+    out_sm = dict(vals=sm["vals"], ray_indices=sm["ray_indices"],
+                  packed_info=np.stack([sm["chunk_starts"], sm["chunk_cnts"]], -1),
+                  is_valid=sm["is_valid"].astype(bool))
+    return out_iv, out_sm, term
+
+
+# --------------------------------------------------------------------------- scan / pack
+_KIND = {"inclusive_sum": 0, "exclusive_sum": 1, "inclusive_prod": 2, "exclusive_prod": 3}
+
+
+def packed_scan(kind, inputs, packed_info, normalize=False, backward=False):
+    """cuda/csrc/scan.cu:9-165,217-257 (forward launches and the reverse-iterator ones)."""
+    inputs = _f32(inputs)
+    packed_info = _i64(packed_info)
+    starts = np.ascontiguousarray(packed_info[:, 0])
+    cnts = np.ascontiguousarray(packed_info[:, 1])
+    out = np.zeros_like(inputs)
+    lib().orc_packed_scan(C.c_int(_KIND[kind]), _p(starts), _p(cnts), C.c_int64(starts.shape[0]),
+                          _p(inputs), C.c_int64(inputs.shape[0]), C.c_int(bool(normalize)),
+                          C.c_int(bool(backward)), _p(out))
+    return out
+
+
+def inclusive_sum(x, packed_info, normalize=False):
+    return packed_scan("inclusive_sum", x, packed_info, normalize)
+
+
+def exclusive_sum(x, packed_info, normalize=False):
+    return packed_scan("exclusive_sum", x, packed_info, normalize)
+
+
+def inclusive_prod(x, packed_info):
+    return packed_scan("inclusive_prod", x, packed_info)
+
+
+def exclusive_prod(x, packed_info):
+    return packed_scan("exclusive_prod", x, packed_info)
+
+
+def sum_backward(kind, grad_out, packed_info):
+    """scan.py:205-214 / :233-242: same scan over reversed data."""
+    return packed_scan(kind, grad_out, packed_info, False, True)
+
+
+def prod_backward(kind, inputs, outputs, grad_out, packed_info):
+    """scan.cu:169-214 / :259-304: reverse sum-scan of g*out, / clamp_min(in, 1e-10)."""
+    sum_kind = "inclusive_sum" if kind == "inclusive_prod" else "exclusive_sum"
+    g = packed_scan(sum_kind, _f32(grad_out) * _f32(outputs), packed_info, False, True)
+    return g / np.maximum(_f32(inputs), np.float32(1e-10))
+
+
+def pack_info(ray_indices, n_rays=None):
+    """nerfacc/pack.py:38-46."""
+    ray_indices = _i64(ray_indices)
+    if n_rays is None:
+        n_rays = int(ray_indices.max()) + 1
+    out = np.zeros((n_rays, 2), np.int64)
+    lib().orc_pack_info(_p(ray_indices), C.c_int64(ray_indices.shape[0]), C.c_int64(n_rays), _p(out))
+    return out
+
+
+# --------------------------------------------------------------------------- volrend (numpy fp32)
+def render_transmittance_from_alpha(alphas, packed_info, prefix_trans=None):
+    """volrend.py:200-206."""
+    trans = exclusive_prod(np.float32(1.0) - _f32(alphas), packed_info)
+    if prefix_trans is not None:
+        trans = trans * _f32(prefix_trans)
+    return trans
+
+
+def render_transmittance_from_density(t_starts, t_ends, sigmas, packed_info, prefix_trans=None):
+    """volrend.py:256-264."""
+    sigmas_dt = _f32(sigmas) * (_f32(t_ends) - _f32(t_starts))
+    alphas = np.float32(1.0) - np.exp(-sigmas_dt)
+    trans = np.exp(-exclusive_sum(sigmas_dt, packed_info))
+    if prefix_trans is not None:
+        trans = trans * _f32(prefix_trans)
+    return trans.astype(np.float32), alphas.astype(np.float32)
+
+
+def render_weight_from_alpha(alphas, packed_info, prefix_trans=None):
+    """volrend.py:305-309."""
+    trans = render_transmittance_from_alpha(alphas, packed_info, prefix_trans)
+    return trans * _f32(alphas), trans
+
+
+def render_weight_from_density(t_starts, t_ends, sigmas, packed_info, prefix_trans=None):
+    """volrend.py:358-362."""
+    trans, alphas = render_transmittance_from_density(t_starts, t_ends, sigmas, packed_info, prefix_trans)
+    return trans * alphas, trans, alphas
+
+
+def render_weight_from_density_backward(t_starts, t_ends, sigmas, packed_info, g_w, g_t=None, g_a=None,
+                                        prefix_trans=None):
+    """Analytic gradient wrt sigmas in float64, used to
+    check the fused HIP backward; cross-checked against torch autograd of the
+    reference's batched path in tests."""
+    ts, te, sg = (np.asarray(a, np.float64) for a in (t_starts, t_ends, sigmas))
+    dt = te - ts
+    x = sg * dt
+    packed_info = _i64(packed_info)
+    gw = np.asarray(g_w, np.float64)
+    gt = np.zeros_like(x) if g_t is None else np.asarray(g_t, np.float64)
+    ga = np.zeros_like(x) if g_a is None else np.asarray(g_a, np.float64)
+    out = np.zeros_like(x)
+    for s, n in packed_info:
+        if n == 0:
+            continue
+        xs = x[s:s + n]
+        T = np.exp(-(np.cumsum(xs) - xs))
+        if prefix_trans is not None:
+            T = T * np.asarray(prefix_trans, np.float64)[s:s + n]
+        e = np.exp(-xs)
+        w = T * (1 - e)
+        q = gw[s:s + n] * w + gt[s:s + n] * T
+        suffix_excl = np.cumsum(q[::-1])[::-1] - q
+        out[s:s + n] = dt[s:s + n] * (gw[s:s + n] * T * e + ga[s:s + n] * e - suffix_excl)
+    return out
+
+
+def render_visibility_from_alpha(alphas, packed_info, early_stop_eps=1e-4, alpha_thre=0.0, prefix_trans=None):
+    """volrend.py:412-418."""
+    trans = render_transmittance_from_alpha(alphas, packed_info, prefix_trans)
+    vis = trans >= np.float32(early_stop_eps)
+    if alpha_thre > 0:
+        vis = vis & (_f32(alphas) >= np.float32(alpha_thre))
+    return vis
+
+
+def render_visibility_from_density(t_starts, t_ends, sigmas, packed_info, early_stop_eps=1e-4,
+                                   alpha_thre=0.0, prefix_trans=None):
+    """volrend.py:474-480."""
+    trans, alphas = render_transmittance_from_density(t_starts, t_ends, sigmas, packed_info, prefix_trans)
+    vis = trans >= np.float32(early_stop_eps)
+    if alpha_thre > 0:
+        vis = vis & (alphas >= np.float32(alpha_thre))
+    return vis
+
+
+def accumulate_along_rays(weights, values, ray_indices, n_rays):
+    """volrend.py:532-547 (index_add_); summed in float64 in sample order."""
+    w = np.asarray(weights, np.float64)
+    src = w[:, None] if values is None else w[:, None] * np.asarray(values, np.float64)
+    out = np.zeros((n_rays, src.shape[-1]), np.float64)
+    np.add.at(out, _i64(ray_indices), src)
+    return out.astype(np.float32)
+
+
+def rendering(t_starts, t_ends, ray_indices, n_rays, rgbs, sigmas=None, alphas=None, render_bkgd=None):
+    """volrend.py:14-158 with the callback's outputs passed in."""
+    pi = pack_info(ray_indices, n_rays)
+    if sigmas is not None:
+        weights, trans, alphas_ = render_weight_from_density(t_starts, t_ends, sigmas, pi)
+    else:
+        weights, trans = render_weight_from_alpha(alphas, pi)
+        alphas_ = _f32(alphas)
+    colors = accumulate_along_rays(weights, rgbs, ray_indices, n_rays)
+    opac = accumulate_along_rays(weights, None, ray_indices, n_rays)
+    mids = ((_f32(t_starts) + _f32(t_ends))[:, None] / np.float32(2.0))
+    depths = accumulate_along_rays(weights, mids, ray_indices, n_rays)
+    depths = depths / np.maximum(opac, np.finfo(np.float32).eps)
+    if render_bkgd is not None:
+        colors = colors + _f32(render_bkgd) * (np.float32(1.0) - opac)
+    return colors, opac, depths, dict(weights=weights, trans=trans, alphas=alphas_)
+
+
+# --------------------------------------------------------------------------- pdf
+def philox_uniform(seed, subsequence, offset):
+    return float(lib().orc_philox_uniform(C.c_uint64(seed), C.c_uint64(subsequence), C.c_uint64(offset)))
+
+
+def philox4x32_10(ctr, key):
+    ctr = np.asarray(ctr, np.uint32)
+    key = np.asarray(key, np.uint32)
+    out = np.zeros(4, np.uint32)
+    lib().orc_philox4x32_10(_p(ctr), _p(key), _p(out))
+    return out
+
+
+def importance_sampling(vals, cdfs, n_intervals_per_ray, stratified=False, packed_info=None,
+                        seed=0, offset=0):
+    """nerfacc/pdf.py:65-131, int overload cuda/csrc/pdf.cu:359-421.
+
+    Returns (interval edges [R, S+1], sample centres [R, S])."""
+    vals, cdfs = _f32(vals), _f32(cdfs)
+    S = int(n_intervals_per_ray)
+    assert S >= 2, "S == 1 reads out of bounds in the reference (pdf.cu:211)"
+    if packed_info is None:
+        lead = vals.shape[:-1]
+        n_rays = int(np.prod(lead)) if lead else 1
+        per = vals.shape[-1]
+        starts = cnts = None
+    else:
+        packed_info = _i64(packed_info)
+        starts = np.ascontiguousarray(packed_info[:, 0])
+        cnts = np.ascontiguousarray(packed_info[:, 1])
+        n_rays, per, lead = starts.shape[0], 0, (starts.shape[0],)
+    out_i = np.empty((n_rays, S + 1), np.float32)
+    out_s = np.empty((n_rays, S), np.float32)
+    lib().orc_importance_sampling(_p(vals), _p(cdfs), _p(starts), _p(cnts), C.c_int64(n_rays),
+                                  C.c_int64(per), C.c_int64(S), C.c_int(bool(stratified)),
+                                  C.c_uint64(seed), C.c_uint64(offset), _p(out_i), _p(out_s))
+    return out_i.reshape(*lead, S + 1), out_s.reshape(*lead, S)
+
+
+def searchsorted(key_vals, query_vals, key_packed_info=None, query_packed_info=None, query_ray_indices=None):
+    """nerfacc/pdf.py:13-62 -> cuda/csrc/pdf.cu:426-456.  Returns (ids_left, ids_right)."""
+    k, q = _f32(key_vals), _f32(query_vals)
+    ks = kc = qs = qc = qr = None
+    k_per = q_per = 0
+    if key_packed_info is not None:
+        kp = _i64(key_packed_info)
+        ks, kc = np.ascontiguousarray(kp[:, 0]), np.ascontiguousarray(kp[:, 1])
+    else:
+        k_per = k.shape[-1]
+    q_rays = 0
+    if query_packed_info is not None:
+        qp = _i64(query_packed_info)
+        qs, qc = np.ascontiguousarray(qp[:, 0]), np.ascontiguousarray(qp[:, 1])
+        q_rays = qs.shape[0]
+        if query_ray_indices is not None:
+            qr = _i64(query_ray_indices)
+    else:
+        q_per = q.shape[-1]
+    l = np.empty(q.shape, np.int64)
+    r = np.empty(q.shape, np.int64)
+    lib().orc_searchsorted(_p(q), _p(qs), _p(qc), _p(qr), C.c_int64(q_rays), C.c_int64(q_per),
+                           C.c_int64(q.size), _p(k), _p(ks), _p(kc), C.c_int64(k_per), _p(l), _p(r))
+    return l, r
+
+
+# --------------------------------------------------------------------------- estimator sampling
+def occgrid_sampling(rays_o, rays_d, binaries, aabbs, sigma_fn=None, alpha_fn=None, near_plane=0.0,
+                     far_plane=1e10, t_min=None, t_max=None, render_step_size=1e-3, early_stop_eps=1e-4,
+                     alpha_thre=0.0, cone_angle=0.0, occs_mean=None, return_all=False):
+    """nerfacc/estimators/occ_grid.py:85-221 (stratified=False)."""
+    rays_o = _f32(rays_o)
+    n = rays_o.shape[0]
+    near = np.full(n, near_plane, np.float32)
+    far = np.full(n, far_plane, np.float32)
+    if t_min is not None:
+        near = np.maximum(near, _f32(t_min))
+    if t_max is not None:
+        far = np.minimum(far, _f32(t_max))
+    iv, sm, _ = traverse_grids(rays_o, rays_d, binaries, aabbs, near, far, render_step_size, cone_angle)
+    t_starts = iv["vals"][iv["is_left"]]
+    t_ends = iv["vals"][iv["is_right"]]
+    ray_indices = sm["ray_indices"]
+    packed_info = sm["packed_info"]
+    full = (ray_indices, t_starts, t_ends, packed_info)
+    if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None or alpha_fn is not None):
+        if occs_mean is not None:
+            alpha_thre = min(alpha_thre, occs_mean)
+        if sigma_fn is not None:
+            sig = sigma_fn(t_starts, t_ends, ray_indices)
+            masks = render_visibility_from_density(t_starts, t_ends, sig, packed_info, early_stop_eps, alpha_thre)
+        else:
+            al = alpha_fn(t_starts, t_ends, ray_indices)
+            masks = render_visibility_from_alpha(al, packed_info, early_stop_eps, alpha_thre)
+        ray_indices, t_starts, t_ends = ray_indices[masks], t_starts[masks], t_ends[masks]
+    if return_all:
+        return (ray_indices, t_starts, t_ends), full
+    return ray_indices, t_starts, t_ends
