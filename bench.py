@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/sec (fwd+bwd) through a 128^3 occupancy grid, 1M-ray batch.
+
+One "step" = one pass of the hot path over one synthetic batch (cfg 2):
+    OccGridEstimator.sampling (traversal + sigma callback + visibility + compaction)
+ -> rendering (rgb/sigma callback, fused weights, fused accumulation)
+ -> loss.backward()  (+ all-reduce of the 4-float parameter gradient when N > 1)
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Inputs are resident in HBM before the timed region.  Rays shard
+across ranks (independent batches, weak scaling); the only collective is the all-reduce of the
+tiny parameter gradient.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+# ----------------------------------------------------------------------------- synthetic workload
+def make_grid(res: int, variant: str, seed: int = 42) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    if variant == "iid10":
+        return rng.random((1, res, res, res)) < 0.10
+    c = (np.arange(res) + 0.5) / res * 2 - 1
+    x, y, z = np.meshgrid(c, c, c, indexing="ij")
+    r = np.sqrt(x * x + y * y + z * z)
+    shell = (r >= 0.50) & (r <= 0.66)                       # ~8.5 % of the cube
+    speckle = rng.random((res, res, res)) < 0.02
+    return (shell | speckle)[None]
+
+
+def make_rays(n_rays: int, variant: str, rank: int = 0, seed: int = 42):
+    if variant == "random":
+        rng = np.random.default_rng(seed + rank)
+        o = rng.standard_normal((n_rays, 3)).astype(np.float32)
+        d = rng.standard_normal((n_rays, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=-1, keepdims=True)
+        return o, d
+    # pinhole camera on a ring around the scene (rank-seeded azimuth), looking at the origin,
+    # fov chosen so the frustum just covers the [-1,1]^3 box; row-major pixel order.
+    side = int(round(math.sqrt(n_rays)))
+    assert side * side == n_rays, "image variant needs a square ray count"
+    t = 1.0 / 2.2
+    u = (np.arange(side, dtype=np.float32) + 0.5) / side * 2 - 1
+    px, py = np.meshgrid(u * t, u * t, indexing="xy")
+    d_cam = np.stack([px, py, np.ones_like(px)], -1).reshape(-1, 3)
+    d_cam /= np.linalg.norm(d_cam, axis=-1, keepdims=True)
+    az = 2 * math.pi * rank / 8.0
+    rot = np.array([[math.cos(az), 0, math.sin(az)], [0, 1, 0], [-math.sin(az), 0, math.cos(az)]], np.float32)
+    d = (d_cam @ rot.T).astype(np.float32)
+    o = np.broadcast_to((np.array([0, 0, -3.2], np.float32) @ rot.T), d.shape).copy()
+    return o, d
+
+
+def make_workload(dev, n_rays: int = 1024 * 1024, res: int = 128, grid: str = "shell10", rays: str = "image",
+                  rank: int = 0):
+    import nerfacc_amd as na
+    b = make_grid(res, grid)
+    o, d = make_rays(n_rays, rays, rank)
+    est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=res, levels=1).to(dev)
+    est.binaries = torch.from_numpy(b).to(dev)
+    est.occs = torch.from_numpy(b.reshape(-1).astype(np.float32)).to(dev)
+    step = 2 * math.sqrt(3) / 1024                          # <= 1024 samples per ray
+    params = torch.nn.Parameter(torch.tensor([1.0, 1.0, 1.0, 1.0], device=dev))   # [sigma scale, r, g, b]
+
+    def base_sigma(ts, te):
+        return 4.0 * (0.5 + 0.5 * torch.sin(20.0 * (ts + te)))
+
+    def sigma_fn(ts, te, ri):                                # used inside sampling (no grad)
+        return base_sigma(ts, te)
+
+    def rgb_sigma_fn(ts, te, ri):                            # used inside rendering (with grad)
+        rgbs = ts[:, None] * params[1:][None, :]
+        return rgbs, base_sigma(ts, te) * params[0]
+
+    return dict(estimator=est, rays_o=torch.from_numpy(o).to(dev), rays_d=torch.from_numpy(d).to(dev),
+                binaries_np=b, rays_np=(o, d), step=step, params=params, sigma_fn=sigma_fn, rgb_sigma_fn=rgb_sigma_fn,
+                n_rays=n_rays, res=res)
+
+
+def run_step(w, world_size: int = 1):
+    import nerfacc_amd as na
+    est, n = w["estimator"], w["n_rays"]
+    ri, ts, te = est.sampling(w["rays_o"], w["rays_d"], sigma_fn=w["sigma_fn"], render_step_size=w["step"],
+                              early_stop_eps=1e-4, alpha_thre=0.0)
+    colors, opac, depth, _ = na.rendering(ts, te, ri, n_rays=n, rgb_sigma_fn=w["rgb_sigma_fn"])
+    loss = colors.sum()
+    w["params"].grad = None
+    loss.backward()
+    if world_size > 1:
+        torch.distributed.all_reduce(w["params"].grad)      # RCCL over xGMI: 16 bytes
+    return ri.numel(), loss
+
+
+# ----------------------------------------------------------------------------- per-kernel timing (HIP events)
+class KernelTimer:
+    """Brackets every native call with HIP events on the stream it is launched on."""
+
+    def __init__(self):
+        self.records = []
+
+    def install(self):
+        from nerfacc_amd import _backend as B
+        self._orig = B.call
+        timer = self
+
+        def timed_call(name, *args):
+            key = name
+            if name == "nfa_traverse_grids":
+                key = "nfa_traverse_grids[mode=%d]" % args[0]._obj.mode
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            timer._orig(name, *args)
+            e1.record()
+            timer.records.append((key, e0, e1))
+
+        B.call = timed_call
+        for mod in list(sys.modules.values()):
+            if getattr(mod, "__name__", "").startswith("nerfacc_amd") and getattr(mod, "B", None) is B:
+                pass  # modules reach call() through the B namespace, nothing else to patch
+
+    def uninstall(self):
+        from nerfacc_amd import _backend as B
+        B.call = self._orig
+
+    def summary(self, steps):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            a = agg.setdefault(key, [0.0, 0])
+            a[0] += ms; a[1] += 1
+        return {k: dict(ms_per_step=v[0] / steps, launches_per_step=v[1] / steps, ms_per_launch=v[0] / v[1])
+                for k, v in agg.items()}
+
+
+def algorithmic_bytes(R, M, Mv, res, G=1):
+    """compulsory traffic with the API's dtypes, each array touched once."""
+    grid = G * res ** 3
+    return {
+        "nfa_traverse_grids[mode=0]": R * (24 + 8) + grid + R * 8,                 # rays + planes, grid, counts
+        "nfa_traverse_grids[mode=1]": R * (24 + 8) + grid + M * (4 + 4 + 8) + R * 16,  # + samples, packed_info
+        "nfa_render_visibility": M * (4 + 4 + 4) + R * 16 + M * 1 + R * 8,
+        "nfa_compact_samples": M * (1 + 4 + 4) + R * 24 + Mv * 16,
+        "nfa_render_from_density_fwd": Mv * (12 + 12) + R * 16,
+        "nfa_render_from_density_bwd": Mv * (4 + 12 + 4) + R * 16,
+        "nfa_render_accumulate_fwd": Mv * (4 + 12 + 8) + R * (16 + 20),
+        "nfa_render_accumulate_bwd": Mv * (4 + 12 + 8 + 4 + 12) + R * 36,
+    }
+
+
+# ----------------------------------------------------------------------------- CPU baseline (oracle, bounded sample)
+def cpu_baseline(w, sample_rays: int = 65536):
+    """The CPU restatement (oracle/) on every (R/sample)-th ray of the same batch: sampling +
+    rendering forward + analytic backward, timed on the host cores."""
+    from oracle import oracle as O
+    O.build()
+    o, d = w["rays_np"]
+    stride = max(1, o.shape[0] // sample_rays)
+    o, d = np.ascontiguousarray(o[::stride]), np.ascontiguousarray(d[::stride])
+    b = w["binaries_np"]
+    aabb = np.array([[-1, -1, -1, 1, 1, 1]], np.float32)
+
+    def sig(ts, te, ri):
+        return (4.0 * (0.5 + 0.5 * np.sin(20.0 * (ts + te)))).astype(np.float32)
+
+    t0 = time.perf_counter()
+    ri, ts, te = O.occgrid_sampling(o, d, b, aabb, sigma_fn=sig, render_step_size=w["step"], early_stop_eps=1e-4,
+                                    alpha_thre=0.0, occs_mean=float(b.mean()))
+    n = o.shape[0]
+    pi = O.pack_info(ri, n)
+    s = sig(ts, te, ri)
+    wts, tr, al = O.render_weight_from_density(ts, te, s, pi)
+    rgb = np.repeat(ts[:, None], 3, 1)
+    colors = O.accumulate_along_rays(wts, rgb, ri, n)
+    # backward of colors.sum(): g_w = sum_c rgb, then the reverse scan (vectorised restatement)
+    gw = rgb.sum(-1)
+    q = gw * wts
+    suffix = O.packed_scan("exclusive_sum", q, pi, backward=True)
+    gsig = (te - ts) * (gw * tr * (1 - al) - suffix)
+    dt = time.perf_counter() - t0
+    del colors, gsig
+    return dict(value=n / dt, unit="rays/s", cores=O.max_threads(), kind="port",
+                sample=f"{n} rays (every {stride}th ray of the batch), {ri.size} samples, {dt:.2f} s, "
+                       f"C/OpenMP traversal + scans, numpy elementwise")
+
+
+# ----------------------------------------------------------------------------- main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rays", type=int, default=1024 * 1024)
+    ap.add_argument("--res", type=int, default=128)
+    ap.add_argument("--grid", default="shell10", choices=["shell10", "iid10"])
+    ap.add_argument("--ray-variant", default="image", choices=["image", "random"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group(backend="nccl", device_id=dev)
+    assert world == max(1, args.gpus) or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+
+    w = make_workload(dev, args.rays, args.res, args.grid, args.ray_variant, rank)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run_step(w, world)
+    timer = None
+    if not args.no_kernel_timing and rank == 0:
+        timer = KernelTimer(); timer.install()
+    sync()
+    t0 = time.perf_counter()
+    m_last = 0
+    for _ in range(args.steps):
+        m_last, _ = run_step(w, world)
+    sync()
+    dt = time.perf_counter() - t0
+    if timer is not None:
+        ksum = timer.summary(args.steps); timer.uninstall()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * args.rays / (dt / args.steps)
+        out = {
+            "metric": "rays/sec (fwd+bwd) through 128^3 occ-grid, 1M-ray batch",
+            "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg2: {args.rays} {args.ray_variant} rays/GPU, {args.res}^3 {args.grid} occ grid "
+                                   f"(G=1), step 2*sqrt(3)/1024, sampling+rendering fwd+bwd",
+                       "rays_per_gpu": args.rays, "resolution": args.res, "grid": args.grid,
+                       "samples_after_compaction": int(m_last), "parallelism": f"ray-sharded x{world}"},
+        }
+        if timer is not None:
+            # total samples before compaction: size of the traversal output, from the estimator
+            import nerfacc_amd as na
+            ri, ts, te, pi = na.grid._traverse_samples(
+                w["rays_o"], w["rays_d"], w["estimator"].binaries, w["estimator"].aabbs,
+                torch.zeros(args.rays, device=dev), torch.full((args.rays,), 1e10, device=dev), w["step"], 0.0)
+            M = int(ri.numel())
+            ab = algorithmic_bytes(args.rays, M, int(m_last), args.res)
+            kernels = {}
+            for k, v in ksum.items():
+                entry = dict(v)
+                if k in ab:
+                    per_launch = ab[k] / max(v["launches_per_step"], 1e-9)
+                    entry["algorithmic_bytes_per_launch"] = per_launch
+                    entry["achieved_GBps"] = per_launch / (v["ms_per_launch"] * 1e-3) / 1e9
+                kernels[k] = entry
+            dom = max((k for k in kernels if k in ab), key=lambda k: kernels[k]["ms_per_step"])
+            a = kernels[dom]["achieved_GBps"]
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": a / HBM_PEAK_GBPS, "traffic": None,
+                               "ms_per_launch": kernels[dom]["ms_per_launch"],
+                               "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"]}
+            out["kernels"] = kernels
+            out["config"]["samples_before_compaction"] = M
+            native_ms = sum(v["ms_per_step"] for v in ksum.values())
+            out["native_ms_per_step"] = native_ms
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

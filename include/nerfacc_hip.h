@@ -1,0 +1,226 @@
+/*
+ * nerfacc_hip.h -- C ABI of libnerfacc_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for nerfacc's native hot path.  The reference
+ * binds its native layer through pybind11/ATen (nerfacc/cuda/csrc/nerfacc.cpp:
+ * 100-129, resolved lazily by nerfacc/cuda/__init__.py:8-41); there is no C ABI
+ * upstream.  Each entry point below replaces one of those pybind symbols (or
+ * one ATen composite the Python layer builds around them) and takes only plain
+ * device pointers, sizes and a stream: no torch types cross this line.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - fp32 data, int64 indices/counts, uint8 for bool tensors (torch.bool);
+ *   - all work is enqueued on `stream` (hipStream_t passed as void*); nothing
+ *     synchronises unless stated;
+ *   - return value: 0 on success, otherwise a negative NFA_E* code; the text
+ *     of the last error on the calling thread is nfa_last_error();
+ *   - outputs are caller-allocated (the Python host layer allocates them with
+ *     torch so they live in the caching allocator like the reference's).
+ *
+ * Citations "ref:" are relative to /root/reference/nerfacc/.
+ */
+#ifndef NERFACC_HIP_H
+#define NERFACC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFA_OK 0
+#define NFA_EINVAL (-1)   /* bad argument (shape, null pointer, unsupported mode) */
+#define NFA_EHIP (-2)     /* HIP runtime error (launch failure, ...) */
+
+#define NFA_MAX_GRID_LEVELS 8 /* fused in-kernel intersection+sort supports up to this many levels */
+
+typedef void *nfa_stream_t; /* hipStream_t */
+
+const char *nfa_last_error(void);
+int nfa_version(void);          /* 10000*major + 100*minor + patch */
+int nfa_device_arch(char *buf, int buflen); /* gcnArchName of the current device */
+
+/* ------------------------------------------------------------------ utilities */
+
+/* starts[i] = sum(cnts[0..i)), *total = sum(cnts).  `scratch` needs
+ * nfa_cumsum_scratch_bytes(n) bytes.  Replaces torch::cumsum in
+ * ref: cuda/csrc/include/data_spec.hpp:86-105. */
+int64_t nfa_cumsum_scratch_bytes(int64_t n);
+int nfa_exclusive_cumsum_i64(const int64_t *cnts, int64_t n, int64_t *starts, int64_t *total,
+                             void *scratch, nfa_stream_t stream);
+
+/* packed_info[r] = {start, count} of ray r in a ray-sorted index stream; also
+ * reports (flags[0]) whether ray_indices is non-decreasing and in range.
+ * ref: pack.py:38-46 (index_add_ histogram + cumsum). scratch as above (n_rays). */
+int nfa_pack_info(const int64_t *ray_indices, int64_t n, int64_t n_rays, int64_t *packed_info /*[n_rays,2]*/,
+                  int32_t *flags /*[1], set to 1 if unsorted/out of range*/, void *scratch, nfa_stream_t stream);
+
+/* 1 bit per cell copy of a torch.bool grid [n_cells] (derived cache, never serialised). */
+int nfa_pack_bits(const uint8_t *binaries, int64_t n_cells, uint32_t *bits /*[(n_cells+31)/32]*/, nfa_stream_t stream);
+
+/* ------------------------------------------------------------------ grid */
+
+/* ref: cuda/csrc/grid.cu:477-519 (ray_aabb_intersect). */
+int nfa_ray_aabb_intersect(const float *rays_o, const float *rays_d, int64_t n_rays,
+                           const float *aabbs, int32_t n_aabbs, float near_plane, float far_plane,
+                           float miss_value, float *t_mins, float *t_maxs, uint8_t *hits,
+                           nfa_stream_t stream);
+
+/* One launch of the traversal, ref: cuda/csrc/grid.cu:68-282 + host :320-474.
+ *
+ * mode 0  count pass  : writes iv_cnts / sm_cnts (whichever is non-null) and terminate_planes.
+ * mode 1  fill pass   : reads iv_starts/iv_cnts, sm_starts/sm_cnts, writes the data arrays.
+ * mode 2  one pass into over-allocated chunks (reads *_starts as the over-allocated offsets,
+ *         honours rays_mask, writes the actual counts to *_cnts and terminate_planes).
+ *
+ * Intersections: pass t_sorted/t_indices/hits as produced by nfa_ray_aabb_intersect + sort,
+ * or all three NULL to have the kernel intersect (and, for n_grids > 1, sort) in registers
+ * (n_grids <= NFA_MAX_GRID_LEVELS).
+ *
+ * Sample-only fast path used by OccGridEstimator.sampling: pass iv_* NULL and
+ * sm_t_starts/sm_t_ends non-null; the kernel then emits (t_starts, t_ends, ray_indices)
+ * per sample directly instead of interval edges + masks (same values as
+ * intervals.vals[is_left] / [is_right], ref: estimators/occ_grid.py:174-177).
+ */
+typedef struct nfa_traverse_args {
+    int64_t n_rays;
+    const float *rays_o;        /* [n_rays,3] */
+    const float *rays_d;        /* [n_rays,3] */
+    const uint8_t *rays_mask;   /* [n_rays] or NULL (mode 2 only) */
+    int32_t n_grids;
+    int32_t res[3];
+    const uint8_t *binaries;    /* [n_grids,res0,res1,res2] torch.bool */
+    const float *aabbs;         /* [n_grids,6] */
+    const uint8_t *hits;        /* [n_rays,n_grids] or NULL */
+    const float *t_sorted;      /* [n_rays,2*n_grids] or NULL */
+    const int64_t *t_indices;   /* [n_rays,2*n_grids] or NULL */
+    const float *near_planes;   /* [n_rays] */
+    const float *far_planes;    /* [n_rays] */
+    float step_size;
+    float cone_angle;
+    int32_t traverse_steps_limit; /* <= 0: none */
+    int32_t mode;
+    /* intervals (all NULL => not computed) */
+    float *iv_vals; int64_t *iv_ray_indices; uint8_t *iv_is_left; uint8_t *iv_is_right;
+    int64_t *iv_starts; int64_t *iv_cnts;
+    /* samples */
+    float *sm_vals; int64_t *sm_ray_indices; uint8_t *sm_is_valid;
+    float *sm_t_starts; float *sm_t_ends;       /* sample-only fast path */
+    int64_t *sm_starts; int64_t *sm_cnts;
+    float *terminate_planes;    /* [n_rays] or NULL */
+} nfa_traverse_args;
+int nfa_traverse_grids(const nfa_traverse_args *args, nfa_stream_t stream);
+
+/* ------------------------------------------------------------------ packed segments */
+
+/* Ownership table for the flat segmented kernels: tile b (NFA_SEG_TILE consecutive element
+ * offsets) owns the rays whose chunk starts inside it.  Requires contiguous chunks
+ * (starts[r+1] == starts[r] + cnts[r]); flags[0] is set to 1 when they are not, in which case
+ * the caller must use the *_generic entry points.  tiles has nfa_seg_num_tiles(n)+1 entries. */
+#define NFA_SEG_TILE 2048
+int64_t nfa_seg_num_tiles(int64_t n_elems);
+int nfa_seg_build_tiles(const int64_t *packed_info /*[n_rays,2]*/, int64_t n_rays, int64_t n_elems,
+                        int32_t *tiles, int32_t *flags, nfa_stream_t stream);
+
+/* kind: 0 inclusive_sum 1 exclusive_sum 2 inclusive_prod 3 exclusive_prod.
+ * reverse != 0 scans each chunk from its last element to its first: the reverse-iterator
+ * launches of ref: cuda/csrc/scan.cu:41-51,100-110 (backward of the sums).
+ * ref: cuda/csrc/scan.cu:9-165,217-257; kernels include/utils_scan.cuh:28-263. */
+int nfa_packed_scan(int kind, int reverse, const int64_t *packed_info, const int32_t *tiles,
+                    int64_t n_rays, int64_t n_elems, const float *inputs, float *outputs,
+                    nfa_stream_t stream);
+/* Any (start,count) chunks (overlapping, unordered, gaps), one wave per ray; also implements
+ * `normalize` (ref: include/utils_scan.cuh:102-110,229-237). */
+int nfa_packed_scan_generic(int kind, int reverse, int normalize, const int64_t *packed_info,
+                            int64_t n_rays, int64_t n_elems, const float *inputs, float *outputs,
+                            nfa_stream_t stream);
+/* grad_in = reverse_{incl|excl}_sum(grad_out * outputs) / max(inputs, 1e-10)
+ * ref: cuda/csrc/scan.cu:169-214 (inclusive), :259-304 (exclusive). kind: 2 or 3. */
+int nfa_packed_prod_backward(int kind, const int64_t *packed_info, const int32_t *tiles,
+                             int64_t n_rays, int64_t n_elems, const float *inputs,
+                             const float *outputs, const float *grad_outputs, float *grad_inputs,
+                             nfa_stream_t stream);
+
+/* Fused transmittance / weights.  ref: volrend.py:256-264,358-362 (density) and
+ * :200-206,305-309 (alpha).  Any of weights/trans/alphas may be NULL. */
+int nfa_render_from_density_fwd(const float *t_starts, const float *t_ends, const float *sigmas,
+                                const float *prefix_trans /*NULL ok*/, const int64_t *packed_info,
+                                const int32_t *tiles, int64_t n_rays, int64_t n_elems,
+                                float *weights, float *trans, float *alphas, nfa_stream_t stream);
+int nfa_render_from_alpha_fwd(const float *alphas, const float *prefix_trans, const int64_t *packed_info,
+                              const int32_t *tiles, int64_t n_rays, int64_t n_elems,
+                              float *weights, float *trans, nfa_stream_t stream);
+/* Backward of the fused density op given the forward's saved trans/alphas:
+ *   B_k = g_w_k T_k (1-a_k) + g_a_k (1-a_k) - sum_{i>k}(g_w_i w_i + g_T_i T_i)
+ *   grad_sigmas = (t_ends - t_starts) * B,  grad_x = B  (either may be NULL). */
+int nfa_render_from_density_bwd(const float *t_starts, const float *t_ends, const float *trans,
+                                const float *alphas, const float *g_weights, const float *g_trans,
+                                const float *g_alphas, const int64_t *packed_info, const int32_t *tiles,
+                                int64_t n_rays, int64_t n_elems, float *grad_sigmas, float *grad_x,
+                                nfa_stream_t stream);
+/*   grad_alphas_k = g_w_k T_k - sum_{i>k}(g_w_i w_i + g_T_i T_i) / max(1 - a_k, 1e-10) */
+int nfa_render_from_alpha_bwd(const float *alphas, const float *trans, const float *g_weights,
+                              const float *g_trans, const int64_t *packed_info, const int32_t *tiles,
+                              int64_t n_rays, int64_t n_elems, float *grad_alphas, nfa_stream_t stream);
+
+/* Visibility mask (ref: volrend.py:412-418,474-480) fused with the per-ray visible count that
+ * the compaction of OccGridEstimator.sampling needs (ref: estimators/occ_grid.py:216-220).
+ * sigmas_or_alphas is sigma when t_starts != NULL, alpha otherwise. vis_cnts may be NULL. */
+int nfa_render_visibility(const float *t_starts, const float *t_ends, const float *sigmas_or_alphas,
+                          const float *prefix_trans, float early_stop_eps, float alpha_thre,
+                          const int64_t *packed_info, const int32_t *tiles, int64_t n_rays,
+                          int64_t n_elems, uint8_t *vis, int64_t *vis_cnts, nfa_stream_t stream);
+/* Boolean-mask compaction of (ray_indices, t_starts, t_ends) with known per-ray output offsets. */
+int nfa_compact_samples(const uint8_t *vis, const float *t_starts, const float *t_ends,
+                        const int64_t *packed_info, const int32_t *tiles, const int64_t *out_starts,
+                        int64_t n_rays, int64_t n_elems, int64_t *out_ray_indices,
+                        float *out_t_starts, float *out_t_ends, nfa_stream_t stream);
+
+/* out[r, :] (+)= sum_i w_i * values[i, :] over ray r's chunk, deterministic order.
+ * values NULL => D = 1 and out = sum w.  accumulate != 0 adds to `out` (accumulate_along_rays_).
+ * ref: volrend.py:483-573 (index_add_). */
+int nfa_accumulate_along_rays(const float *weights, const float *values, int32_t D,
+                              const int64_t *packed_info, const int32_t *tiles, int64_t n_rays,
+                              int64_t n_elems, int accumulate, float *out, nfa_stream_t stream);
+/* Fallback for unsorted ray_indices: atomics, same contract as index_add_. out must be initialised. */
+int nfa_accumulate_along_rays_atomic(const float *weights, const float *values, int32_t D,
+                                     const int64_t *ray_indices, int64_t n_rays, int64_t n_elems,
+                                     float *out, nfa_stream_t stream);
+/* g_w[i] = sum_c g_out[ray(i),c] v[i,c];  g_v[i,c] = g_out[ray(i),c] w[i]. */
+int nfa_accumulate_along_rays_bwd(const float *weights, const float *values, int32_t D,
+                                  const float *g_out, const int64_t *packed_info, const int32_t *tiles,
+                                  int64_t n_rays, int64_t n_elems, float *g_weights, float *g_values,
+                                  nfa_stream_t stream);
+/* The three accumulations of `rendering` in one pass (ref: volrend.py:140-156):
+ * colors[r,3] = sum w rgb, opacities[r] = sum w, depths[r] = sum w (ts+te)/2 (un-normalised). */
+int nfa_render_accumulate_fwd(const float *weights, const float *rgbs, const float *t_starts,
+                              const float *t_ends, const int64_t *packed_info, const int32_t *tiles,
+                              int64_t n_rays, int64_t n_elems, float *colors, float *opacities,
+                              float *depths, nfa_stream_t stream);
+int nfa_render_accumulate_bwd(const float *weights, const float *rgbs, const float *t_starts,
+                              const float *t_ends, const float *g_colors, const float *g_opacities,
+                              const float *g_depths, const int64_t *packed_info, const int32_t *tiles,
+                              int64_t n_rays, int64_t n_elems, float *g_weights, float *g_rgbs,
+                              nfa_stream_t stream);
+
+/* ------------------------------------------------------------------ pdf */
+
+/* ref: cuda/csrc/pdf.cu:359-421 (int overload): S samples + S+1 edges per ray, batched outputs.
+ * Input segments batched (in_packed_info NULL, n_edges_per_ray each) or packed.
+ * stratified: one Philox4x32-10 uniform per ray, subsequence = ray id (pdf.cu:139-144). */
+int nfa_importance_sampling(const float *in_vals, const float *cdfs, const int64_t *in_packed_info,
+                            int64_t n_rays, int64_t n_edges_per_ray, int64_t n_samples,
+                            int stratified, uint64_t seed, uint64_t offset,
+                            float *out_intervals /*[n_rays,S+1]*/, float *out_samples /*[n_rays,S] or NULL*/,
+                            nfa_stream_t stream);
+/* ref: cuda/csrc/pdf.cu:245-286,426-456. Batched query => ray-relative ids. */
+int nfa_searchsorted(const float *q_vals, const int64_t *q_packed_info, const int64_t *q_ray_indices,
+                     int64_t q_n_rays, int64_t q_per_ray, int64_t q_total,
+                     const float *k_vals, const int64_t *k_packed_info, int64_t k_per_ray,
+                     int64_t *ids_left, int64_t *ids_right, nfa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFACC_HIP_H */

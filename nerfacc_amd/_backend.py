@@ -1,0 +1,151 @@
+"""ctypes binding of libnerfacc_hip.so (C ABI: include/nerfacc_hip.h).
+
+This is the counterpart of the reference's ``nerfacc/cuda/__init__.py`` +
+``nerfacc/cuda/_backend.py`` (lazy ``getattr(_C, name)`` over a pybind11 module):
+the library is loaded on first use and every native call goes through
+:func:`call`.  There is NO fallback: if the library cannot be loaded or the
+tensors are not on a ROCm device the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional
+
+import torch
+
+from . import _build
+
+_lock = threading.Lock()
+_lib: Optional[C.CDLL] = None
+
+_vp, _i64, _i32, _f32, _u64, _int = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_int
+
+
+class TraverseArgs(C.Structure):
+    """struct nfa_traverse_args (include/nerfacc_hip.h)."""
+    _fields_ = [
+        ("n_rays", _i64), ("rays_o", _vp), ("rays_d", _vp), ("rays_mask", _vp),
+        ("n_grids", _i32), ("res", _i32 * 3), ("binaries", _vp), ("aabbs", _vp),
+        ("hits", _vp), ("t_sorted", _vp), ("t_indices", _vp),
+        ("near_planes", _vp), ("far_planes", _vp),
+        ("step_size", _f32), ("cone_angle", _f32), ("traverse_steps_limit", _i32), ("mode", _i32),
+        ("iv_vals", _vp), ("iv_ray_indices", _vp), ("iv_is_left", _vp), ("iv_is_right", _vp),
+        ("iv_starts", _vp), ("iv_cnts", _vp),
+        ("sm_vals", _vp), ("sm_ray_indices", _vp), ("sm_is_valid", _vp),
+        ("sm_t_starts", _vp), ("sm_t_ends", _vp), ("sm_starts", _vp), ("sm_cnts", _vp),
+        ("terminate_planes", _vp),
+    ]
+
+
+# name -> argtypes (all return int unless listed in _RESTYPES)
+_SIGS = {
+    "nfa_exclusive_cumsum_i64": [_vp, _i64, _vp, _vp, _vp, _vp],
+    "nfa_pack_info": [_vp, _i64, _i64, _vp, _vp, _vp, _vp],
+    "nfa_pack_bits": [_vp, _i64, _vp, _vp],
+    "nfa_ray_aabb_intersect": [_vp, _vp, _i64, _vp, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
+    "nfa_traverse_grids": [C.POINTER(TraverseArgs), _vp],
+    "nfa_seg_build_tiles": [_vp, _i64, _i64, _vp, _vp, _vp],
+    "nfa_packed_scan": [_int, _int, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
+    "nfa_packed_scan_generic": [_int, _int, _int, _vp, _i64, _i64, _vp, _vp, _vp],
+    "nfa_packed_prod_backward": [_int, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp],
+    "nfa_render_from_density_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
+    "nfa_render_from_alpha_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
+    "nfa_render_from_density_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
+    "nfa_render_from_alpha_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp],
+    "nfa_render_visibility": [_vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
+    "nfa_compact_samples": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
+    "nfa_accumulate_along_rays": [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _int, _vp, _vp],
+    "nfa_accumulate_along_rays_atomic": [_vp, _vp, _i32, _vp, _i64, _i64, _vp, _vp],
+    "nfa_accumulate_along_rays_bwd": [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
+    "nfa_render_accumulate_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
+    "nfa_render_accumulate_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
+    "nfa_importance_sampling": [_vp, _vp, _vp, _i64, _i64, _i64, _int, _u64, _u64, _vp, _vp, _vp],
+    "nfa_searchsorted": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp],
+    "nfa_cumsum_scratch_bytes": [_i64],
+    "nfa_seg_num_tiles": [_i64],
+    "nfa_last_error": [],
+    "nfa_version": [],
+    "nfa_device_arch": [C.c_char_p, _int],
+}
+_RESTYPES = {"nfa_cumsum_scratch_bytes": _i64, "nfa_seg_num_tiles": _i64, "nfa_last_error": C.c_char_p}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+SEG_TILE = 2048  # NFA_SEG_TILE
+
+
+def library_path() -> str:
+    return _build.LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load (building first if the in-tree library is missing or stale and hipcc exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = _build.LIB_PATH
+        if _build.is_stale() and _build.hipcc() is not None:
+            path = _build.build()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "nerfacc_amd: libnerfacc_hip.so is missing and hipcc is not available to build it. "
+                "There is no CPU fallback for the native ops.")
+        lib = C.CDLL(path)
+        for name, argtypes in _SIGS.items():
+            fn = getattr(lib, name)  # AttributeError => header and library disagree
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, _int)
+        _lib = lib
+    return _lib
+
+
+class NativeError(RuntimeError):
+    """Counterpart of the RuntimeError TORCH_CHECK raises in the reference."""
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.nfa_last_error()
+        raise NativeError(f"{name}: {msg.decode() if msg else rc}")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(*tensors: Optional[torch.Tensor]) -> torch.device:
+    """All tensors on one ROCm device (the reference's CHECK_CUDA, utils_cuda.cuh:13-18)."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise NotImplementedError(
+                "nerfacc_amd: this op runs only on a ROCm device (the reference has no CPU "
+                "implementation of its native ops either); got a tensor on " + str(t.device))
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"nerfacc_amd: tensors on different devices ({dev} vs {t.device})")
+    if dev is None:
+        raise RuntimeError("nerfacc_amd: no tensor argument")
+    return dev
+
+
+def seg_num_tiles(n_elems: int) -> int:
+    return n_elems // SEG_TILE + 1
+
+
+def cumsum_scratch(n: int, device) -> torch.Tensor:
+    nbytes = ((max(n, 1) + 2047) // 2048 + 1) * 8
+    return torch.empty(nbytes // 8, dtype=torch.int64, device=device)

@@ -1,0 +1,547 @@
+// grid.hip -- ray/AABB intersection, occupancy-grid traversal, int64 cumsum, pack_info.
+//
+// Hand-written for gfx950 (wave64).  Semantics follow the reference kernels cited below
+// (paths relative to /root/reference/nerfacc/cuda/csrc/); the structure does not: one
+// templated marcher shared by the count / fill / over-allocated launches, optional in-kernel
+// intersection, direct (t_starts, t_ends, ray_indices) emission for the sampler, a device-side
+// int64 scan instead of torch::cumsum, and launch errors are reported.
+//
+// Floating-point contract: this TU is compiled with -ffp-contract=off; every expression is
+// un-fused IEEE fp32 in the reference's source order so that sample counts are bit-identical
+// to oracle/nerfacc_oracle.c.
+#include <stdarg.h>
+
+#include "common.hip.h"
+
+namespace nfa {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------------
+// Slab test, grid.cu:284-313 / include/utils_grid.cuh:10-55.
+__device__ __forceinline__ bool slab_test(const float o[3], const float inv[3], const float *bmin,
+                                          const float *bmax, float near, float far, float &tmin,
+                                          float &tmax)
+{
+    float lo, hi;
+    if (inv[0] >= 0) { tmin = (bmin[0] - o[0]) * inv[0]; tmax = (bmax[0] - o[0]) * inv[0]; }
+    else             { tmin = (bmax[0] - o[0]) * inv[0]; tmax = (bmin[0] - o[0]) * inv[0]; }
+#pragma unroll
+    for (int a = 1; a < 3; ++a) {
+        if (inv[a] >= 0) { lo = (bmin[a] - o[a]) * inv[a]; hi = (bmax[a] - o[a]) * inv[a]; }
+        else             { lo = (bmax[a] - o[a]) * inv[a]; hi = (bmin[a] - o[a]) * inv[a]; }
+        if (tmin > hi || lo > tmax) return false;
+        if (lo > tmin) tmin = lo;
+        if (hi < tmax) tmax = hi;
+    }
+    if (tmax <= 0) return false;
+    tmin = fmaxf(tmin, near);
+    tmax = fminf(tmax, far);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void ray_aabb_kernel(const float *__restrict__ rays_o,
+                                                       const float *__restrict__ rays_d, int64_t n_rays,
+                                                       const float *__restrict__ aabbs, int32_t n_aabbs,
+                                                       float near, float far, float miss,
+                                                       float *__restrict__ t_mins, float *__restrict__ t_maxs,
+                                                       uint8_t *__restrict__ hits)
+{
+    const int64_t numel = n_rays * n_aabbs;
+    for (int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tid < numel;
+         tid += (int64_t)blockDim.x * gridDim.x) {
+        const int64_t r = tid / n_aabbs;
+        const int32_t g = (int32_t)(tid - r * n_aabbs);
+        const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+        const float inv[3] = {1.0f / rays_d[3 * r], 1.0f / rays_d[3 * r + 1], 1.0f / rays_d[3 * r + 2]};
+        float tmin, tmax;
+        const bool hit = slab_test(o, inv, aabbs + 6 * g, aabbs + 6 * g + 3, near, far, tmin, tmax);
+        t_mins[tid] = hit ? tmin : miss;
+        t_maxs[tid] = hit ? tmax : miss;
+        hits[tid] = hit ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Traversal, grid.cu:68-282; helpers include/utils_grid.cuh:58-142.
+
+__device__ __forceinline__ float calc_dt(float t, float cone_angle, float step)
+{
+    return fmaxf(step, fminf(t * cone_angle, 1e10f));  // grid.cu:23-28, utils_math.cuh:1167
+}
+
+// March t_last in whole steps until the step's mid-point reaches `target`
+// (grid.cu:153-163, :196-205).  dt is evaluated once, as in the reference.
+__device__ __forceinline__ float fast_forward(float t_last, float target, float step, float cone_angle)
+{
+    if (step <= 0.0f) return target;
+    const float dt = calc_dt(t_last, cone_angle, step);
+    const float half = dt * 0.5f;
+    while (t_last + half < target) {
+        const float t_new = t_last + dt;
+        if (t_new == t_last) { t_last = target; break; }  // no progress: the reference would spin
+        t_last = t_new;
+    }
+    return t_last;
+}
+
+enum { EMIT_NONE = 0, EMIT_API = 1, EMIT_DIRECT = 2 };
+
+struct RayState {
+    float t_last;
+    bool continuous;
+    int32_t n_intervals;
+    int32_t n_samples;
+};
+
+// One [this_tmin, this_tmax) span inside grid `level`.
+template <int EMIT, bool HAS_IV, bool HAS_SM>
+__device__ __forceinline__ void traverse_span(const nfa_traverse_args &a, int64_t tid, const float o[3],
+                                              const float d[3], const float inv[3], int32_t level,
+                                              float this_tmin, float this_tmax, int64_t iv_base,
+                                              int64_t sm_base, RayState &st)
+{
+    const float eps = 1e-6f;  // grid.cu:95
+    const float step_size = a.step_size, cone = a.cone_angle;
+    const int32_t limit = a.traverse_steps_limit;
+    if (!st.continuous) st.t_last = fast_forward(st.t_last, this_tmin, step_size, cone);
+
+    const float *bmin = a.aabbs + 6 * level, *bmax = bmin + 3;
+    float tdist[3], delta[3];
+    int32_t step[3], cur[3], overflow[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const float resf = (float)a.res[ax];
+        const float extent = bmax[ax] - bmin[ax];
+        const float voxel = extent / resf;
+        const float ray_start = o[ax] + d[ax] * (this_tmin + eps);
+        const float ray_end = o[ax] + d[ax] * (this_tmax - eps);
+        int32_t c = (int32_t)(((ray_start - bmin[ax]) / extent) * resf);  // v_cvt_i32_f32 saturates
+        int32_t f = (int32_t)(((ray_end - bmin[ax]) / extent) * resf);
+        c = max(0, min(c, a.res[ax] - 1));
+        f = max(0, min(f, a.res[ax] - 1));
+        const int32_t start_index = c + (d[ax] > 0.0f ? 1 : 0);
+        const float tmax_ax = ((bmin[ax] + (((float)start_index * voxel) - ray_start)) * inv[ax]) + this_tmin;
+        const float step_f = (d[ax] == 0.0f) ? 0.0f : (d[ax] > 0.0f ? 1.0f : -1.0f);
+        tdist[ax] = (d[ax] == 0.0f) ? this_tmax : tmax_ax;
+        step[ax] = (int32_t)step_f;
+        const float delta_tmp = voxel * inv[ax] * step_f;
+        delta[ax] = (d[ax] == 0.0f) ? this_tmax : delta_tmp;
+        cur[ax] = c;
+        overflow[ax] = f + step[ax];
+    }
+    const int64_t level_base = (int64_t)level * a.res[0] * a.res[1] * a.res[2];
+    int32_t cells_left = a.res[0] + a.res[1] + a.res[2] + 3;  // safety cap, never binding for a valid DDA
+
+    while (limit <= 0 || st.n_samples < limit) {
+        const float t_traverse = fminf(fminf(tdist[0], fminf(tdist[1], tdist[2])), this_tmax);
+        const int64_t cell = level_base + (int64_t)(cur[0] * a.res[1] * a.res[2] + cur[1] * a.res[2] + cur[2]);
+        if (!a.binaries[cell]) {
+            st.t_last = fast_forward(st.t_last, t_traverse, step_size, cone);
+            st.continuous = false;
+        } else {
+            while (limit <= 0 || st.n_samples < limit) {
+                float t_next;
+                if (step_size <= 0.0f) {
+                    t_next = t_traverse;
+                } else {
+                    const float dt = calc_dt(st.t_last, cone, step_size);
+                    if (st.t_last + dt * 0.5f >= t_traverse) break;
+                    t_next = st.t_last + dt;
+                    if (t_next == st.t_last) break;  // no-progress guard (ours)
+                }
+                if (HAS_IV) {
+                    if (EMIT == EMIT_API) {
+                        // Both mask bytes of every edge are written (the reference zero-fills the
+                        // arrays first and only sets the true ones, data_spec.hpp:66-71).
+                        const int64_t idx = iv_base + st.n_intervals;
+                        if (!st.continuous) {
+                            a.iv_vals[idx] = st.t_last; a.iv_ray_indices[idx] = tid;
+                            a.iv_is_left[idx] = 1; a.iv_is_right[idx] = 0;
+                            a.iv_vals[idx + 1] = t_next; a.iv_ray_indices[idx + 1] = tid;
+                            a.iv_is_left[idx + 1] = 0; a.iv_is_right[idx + 1] = 1;
+                        } else {
+                            a.iv_vals[idx] = t_next; a.iv_ray_indices[idx] = tid;
+                            a.iv_is_left[idx - 1] = 1; a.iv_is_left[idx] = 0; a.iv_is_right[idx] = 1;
+                        }
+                    }
+                    st.n_intervals += st.continuous ? 1 : 2;
+                }
+                if (HAS_SM) {
+                    const int64_t idx = sm_base + st.n_samples;
+                    if (EMIT == EMIT_API) {
+                        a.sm_vals[idx] = (t_next + st.t_last) * 0.5f;
+                        a.sm_ray_indices[idx] = tid;
+                        a.sm_is_valid[idx] = 1;
+                    } else if (EMIT == EMIT_DIRECT) {
+                        a.sm_t_starts[idx] = st.t_last;
+                        a.sm_t_ends[idx] = t_next;
+                        a.sm_ray_indices[idx] = tid;
+                    }
+                }
+                st.n_samples++;
+                st.continuous = true;
+                st.t_last = t_next;
+                if (t_next >= t_traverse) break;
+            }
+        }
+        // single_traversal, utils_grid.cuh:116-142
+        const int ax = (tdist[0] < tdist[1] && tdist[0] < tdist[2]) ? 0 : (tdist[1] < tdist[2] ? 1 : 2);
+        bool done;
+        if (ax == 0)      { cur[0] += step[0]; tdist[0] += delta[0]; done = cur[0] == overflow[0]; }
+        else if (ax == 1) { cur[1] += step[1]; tdist[1] += delta[1]; done = cur[1] == overflow[1]; }
+        else              { cur[2] += step[2]; tdist[2] += delta[2]; done = cur[2] == overflow[2]; }
+        if (done || --cells_left <= 0) break;
+    }
+}
+
+// EMIT_NONE  : count pass (mode 0)
+// EMIT_API   : interval edges + masks, sample centres + is_valid (modes 1, 2)
+// EMIT_DIRECT: (t_starts, t_ends, ray_indices) per sample (modes 1, 2)
+// FUSED      : single grid, intersection computed here (t_sorted/t_indices/hits are NULL)
+template <int EMIT, bool HAS_IV, bool HAS_SM, bool FUSED>
+__global__ __launch_bounds__(256) void traverse_kernel(const nfa_traverse_args a)
+{
+    for (int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tid < a.n_rays;
+         tid += (int64_t)blockDim.x * gridDim.x) {
+        const bool overalloc = a.mode == 2;
+        if (overalloc && a.rays_mask != nullptr && !a.rays_mask[tid]) {  // grid.cu:100
+            // (the reference leaves these entries uninitialised; we define them)
+            if (a.terminate_planes) a.terminate_planes[tid] = a.near_planes[tid];
+            if (HAS_IV) a.iv_cnts[tid] = 0;
+            if (HAS_SM) a.sm_cnts[tid] = 0;
+            continue;
+        }
+        int64_t iv_base = 0, sm_base = 0;
+        if (EMIT != EMIT_NONE) {
+            if (a.mode == 1) {  // grid.cu:103-106: nothing to fill for empty rays
+                if (HAS_IV && a.iv_cnts[tid] == 0) continue;
+                if (HAS_SM && a.sm_cnts[tid] == 0) continue;
+            }
+            if (HAS_IV) iv_base = a.iv_starts[tid];
+            if (HAS_SM) sm_base = a.sm_starts[tid];
+        }
+        const float near_plane = a.near_planes[tid], far_plane = a.far_planes[tid];
+        const float o[3] = {a.rays_o[3 * tid], a.rays_o[3 * tid + 1], a.rays_o[3 * tid + 2]};
+        const float d[3] = {a.rays_d[3 * tid], a.rays_d[3 * tid + 1], a.rays_d[3 * tid + 2]};
+        const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
+
+        RayState st;
+        st.t_last = near_plane;
+        st.continuous = false;
+        st.n_intervals = 0;
+        st.n_samples = 0;
+
+        if (FUSED) {
+            // grid.py:158-162 with one grid: events are (t_min: enter 0), (t_max: leave 0).
+            float tmin, tmax;
+            const bool hit = slab_test(o, inv, a.aabbs, a.aabbs + 3, -INFINITY, INFINITY, tmin, tmax);
+            if (hit) {
+                const float this_tmin = fmaxf(tmin, near_plane);
+                const float this_tmax = fminf(tmax, far_plane);
+                if (this_tmin < this_tmax)
+                    traverse_span<EMIT, HAS_IV, HAS_SM>(a, tid, o, d, inv, 0, this_tmin, this_tmax, iv_base,
+                                                        sm_base, st);
+            }
+        } else {
+            const int32_t G = a.n_grids;
+            const uint8_t *hits = a.hits + tid * G;
+            const float *ts = a.t_sorted + tid * 2 * G;
+            const int64_t *ti = a.t_indices + tid * 2 * G;
+            for (int32_t i = 0; i < 2 * G - 1; ++i) {  // grid.cu:125-150
+                const int64_t idx = ti[i];
+                const bool is_entering = idx < G;
+                int32_t level = (int32_t)(idx % G);
+                if (!hits[level]) continue;
+                if (!is_entering) {
+                    const int64_t nidx = ti[i + 1];
+                    if (nidx < G) continue;
+                    level = (int32_t)(nidx % G);
+                    if (!hits[level]) continue;
+                }
+                const float this_tmin = fmaxf(ts[i], near_plane);
+                const float this_tmax = fminf(ts[i + 1], far_plane);
+                if (this_tmin >= this_tmax) continue;
+                traverse_span<EMIT, HAS_IV, HAS_SM>(a, tid, o, d, inv, level, this_tmin, this_tmax, iv_base,
+                                                    sm_base, st);
+            }
+        }
+        if (a.terminate_planes) a.terminate_planes[tid] = st.t_last;
+        if (EMIT == EMIT_NONE || overalloc) {
+            if (HAS_IV) a.iv_cnts[tid] = st.n_intervals;
+            if (HAS_SM) a.sm_cnts[tid] = st.n_samples;
+        }
+    }
+}
+
+template <int EMIT, bool HAS_IV, bool HAS_SM>
+static void launch_traverse(const nfa_traverse_args &a, bool fused, hipStream_t s)
+{
+    const unsigned grid = grid_1d(a.n_rays, 256, 1 << 20);
+    if (fused) hipLaunchKernelGGL((traverse_kernel<EMIT, HAS_IV, HAS_SM, true>), dim3(grid), dim3(256), 0, s, a);
+    else       hipLaunchKernelGGL((traverse_kernel<EMIT, HAS_IV, HAS_SM, false>), dim3(grid), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------
+// int64 exclusive cumsum (replaces torch::cumsum + the .item() of data_spec.hpp:86-96;
+// the total stays on the device, the caller decides when to read it).
+constexpr int CS_THREADS = 256;
+constexpr int CS_ITEMS = 8;
+constexpr int CS_BLOCK = CS_THREADS * CS_ITEMS;  // 2048 elements per workgroup
+
+__device__ __forceinline__ int64_t block_excl_scan_i64(int64_t v, int64_t &block_total, int64_t *lds /*[4+1]*/)
+{
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int64_t incl = wave_incl_sum_i64(v);
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    int64_t wave_off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < CS_THREADS / 64; ++w) {
+        const int64_t x = lds[w];
+        if (w < wave) wave_off += x;
+        tot += x;
+    }
+    __syncthreads();
+    block_total = tot;
+    return wave_off + incl - v;
+}
+
+__global__ __launch_bounds__(CS_THREADS) void cumsum_partials_kernel(const int64_t *__restrict__ in, int64_t n,
+                                                                      int64_t in_stride, int64_t *__restrict__ partials)
+{
+    __shared__ int64_t lds[8];
+    const int64_t base = (int64_t)blockIdx.x * CS_BLOCK + (int64_t)threadIdx.x * CS_ITEMS;
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < CS_ITEMS; ++k)
+        if (base + k < n) s += in[(base + k) * in_stride];
+    int64_t tot;
+    block_excl_scan_i64(s, tot, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+// one workgroup: exclusive scan of the per-block partials in place; total -> *total
+__global__ __launch_bounds__(CS_THREADS) void cumsum_spine_kernel(int64_t *partials, int64_t n_blocks, int64_t *total)
+{
+    __shared__ int64_t lds[8];
+    int64_t carry = 0;
+    for (int64_t base = 0; base < n_blocks; base += CS_THREADS) {
+        const int64_t i = base + threadIdx.x;
+        const int64_t v = i < n_blocks ? partials[i] : 0;
+        int64_t tot;
+        const int64_t ex = block_excl_scan_i64(v, tot, lds);
+        if (i < n_blocks) partials[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && total) *total = carry;
+}
+
+// out_starts[i*out_stride] = exclusive prefix; optionally copies the counts next to it
+// (pairs != 0 writes packed_info rows {start, count}).
+__global__ __launch_bounds__(CS_THREADS) void cumsum_final_kernel(const int64_t *__restrict__ in, int64_t n,
+                                                                   int64_t in_stride,
+                                                                   const int64_t *__restrict__ partials,
+                                                                   int64_t *__restrict__ out, int pairs)
+{
+    __shared__ int64_t lds[8];
+    const int64_t base = (int64_t)blockIdx.x * CS_BLOCK + (int64_t)threadIdx.x * CS_ITEMS;
+    int64_t v[CS_ITEMS];
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < CS_ITEMS; ++k) {
+        v[k] = (base + k < n) ? in[(base + k) * in_stride] : 0;
+        s += v[k];
+    }
+    int64_t tot;
+    int64_t run = partials[blockIdx.x] + block_excl_scan_i64(s, tot, lds);
+#pragma unroll
+    for (int k = 0; k < CS_ITEMS; ++k) {
+        if (base + k < n) {
+            if (pairs) { out[2 * (base + k)] = run; out[2 * (base + k) + 1] = v[k]; }
+            else out[base + k] = run;
+        }
+        run += v[k];
+    }
+}
+
+static int run_cumsum(const int64_t *in, int64_t n, int64_t in_stride, int64_t *out, int pairs, int64_t *total,
+                      void *scratch, hipStream_t s)
+{
+    const int64_t n_blocks = ceil_div64(n > 0 ? n : 1, CS_BLOCK);
+    int64_t *partials = reinterpret_cast<int64_t *>(scratch);
+    hipLaunchKernelGGL(cumsum_partials_kernel, dim3((unsigned)n_blocks), dim3(CS_THREADS), 0, s, in, n, in_stride, partials);
+    hipLaunchKernelGGL(cumsum_spine_kernel, dim3(1), dim3(CS_THREADS), 0, s, partials, n_blocks, total);
+    hipLaunchKernelGGL(cumsum_final_kernel, dim3((unsigned)n_blocks), dim3(CS_THREADS), 0, s, in, n, in_stride, partials, out, pairs);
+    NFA_CHECK_LAUNCH("exclusive_cumsum_i64");
+    return NFA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// pack_info, pack.py:38-46.  Histogram with one atomic per (wave, run of equal indices);
+// for a ray-sorted stream that is ~1 atomic per ray instead of one per sample.
+// cnts of ray r lives at packed[2r+1].
+__global__ __launch_bounds__(256) void pack_hist_kernel(const int64_t *__restrict__ ray_indices, int64_t n,
+                                                        int64_t n_rays, unsigned long long *__restrict__ packed,
+                                                        int32_t *__restrict__ flags)
+{
+    const int lane = lane_id();
+    for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; base < n;
+         base += (int64_t)blockDim.x * gridDim.x) {
+        const int64_t i = base + lane;
+        const bool valid = i < n;
+        const int64_t r = valid ? ray_indices[i] : -1;
+        int64_t prev = __shfl_up(r, 1, NFA_WAVE);
+        if (lane == 0) prev = (i > 0 && valid) ? ray_indices[i - 1] : r;
+        const bool in_range = valid && r >= 0 && r < n_rays;
+        if (valid && (!in_range || r < prev)) atomicOr(flags, 1);
+        const bool head = valid && (lane == 0 || r != prev);
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long live = __ballot(valid);
+        if (head && in_range) {
+            const unsigned long long later = (lane == 63) ? 0ull : (heads >> (lane + 1));
+            const int next = later ? (lane + 1 + __builtin_ctzll(later)) : (int)__builtin_popcountll(live);
+            atomicAdd(&packed[2 * r + 1], (unsigned long long)(next - lane));
+        }
+    }
+}
+
+__global__ void zero_i64_kernel(int64_t *p, int64_t n, int32_t *flags)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)blockDim.x * gridDim.x) p[i] = 0;
+    if (flags && blockIdx.x == 0 && threadIdx.x == 0) *flags = 0;
+}
+
+__global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t *__restrict__ b, int64_t n, uint32_t *__restrict__ bits)
+{
+    const int lane = lane_id();
+    for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; base < n;
+         base += (int64_t)blockDim.x * gridDim.x) {
+        const int64_t i = base + lane;
+        const unsigned long long m = __ballot(i < n && b[i] != 0);
+        if (lane == 0) bits[base >> 5] = (uint32_t)m;
+        if (lane == 32 && base + 32 < n) bits[(base >> 5) + 1] = (uint32_t)(m >> 32);
+    }
+}
+
+}  // namespace nfa
+
+using namespace nfa;
+
+extern "C" {
+
+const char *nfa_last_error(void) { return g_err; }
+int nfa_version(void) { return 100; }
+
+int nfa_device_arch(char *buf, int buflen)
+{
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        set_error("no HIP device");
+        return NFA_EHIP;
+    }
+    snprintf(buf, buflen, "%s", prop.gcnArchName);
+    return NFA_OK;
+}
+
+int64_t nfa_cumsum_scratch_bytes(int64_t n) { return (ceil_div64(n > 0 ? n : 1, CS_BLOCK) + 1) * 8; }
+
+int nfa_exclusive_cumsum_i64(const int64_t *cnts, int64_t n, int64_t *starts, int64_t *total, void *scratch,
+                             nfa_stream_t stream)
+{
+    NFA_REQUIRE(n >= 0 && scratch && (n == 0 || (cnts && starts)), "exclusive_cumsum_i64: bad arguments");
+    return run_cumsum(cnts, n, 1, starts, 0, total, scratch, as_stream(stream));
+}
+
+int nfa_pack_info(const int64_t *ray_indices, int64_t n, int64_t n_rays, int64_t *packed_info, int32_t *flags,
+                  void *scratch, nfa_stream_t stream)
+{
+    NFA_REQUIRE(n >= 0 && n_rays >= 0 && flags && scratch, "pack_info: bad arguments");
+    NFA_REQUIRE(n_rays == 0 || packed_info, "pack_info: packed_info is null");
+    NFA_REQUIRE(n == 0 || ray_indices, "pack_info: ray_indices is null");
+    hipStream_t s = as_stream(stream);
+    // Counts are accumulated in the count slots packed_info[2r+1], then scanned in place.
+    hipLaunchKernelGGL(zero_i64_kernel, dim3(grid_1d(2 * n_rays + 1, 256)), dim3(256), 0, s, packed_info, 2 * n_rays, flags);
+    if (n > 0 && n_rays > 0)
+        hipLaunchKernelGGL(pack_hist_kernel, dim3(grid_1d(n, 256)), dim3(256), 0, s, ray_indices, n, n_rays,
+                           reinterpret_cast<unsigned long long *>(packed_info), flags);
+    NFA_CHECK_LAUNCH("pack_info");
+    if (n_rays == 0) return NFA_OK;
+    return run_cumsum(packed_info + 1, n_rays, 2, packed_info, 1, nullptr, scratch, s);
+}
+
+int nfa_pack_bits(const uint8_t *binaries, int64_t n_cells, uint32_t *bits, nfa_stream_t stream)
+{
+    NFA_REQUIRE(n_cells >= 0 && (n_cells == 0 || (binaries && bits)), "pack_bits: bad arguments");
+    if (n_cells == 0) return NFA_OK;
+    hipLaunchKernelGGL(pack_bits_kernel, dim3(grid_1d(n_cells, 256)), dim3(256), 0, as_stream(stream), binaries, n_cells, bits);
+    NFA_CHECK_LAUNCH("pack_bits");
+    return NFA_OK;
+}
+
+int nfa_ray_aabb_intersect(const float *rays_o, const float *rays_d, int64_t n_rays, const float *aabbs,
+                           int32_t n_aabbs, float near_plane, float far_plane, float miss_value, float *t_mins,
+                           float *t_maxs, uint8_t *hits, nfa_stream_t stream)
+{
+    NFA_REQUIRE(n_rays >= 0 && n_aabbs >= 0, "ray_aabb_intersect: negative size");
+    if (n_rays * (int64_t)n_aabbs == 0) return NFA_OK;
+    NFA_REQUIRE(rays_o && rays_d && aabbs && t_mins && t_maxs && hits, "ray_aabb_intersect: null pointer");
+    hipLaunchKernelGGL(ray_aabb_kernel, dim3(grid_1d(n_rays * n_aabbs, 256)), dim3(256), 0, as_stream(stream), rays_o,
+                       rays_d, n_rays, aabbs, n_aabbs, near_plane, far_plane, miss_value, t_mins, t_maxs, hits);
+    NFA_CHECK_LAUNCH("ray_aabb_intersect");
+    return NFA_OK;
+}
+
+int nfa_traverse_grids(const nfa_traverse_args *pa, nfa_stream_t stream)
+{
+    NFA_REQUIRE(pa != nullptr, "traverse_grids: null args");
+    const nfa_traverse_args &a = *pa;
+    NFA_REQUIRE(a.n_rays >= 0 && a.n_rays < (int64_t)1 << 31, "traverse_grids: n_rays out of range");
+    if (a.n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(a.mode >= 0 && a.mode <= 2, "traverse_grids: mode must be 0, 1 or 2");
+    NFA_REQUIRE(a.rays_o && a.rays_d && a.binaries && a.aabbs && a.near_planes && a.far_planes,
+                "traverse_grids: null input pointer");
+    NFA_REQUIRE(a.n_grids >= 1 && a.res[0] > 0 && a.res[1] > 0 && a.res[2] > 0, "traverse_grids: bad grid shape");
+    NFA_REQUIRE((int64_t)a.res[0] * a.res[1] * a.res[2] < (int64_t)1 << 31, "traverse_grids: grid level too large");
+    const bool fused = !a.t_sorted && !a.t_indices && !a.hits;
+    NFA_REQUIRE(fused || (a.t_sorted && a.t_indices && a.hits),
+                "traverse_grids: t_sorted, t_indices and hits must be given together");
+    NFA_REQUIRE(!fused || a.n_grids == 1, "traverse_grids: in-kernel intersection supports one grid; pass t_sorted/t_indices/hits");
+    NFA_REQUIRE(a.mode != 2 || a.traverse_steps_limit > 0,
+                "traverse_steps_limit must be > 0 when over_allocate is true");  // grid.cu:345
+    const bool has_iv = a.iv_cnts != nullptr, has_sm = a.sm_cnts != nullptr;
+    NFA_REQUIRE(has_iv || has_sm, "traverse_grids: nothing to compute");
+    const bool direct = a.sm_t_starts != nullptr;
+    hipStream_t s = as_stream(stream);
+    if (a.mode == 0) {
+        if (has_iv && has_sm) launch_traverse<EMIT_NONE, true, true>(a, fused, s);
+        else if (has_sm) launch_traverse<EMIT_NONE, false, true>(a, fused, s);
+        else launch_traverse<EMIT_NONE, true, false>(a, fused, s);
+    } else {
+        NFA_REQUIRE(!has_iv || (a.iv_vals && a.iv_ray_indices && a.iv_is_left && a.iv_is_right && a.iv_starts),
+                    "traverse_grids: interval outputs missing");
+        NFA_REQUIRE(!has_sm || a.sm_starts, "traverse_grids: sample starts missing");
+        if (direct) {
+            NFA_REQUIRE(!has_iv && has_sm && a.sm_t_ends && a.sm_ray_indices,
+                        "traverse_grids: direct emission needs sm_t_starts, sm_t_ends, sm_ray_indices and no intervals");
+            launch_traverse<EMIT_DIRECT, false, true>(a, fused, s);
+        } else {
+            NFA_REQUIRE(!has_sm || (a.sm_vals && a.sm_ray_indices && a.sm_is_valid), "traverse_grids: sample outputs missing");
+            if (has_iv && has_sm) launch_traverse<EMIT_API, true, true>(a, fused, s);
+            else if (has_sm) launch_traverse<EMIT_API, false, true>(a, fused, s);
+            else launch_traverse<EMIT_API, true, false>(a, fused, s);
+        }
+    }
+    NFA_CHECK_LAUNCH("traverse_grids");
+    return NFA_OK;
+}
+
+}  // extern "C"

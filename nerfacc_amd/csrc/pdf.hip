@@ -1,0 +1,195 @@
+// pdf.hip -- inverse-CDF importance sampling and per-ray searchsorted.
+//
+// Semantics: /root/reference/nerfacc/cuda/csrc/pdf.cu:98-167 (importance_sampling_kernel),
+// :169-241 (compute_intervels_kernel), :245-286 (searchsorted_kernel), :43-63 (upper_bound).
+// Structure (ours): the two reference kernels are fused; a power-of-two lane group owns one ray,
+// each lane inverts the CDF for one sample, neighbouring samples are exchanged with wave
+// shuffles to form the S+1 interval edges, and a wave writes whole [rays_per_wave, S+1] rows
+// (coalesced).  The per-ray jitter is one Philox4x32-10 draw per RAY (the reference initialises
+// a curand state per sample for the same value, pdf.cu:139-144).
+#include "common.hip.h"
+
+namespace nfa {
+
+__device__ __forceinline__ int64_t upper_bound_f(const float *__restrict__ data, int64_t start, int64_t end, float val)
+{
+    while (start < end) {
+        const int64_t mid = start + ((end - start) >> 1);
+        if (!(data[mid] > val)) start = mid + 1;
+        else end = mid;
+    }
+    return start;
+}
+__device__ __forceinline__ int64_t clamp64(int64_t v, int64_t lo, int64_t hi)
+{
+    const int64_t m = v < hi ? v : hi;
+    return m > lo ? m : lo;
+}
+
+// Philox4x32-10 (Salmon et al. 2011), counter layout of curand_init(seed, subsequence, offset).
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t subsequence, uint64_t offset)
+{
+    const uint64_t blk = offset >> 2;
+    uint32_t c0 = (uint32_t)blk, c1 = (uint32_t)(blk >> 32), c2 = (uint32_t)subsequence, c3 = (uint32_t)(subsequence >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const uint32_t out[4] = {c0, c1, c2, c3};
+    // curand_uniform: x * 2^-32 + 2^-33  (in (0, 1])
+    return (float)out[offset & 3] * 2.3283064365386963e-10f + 1.1641532182693481e-10f;
+}
+
+// L lanes per ray (power of two <= 64); 64 / L rays per wave.
+__global__ __launch_bounds__(256) void importance_sampling_kernel(
+    const float *__restrict__ in_vals, const float *__restrict__ cdfs, const int64_t *__restrict__ in_packed,
+    int64_t n_rays, int64_t n_edges_per_ray, int64_t S, int L, int stratified, uint64_t seed, uint64_t offset,
+    float *__restrict__ out_iv, float *__restrict__ out_sm)
+{
+    const int lane = lane_id();
+    const int gl = lane & (L - 1);            // lane within the ray's group
+    const int rays_per_wave = 64 / L;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r0 = wave * rays_per_wave; r0 < n_rays; r0 += n_waves * rays_per_wave) {
+        const int64_t ray = r0 + lane / L;
+        const bool ray_ok = ray < n_rays;
+        int64_t base = 0, last = 0;
+        if (ray_ok) {
+            if (in_packed) { base = in_packed[2 * ray]; last = base + in_packed[2 * ray + 1] - 1; }
+            else { base = ray * n_edges_per_ray; last = base + n_edges_per_ray - 1; }
+        }
+        float u_floor = 0.f, u_step = 0.f, bias = 0.5f, t_min = 0.f, t_max = 0.f;
+        if (ray_ok) {
+            u_floor = cdfs[base];
+            const float u_ceil = cdfs[last];
+            u_step = (u_ceil - u_floor) / S;
+            if (stratified) bias = philox_uniform(seed, (uint64_t)ray, offset);
+            t_min = in_vals[base];
+            t_max = in_vals[last];
+        }
+        float t_carry = 0.f;  // last sample of the previous block of L samples
+        float t_first = 0.f;
+        for (int64_t s0 = 0; s0 < S; s0 += L) {
+            const int64_t sid = s0 + gl;
+            const bool ok = ray_ok && sid < S;
+            float t = 0.f;
+            if (ok) {  // pdf.cu:133-166
+                const float u = u_floor + (sid + bias) * u_step;
+                const int64_t p = upper_bound_f(cdfs, base, last, u);
+                const int64_t p0 = clamp64(p - 1, base, last), p1 = clamp64(p, base, last);
+                const float u_lower = cdfs[p0], u_upper = cdfs[p1];
+                const float t_lower = in_vals[p0], t_upper = in_vals[p1];
+                if (u_upper - u_lower < 1e-10f) t = (t_lower + t_upper) * 0.5f;
+                else {
+                    const float scaling = (t_upper - t_lower) / (u_upper - u_lower);
+                    t = (u - u_lower) * scaling + t_lower;
+                }
+                if (out_sm) out_sm[ray * S + sid] = t;
+            }
+            // neighbours (pdf.cu:209-239)
+            float t_prev = __shfl_up(t, 1, L);
+            if (gl == 0) t_prev = t_carry;
+            const float t_next = __shfl_down(t, 1, L);
+            if (s0 == 0) t_first = __shfl(t, 0, L);
+            (void)t_first;
+            if (ok) {
+                float *edge = out_iv + ray * (S + 1);
+                if (sid == 0) {
+                    const float half_width = (t_next - t) * 0.5f;  // S >= 2 and L >= 2 guarantee lane 1 holds t_1
+                    edge[0] = fmaxf(t - half_width, t_min);
+                } else {
+                    edge[sid] = (t + t_prev) * 0.5f;
+                    if (sid == S - 1) {
+                        const float half_width = (t - t_prev) * 0.5f;
+                        edge[sid + 1] = fminf(t + half_width, t_max);
+                    }
+                }
+            }
+            t_carry = __shfl(t, L - 1, L);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void searchsorted_kernel(
+    const float *__restrict__ q_vals, const int64_t *__restrict__ q_packed, const int64_t *__restrict__ q_ray_indices,
+    int64_t q_n_rays, int64_t q_per_ray, int64_t q_total, const float *__restrict__ k_vals,
+    const int64_t *__restrict__ k_packed, int64_t k_per_ray, int64_t *__restrict__ ids_left,
+    int64_t *__restrict__ ids_right)
+{
+    const bool q_batched = q_packed == nullptr;
+    for (int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tid < q_total;
+         tid += (int64_t)blockDim.x * gridDim.x) {
+        int64_t ray_id;
+        if (q_batched) ray_id = tid / q_per_ray;
+        else if (q_ray_indices) ray_id = q_ray_indices[tid];
+        else {  // binary_search_chunk_id(tid) - 1, pdf.cu:65-80
+            int64_t s = 0, e = q_n_rays;
+            while (s < e) {
+                const int64_t m = s + ((e - s) >> 1);
+                if (!(q_packed[2 * m] > tid)) s = m + 1; else e = m;
+            }
+            ray_id = s - 1;
+        }
+        int64_t base, last;
+        if (k_packed) { base = k_packed[2 * ray_id]; last = base + k_packed[2 * ray_id + 1] - 1; }
+        else { base = ray_id * k_per_ray; last = base + k_per_ray - 1; }
+        const int64_t p = upper_bound_f(k_vals, base, last, q_vals[tid]);
+        const int64_t l = clamp64(p - 1, base, last), r = clamp64(p, base, last);
+        ids_left[tid] = q_batched ? l - base : l;
+        ids_right[tid] = q_batched ? r - base : r;
+    }
+}
+
+}  // namespace nfa
+
+using namespace nfa;
+
+extern "C" {
+
+int nfa_importance_sampling(const float *in_vals, const float *cdfs, const int64_t *in_packed_info, int64_t n_rays,
+                            int64_t n_edges_per_ray, int64_t n_samples, int stratified, uint64_t seed,
+                            uint64_t offset, float *out_intervals, float *out_samples, nfa_stream_t stream)
+{
+    NFA_REQUIRE(n_rays >= 0, "importance_sampling: negative n_rays");
+    NFA_REQUIRE(n_samples >= 2, "importance_sampling: n_intervals_per_ray must be >= 2 (the reference reads out of bounds for 1, pdf.cu:211)");
+    if (n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(in_vals && cdfs && out_intervals, "importance_sampling: null pointer");
+    NFA_REQUIRE(in_packed_info || n_edges_per_ray >= 1, "importance_sampling: need packed_info or n_edges_per_ray >= 1");
+    int L = 2;
+    while (L < 64 && L < n_samples) L <<= 1;
+    const int64_t rays_per_wave = 64 / L;
+    const int64_t n_waves = ceil_div64(n_rays, rays_per_wave);
+    const unsigned grid = grid_1d(n_waves * 64, 256, 1 << 16);
+    hipLaunchKernelGGL(importance_sampling_kernel, dim3(grid), dim3(256), 0, as_stream(stream), in_vals, cdfs,
+                       in_packed_info, n_rays, n_edges_per_ray, n_samples, L, stratified, seed, offset, out_intervals,
+                       out_samples);
+    NFA_CHECK_LAUNCH("importance_sampling");
+    return NFA_OK;
+}
+
+int nfa_searchsorted(const float *q_vals, const int64_t *q_packed_info, const int64_t *q_ray_indices, int64_t q_n_rays,
+                     int64_t q_per_ray, int64_t q_total, const float *k_vals, const int64_t *k_packed_info,
+                     int64_t k_per_ray, int64_t *ids_left, int64_t *ids_right, nfa_stream_t stream)
+{
+    NFA_REQUIRE(q_total >= 0, "searchsorted: negative size");
+    if (q_total == 0) return NFA_OK;
+    NFA_REQUIRE(q_vals && k_vals && ids_left && ids_right, "searchsorted: null pointer");
+    NFA_REQUIRE(q_packed_info || q_per_ray >= 1, "searchsorted: batched query needs q_per_ray");
+    NFA_REQUIRE(k_packed_info || k_per_ray >= 1, "searchsorted: batched key needs k_per_ray");
+    hipLaunchKernelGGL(searchsorted_kernel, dim3(grid_1d(q_total, 256)), dim3(256), 0, as_stream(stream), q_vals,
+                       q_packed_info, q_ray_indices, q_n_rays, q_per_ray, q_total, k_vals, k_packed_info, k_per_ray,
+                       ids_left, ids_right);
+    NFA_CHECK_LAUNCH("searchsorted");
+    return NFA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1152 @@
+// segscan.hip -- packed-segment ("flattened ray") kernels: scans, fused transmittance /
+// weights forward+backward, visibility + compaction, per-ray accumulation.
+//
+// Design (MI355X, wave64).  The reference scans one ray per 16 threads through a 32-element
+// shared-memory Blelloch tile with ~10 __syncthreads per tile (include/utils_scan.cuh) and
+// builds everything else out of ATen elementwise launches.  Here a single engine streams the
+// flat sample arrays once:
+//   * the flat element range is cut into tiles of NFA_SEG_TILE element offsets; a tile OWNS the
+//     rays whose chunk starts inside it (ownership table built once per packed_info), so every
+//     ray is scanned start-to-end by exactly one wave: no cross-workgroup carry, no atomics,
+//     deterministic results, load balance independent of the ray-length distribution;
+//   * a wave walks its element range in 256-element steps, 16 B per lane per array (coalesced
+//     1 KiB wave loads/stores), does the segmented scan in registers with wave shuffles
+//     (64-lane Hillis-Steele on (value, ray-id) pairs) and carries the open ray across steps;
+//   * segment heads are scattered into a 1 KiB per-wave LDS line from a register-cached window
+//     of packed_info rows (16 B/ray read once); waves never synchronise with each other.
+// The op-specific arithmetic (exp, alpha, weights, gradients, masks, compaction, per-ray sums)
+// is fused into the same pass through small functor structs.
+//
+// Reverse scans (the reference's reverse-iterator launches, scan.cu:41-51) are the same engine
+// with the lane/element order mirrored (DIR = -1).
+#include "common.hip.h"
+
+namespace nfa {
+
+constexpr int SEG_CHUNK = 256;  // elements per wave step (4 per lane)
+constexpr int SEG_WAVES_PER_BLOCK = 4;
+
+// ------------------------------------------------------------------------------------------
+// tile ownership table
+__global__ __launch_bounds__(256) void seg_build_tiles_kernel(const int64_t *__restrict__ packed_info, int64_t n_rays,
+                                                              int64_t n_elems, int64_t n_tiles,
+                                                              int32_t *__restrict__ tiles, int32_t *__restrict__ flags)
+{
+    // thread r (0..n_rays): ray r is the first ray of every tile b with
+    // floor(start[r-1]/TILE) < b <= floor(start[r]/TILE); r == n_rays is the sentinel.
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n_rays;
+         r += (int64_t)blockDim.x * gridDim.x) {
+        int64_t b_lo, b_hi;
+        bool bad = false;
+        if (r < n_rays) {
+            const int64_t s = packed_info[2 * r], n = packed_info[2 * r + 1];
+            int64_t s_prev = -1;
+            if (r > 0) {
+                const int64_t ps = packed_info[2 * r - 2], pn = packed_info[2 * r - 1];
+                s_prev = ps;
+                bad |= (ps + pn != s);
+            }
+            bad |= (n < 0) || (s < 0) || (s + n > n_elems);
+            if (bad) { atomicOr(flags, 1); continue; }
+            b_lo = (s_prev < 0) ? 0 : s_prev / NFA_SEG_TILE + 1;
+            b_hi = s / NFA_SEG_TILE;
+        } else {
+            const int64_t s_prev = n_rays > 0 ? packed_info[2 * n_rays - 2] : -1;
+            b_lo = (s_prev < 0) ? 0 : s_prev / NFA_SEG_TILE + 1;
+            b_hi = n_tiles;  // tiles[n_tiles] is the end sentinel
+            if (s_prev > n_elems) { atomicOr(flags, 1); continue; }
+        }
+        for (int64_t b = b_lo; b <= b_hi && b <= n_tiles; ++b) tiles[b] = (int32_t)r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 16-byte vector helpers (addresses are 16 B aligned when VEC is true)
+template <bool VEC>
+__device__ __forceinline__ void load4(const float *__restrict__ p, int64_t p0, const bool valid[4], float fill,
+                                      float out[4])
+{
+    if (VEC) {
+        if (valid[0] | valid[1] | valid[2] | valid[3]) {
+            const float4 v = *reinterpret_cast<const float4 *>(p + p0);
+            out[0] = valid[0] ? v.x : fill; out[1] = valid[1] ? v.y : fill;
+            out[2] = valid[2] ? v.z : fill; out[3] = valid[3] ? v.w : fill;
+        } else {
+            out[0] = out[1] = out[2] = out[3] = fill;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = valid[j] ? p[p0 + j] : fill;
+    }
+}
+template <bool VEC>
+__device__ __forceinline__ void store4(float *__restrict__ p, int64_t p0, const bool valid[4], const float v[4])
+{
+    if (VEC && valid[0] && valid[1] && valid[2] && valid[3]) {
+        *reinterpret_cast<float4 *>(p + p0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (valid[j]) p[p0 + j] = v[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The engine.  Op interface (all indices j are in ADDRESS order, 0..3, element p0 + j):
+//   static constexpr int NCH;                       scan channels
+//   __device__ float identity(int ch);
+//   __device__ float comb(int ch, float a, float b);   a = earlier in scan order
+//   __device__ void  load(int64_t p0, const bool valid[4]);
+//   __device__ float x(int j, int ch);                scan input of element j
+//   __device__ void  emit(int j, int64_t pos, bool valid, bool is_head, int rid, int prev_rid,
+//                         const float incl[NCH], const float prev[NCH]);
+//        incl = inclusive scan value at this element; prev = inclusive value of the previous
+//        element in scan order (in that element's own ray; exclusive value = is_head ?
+//        identity : prev).  At a head, (prev_rid, prev) is the finished previous ray.
+//   __device__ void  store(int64_t p0, const bool valid[4]);
+//   __device__ void  ray_done(int rid, const float total[NCH]);   last ray of the tile
+//   __device__ void  empty_ray(int rid);
+template <int DIR, class Op>
+__device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__ packed_info,
+                                             const int32_t *__restrict__ tiles, int64_t n_rays, int64_t tile,
+                                             int32_t *__restrict__ hid /* LDS, SEG_CHUNK ints, wave private */)
+{
+    constexpr int NCH = Op::NCH;
+    const int lane = lane_id();
+    const int alane = DIR > 0 ? lane : 63 - lane;  // lane in address order
+    const int32_t r_lo = tiles[tile], r_hi = tiles[tile + 1];
+    if (r_lo >= r_hi) return;
+    const int32_t n_own = r_hi - r_lo;
+    const int64_t e_lo = packed_info[2 * (int64_t)r_lo];
+    const int64_t e_hi = packed_info[2 * (int64_t)(r_hi - 1)] + packed_info[2 * (int64_t)(r_hi - 1) + 1];
+
+    // window of packed_info rows, in walk order v = 0..n_own-1: ray(v) = r_lo + v (fwd) / r_hi-1-v (rev)
+    int32_t v_next = 0, win_base = 0;
+    int64_t win_s = 0, win_n = 0;
+    auto load_window = [&]() {
+        const int32_t v = win_base + lane;
+        if (v < n_own) {
+            const int64_t ray = DIR > 0 ? (int64_t)r_lo + v : (int64_t)r_hi - 1 - v;
+            const longlong2 row = *reinterpret_cast<const longlong2 *>(packed_info + 2 * ray);
+            win_s = row.x; win_n = row.y;
+        }
+    };
+    load_window();
+
+    float carry[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) carry[ch] = op.identity(ch);
+    int32_t carry_rid = -1;
+
+    const int64_t c_first = DIR > 0 ? (e_lo / SEG_CHUNK) * SEG_CHUNK : ((e_hi - 1) / SEG_CHUNK) * SEG_CHUNK;
+    const int64_t n_chunks = e_hi > e_lo ? ((e_hi - 1) / SEG_CHUNK - e_lo / SEG_CHUNK + 1) : 0;
+
+    for (int64_t ci = 0; ci < n_chunks; ++ci) {
+        const int64_t c = c_first + (DIR > 0 ? ci : -ci) * SEG_CHUNK;
+        // ---- segment heads of this chunk -> LDS
+        *reinterpret_cast<int4 *>(hid + 4 * lane) = make_int4(-1, -1, -1, -1);
+        __builtin_amdgcn_wave_barrier();
+        for (;;) {
+            const int32_t v = win_base + lane;
+            const bool live = v >= v_next && v < n_own;
+            const int64_t key = DIR > 0 ? win_s : win_s + win_n - 1;
+            const bool take = live && (DIR > 0 ? key < c + SEG_CHUNK : key >= c);
+            const int32_t ray = DIR > 0 ? r_lo + v : r_hi - 1 - v;
+            if (take) {
+                if (win_n > 0) hid[(int)(key - c)] = ray;
+                else op.empty_ray(ray);
+            }
+            const int cnt = __builtin_popcountll(__ballot(take));
+            v_next += cnt;
+            if (v_next == win_base + 64 && v_next < n_own) { win_base = v_next; load_window(); continue; }
+            break;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int4 h4 = *reinterpret_cast<const int4 *>(hid + 4 * alane);
+        __builtin_amdgcn_wave_barrier();
+        const int32_t hj[4] = {h4.x, h4.y, h4.z, h4.w};
+
+        // ---- load
+        const int64_t p0 = c + 4 * alane;
+        bool valid[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) valid[j] = (p0 + j >= e_lo) && (p0 + j < e_hi);
+        op.load(p0, valid);
+
+        // ---- lane-local inclusive segmented scan, scan order k (address j = DIR>0 ? k : 3-k)
+        float li[4][NCH];
+        int32_t lh[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = DIR > 0 ? k : 3 - k;
+            const int32_t h = valid[j] ? hj[j] : -1;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const float xv = valid[j] ? op.x(j, ch) : op.identity(ch);
+                li[k][ch] = (k == 0 || h >= 0) ? xv : op.comb(ch, li[k - 1 < 0 ? 0 : k - 1][ch], xv);
+            }
+            lh[k] = (k == 0) ? h : max(lh[k - 1 < 0 ? 0 : k - 1], h);
+        }
+        // ---- wave inclusive scan of the lane aggregates
+        float av[NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) av[ch] = li[3][ch];
+        int32_t ah = lh[3];
+#pragma unroll
+        for (int off = 1; off < NFA_WAVE; off <<= 1) {
+            const int32_t uh = __shfl_up(ah, off, NFA_WAVE);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const float uv = __shfl_up(av[ch], off, NFA_WAVE);
+                if (lane >= off && ah < 0) av[ch] = op.comb(ch, uv, av[ch]);
+            }
+            if (lane >= off) ah = max(ah, uh);
+        }
+        // ---- exclusive lane prefix, with the carry of the previous steps folded in
+        float pv[NCH];
+        int32_t ph = __shfl_up(ah, 1, NFA_WAVE);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) pv[ch] = __shfl_up(av[ch], 1, NFA_WAVE);
+        if (lane == 0) {
+            ph = -1;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) pv[ch] = op.identity(ch);
+        }
+        if (ph < 0) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) pv[ch] = op.comb(ch, carry[ch], pv[ch]);
+            ph = carry_rid;
+        }
+        // ---- per element results
+        float prev[NCH];
+        int32_t prev_rid = ph;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) prev[ch] = pv[ch];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = DIR > 0 ? k : 3 - k;
+            float incl[NCH];
+            int32_t rid;
+            if (lh[k] >= 0) {
+                rid = lh[k];
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) incl[ch] = li[k][ch];
+            } else {
+                rid = ph;
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) incl[ch] = op.comb(ch, pv[ch], li[k][ch]);
+            }
+            const bool is_head = valid[j] && hj[j] >= 0;
+            op.emit(j, p0 + j, valid[j], is_head, rid, prev_rid, incl, prev);
+            prev_rid = rid;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) prev[ch] = incl[ch];
+        }
+        op.store(p0, valid);
+        // ---- carry = state after the last element of this step (lane 63, k = 3)
+        carry_rid = __shfl(prev_rid, 63, NFA_WAVE);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) carry[ch] = __shfl(prev[ch], 63, NFA_WAVE);
+    }
+    // remaining owned rays are all empty (their start equals e_hi / e_lo)
+    for (;;) {
+        const int32_t v = win_base + lane;
+        const bool live = v >= v_next && v < n_own;
+        if (live && win_n <= 0) op.empty_ray(DIR > 0 ? r_lo + v : r_hi - 1 - v);
+        v_next = min(win_base + 64, n_own);
+        if (v_next < n_own) { win_base = v_next; load_window(); continue; }
+        break;
+    }
+    if (carry_rid >= 0 && lane == 0) op.ray_done(carry_rid, carry);
+}
+
+template <int DIR, class Op>
+__global__ __launch_bounds__(64 * SEG_WAVES_PER_BLOCK) void seg_kernel(Op op, const int64_t *__restrict__ packed_info,
+                                                                       const int32_t *__restrict__ tiles,
+                                                                       int64_t n_rays, int64_t n_tiles)
+{
+    __shared__ __attribute__((aligned(16))) int32_t hid_all[SEG_WAVES_PER_BLOCK * SEG_CHUNK];
+    const int wave = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * SEG_WAVES_PER_BLOCK + wave;
+    if (tile >= n_tiles) return;
+    seg_run_tile<DIR>(op, packed_info, tiles, n_rays, tile, hid_all + wave * SEG_CHUNK);
+}
+
+template <int DIR, class Op>
+static void launch_seg(const Op &op, const int64_t *packed_info, const int32_t *tiles, int64_t n_rays, int64_t n_elems,
+                       hipStream_t s)
+{
+    const int64_t n_tiles = nfa_seg_num_tiles(n_elems);
+    const unsigned grid = (unsigned)ceil_div64(n_tiles, SEG_WAVES_PER_BLOCK);
+    hipLaunchKernelGGL((seg_kernel<DIR, Op>), dim3(grid), dim3(64 * SEG_WAVES_PER_BLOCK), 0, s, op, packed_info, tiles,
+                       n_rays, n_tiles);
+}
+
+// ------------------------------------------------------------------------------------------
+// Ops.  Each keeps its per-step registers as members (fully unrolled, register resident).
+
+struct OpBase1 {  // one additive channel
+    static constexpr int NCH = 1;
+    __device__ __forceinline__ float identity(int) const { return 0.0f; }
+    __device__ __forceinline__ float comb(int, float a, float b) const { return a + b; }
+    __device__ __forceinline__ void ray_done(int, const float *) const {}
+    __device__ __forceinline__ void empty_ray(int) const {}
+};
+
+// ---- plain scans: scan.cu:9-165 (sum), :127-165 / :217-257 (prod)
+template <bool EXCL, bool PROD, bool VEC>
+struct ScanOp {
+    static constexpr int NCH = 1;
+    const float *in;
+    float *out;
+    float xin[4], res[4];
+    __device__ __forceinline__ float identity(int) const { return PROD ? 1.0f : 0.0f; }
+    __device__ __forceinline__ float comb(int, float a, float b) const { return PROD ? a * b : a + b; }
+    __device__ __forceinline__ void load(int64_t p0, const bool valid[4]) { load4<VEC>(in, p0, valid, identity(0), xin); }
+    __device__ __forceinline__ float x(int j, int) const { return xin[j]; }
+    __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int, int, const float incl[1], const float prev[1])
+    {
+        res[j] = EXCL ? (is_head ? identity(0) : prev[0]) : incl[0];
+    }
+    __device__ __forceinline__ void store(int64_t p0, const bool valid[4]) { store4<VEC>(out, p0, valid, res); }
+    __device__ __forceinline__ void ray_done(int, const float *) const {}
+    __device__ __forceinline__ void empty_ray(int) const {}
+};
+
+// ---- prod backward: reverse {incl,excl} sum of g*out, divided by clamp_min(in, 1e-10)
+//      scan.cu:169-214, :259-304
+template <bool EXCL, bool VEC>
+struct ProdBwdOp : OpBase1 {
+    const float *in, *outv, *g;
+    float *gin;
+    float q[4], den[4], res[4];
+    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    {
+        float o[4], gg[4];
+        load4<VEC>(outv, p0, valid, 0.0f, o);
+        load4<VEC>(g, p0, valid, 0.0f, gg);
+        load4<VEC>(in, p0, valid, 1.0f, den);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = gg[j] * o[j];
+    }
+    __device__ __forceinline__ float x(int j, int) const { return q[j]; }
+    __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int, int, const float incl[1], const float prev[1])
+    {
+        const float sres = EXCL ? (is_head ? 0.0f : prev[0]) : incl[0];
+        res[j] = sres / fmaxf(den[j], 1e-10f);
+    }
+    __device__ __forceinline__ void store(int64_t p0, const bool valid[4]) { store4<VEC>(gin, p0, valid, res); }
+};
+
+// ---- transmittance / alpha / weights from density, volrend.py:256-264, :358-362
+template <bool VEC>
+struct DensityFwdOp : OpBase1 {
+    const float *ts, *te, *sig, *prefix;
+    float *w, *tr, *al;
+    float xs[4], pf[4], rw[4], rt[4], ra[4];
+    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    {
+        float a[4], b[4], s[4];
+        load4<VEC>(ts, p0, valid, 0.0f, a);
+        load4<VEC>(te, p0, valid, 0.0f, b);
+        load4<VEC>(sig, p0, valid, 0.0f, s);
+        if (prefix) load4<VEC>(prefix, p0, valid, 1.0f, pf);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xs[j] = s[j] * (b[j] - a[j]);
+    }
+    __device__ __forceinline__ float x(int j, int) const { return xs[j]; }
+    __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int, int, const float *, const float prev[1])
+    {
+        const float S = is_head ? 0.0f : prev[0];
+        float T = expf(-S);
+        if (prefix) T *= pf[j];
+        const float a = 1.0f - expf(-xs[j]);
+        rt[j] = T; ra[j] = a; rw[j] = T * a;
+    }
+    __device__ __forceinline__ void store(int64_t p0, const bool valid[4])
+    {
+        if (w) store4<VEC>(w, p0, valid, rw);
+        if (tr) store4<VEC>(tr, p0, valid, rt);
+        if (al) store4<VEC>(al, p0, valid, ra);
+    }
+};
+
+// ---- transmittance / weights from alpha, volrend.py:200-206, :305-309
+template <bool VEC>
+struct AlphaFwdOp {
+    static constexpr int NCH = 1;
+    const float *al, *prefix;
+    float *w, *tr;
+    float a4[4], pf[4], rw[4], rt[4];
+    __device__ __forceinline__ float identity(int) const { return 1.0f; }
+    __device__ __forceinline__ float comb(int, float a, float b) const { return a * b; }
+    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    {
+        load4<VEC>(al, p0, valid, 0.0f, a4);
+        if (prefix) load4<VEC>(prefix, p0, valid, 1.0f, pf);
+    }
+    __device__ __forceinline__ float x(int j, int) const { return 1.0f - a4[j]; }
+    __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int, int, const float *, const float prev[1])
+    {
+        float T = is_head ? 1.0f : prev[0];
+        if (prefix) T *= pf[j];
+        rt[j] = T; rw[j] = T * a4[j];
+    }
+    __device__ __forceinline__ void store(int64_t p0, const bool valid[4])
+    {
+        if (w) store4<VEC>(w, p0, valid, rw);
+        if (tr) store4<VEC>(tr, p0, valid, rt);
+    }
+    __device__ __forceinline__ void ray_done(int, const float *) const {}
+    __device__ __forceinline__ void empty_ray(int) const {}
+};
+
+// ---- backward of the fused density op (reverse scan), SURVEY App. A.7
+template <bool VEC>
+struct DensityBwdOp : OpBase1 {
+    const float *ts, *te, *tr, *al, *gw, *gt, *ga;
+    float *gsig, *gx;
+    float T[4], A[4], GW[4], GA[4], dlt[4], q[4], rs[4], rx[4];
+    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    {
+        float a[4], b[4], GT[4];
+        load4<VEC>(ts, p0, valid, 0.0f, a);
+        load4<VEC>(te, p0, valid, 0.0f, b);
+        load4<VEC>(tr, p0, valid, 0.0f, T);
+        load4<VEC>(al, p0, valid, 0.0f, A);
+        if (gw) load4<VEC>(gw, p0, valid, 0.0f, GW); else GW[0] = GW[1] = GW[2] = GW[3] = 0.0f;
+        if (gt) load4<VEC>(gt, p0, valid, 0.0f, GT); else GT[0] = GT[1] = GT[2] = GT[3] = 0.0f;
+        if (ga) load4<VEC>(ga, p0, valid, 0.0f, GA); else GA[0] = GA[1] = GA[2] = GA[3] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dlt[j] = b[j] - a[j];
+            q[j] = GW[j] * (T[j] * A[j]) + GT[j] * T[j];
+        }
+    }
+    __device__ __forceinline__ float x(int j, int) const { return q[j]; }
+    __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int, int, const float *, const float prev[1])
+    {
+        const float E = is_head ? 0.0f : prev[0];
+        const float om = 1.0f - A[j];
+        const float B = GW[j] * T[j] * om + GA[j] * om - E;
+        rx[j] = B; rs[j] = dlt[j] * B;
+    }
+    __device__ __forceinline__ void store(int64_t p0, const bool valid[4])
+    {
+        if (gsig) store4<VEC>(gsig, p0, valid, rs);
+        if (gx) store4<VEC>(gx, p0, valid, rx);
+    }
+};
+
+// ---- backward of the fused alpha op: g_a = g_w T - sum_{i>k}(g_w_i w_i + g_T_i T_i) / max(1-a, 1e-10)
+template <bool VEC>
+struct AlphaBwdOp : OpBase1 {
+    const float *al, *tr, *gw, *gt;
+    float *galpha;
+    float T[4], A[4], GW[4], q[4], res[4];
+    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    {
+        float GT[4];
+        load4<VEC>(tr, p0, valid, 0.0f, T);
+        load4<VEC>(al, p0, valid, 0.0f, A);
+        if (gw) load4<VEC>(gw, p0, valid, 0.0f, GW); else GW[0] = GW[1] = GW[2] = GW[3] = 0.0f;
+        if (gt) load4<VEC>(gt, p0, valid, 0.0f, GT); else GT[0] = GT[1] = GT[2] = GT[3] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = (GW[j] * A[j] + GT[j]) * T[j];
+    }
+    __device__ __forceinline__ float x(int j, int) const { return q[j]; }
+    __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int, int, const float *, const float prev[1])
+    {
+        const float E = is_head ? 0.0f : prev[0];
+        res[j] = GW[j] * T[j] - E / fmaxf(1.0f - A[j], 1e-10f);
+    }
+    __device__ __forceinline__ void store(int64_t p0, const bool valid[4]) { store4<VEC>(galpha, p0, valid, res); }
+};
+
+// ---- visibility mask, volrend.py:412-418 / :474-480 (the per-ray visible count that the
+//      sampler's compaction needs is a second, 1 B/sample pass: MaskCountOp)
+template <bool DENSITY, bool VEC>
+struct VisibilityOp {
+    static constexpr int NCH = 1;
+    const float *ts, *te, *val, *prefix;
+    float eps, thre;
+    uint8_t *vis;
+    float x0[4], a4[4], pf[4];
+    uint8_t m[4];
+    __device__ __forceinline__ float identity(int) const { return DENSITY ? 0.0f : 1.0f; }
+    __device__ __forceinline__ float comb(int, float a, float b) const { return DENSITY ? a + b : a * b; }
+    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    {
+        float s[4];
+        load4<VEC>(val, p0, valid, 0.0f, s);
+        if (prefix) load4<VEC>(prefix, p0, valid, 1.0f, pf);
+        if (DENSITY) {
+            float a[4], b[4];
+            load4<VEC>(ts, p0, valid, 0.0f, a);
+            load4<VEC>(te, p0, valid, 0.0f, b);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { x0[j] = s[j] * (b[j] - a[j]); a4[j] = 1.0f - expf(-x0[j]); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a4[j] = s[j]; x0[j] = 1.0f - s[j]; }
+        }
+    }
+    __device__ __forceinline__ float x(int j, int) const { return x0[j]; }
+    __device__ __forceinline__ void emit(int j, int64_t, bool valid, bool is_head, int, int, const float *, const float prev[1])
+    {
+        float T = DENSITY ? expf(-(is_head ? 0.0f : prev[0])) : (is_head ? 1.0f : prev[0]);
+        if (prefix) T *= pf[j];
+        bool v = T >= eps;
+        if (thre > 0.0f) v = v && (a4[j] >= thre);
+        m[j] = (valid && v) ? 1 : 0;
+    }
+    __device__ __forceinline__ void store(int64_t p0, const bool valid[4])
+    {
+        if (VEC && valid[0] && valid[1] && valid[2] && valid[3]) {
+            *reinterpret_cast<uchar4 *>(vis + p0) = make_uchar4(m[0], m[1], m[2], m[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (valid[j]) vis[p0 + j] = m[j];
+        }
+    }
+    __device__ __forceinline__ void ray_done(int, const float *) const {}
+    __device__ __forceinline__ void empty_ray(int) const {}
+};
+
+// ---- per-ray count of set mask bytes (second pass input of the compaction) and the compaction
+template <bool VEC>
+struct MaskCountOp : OpBase1 {
+    const uint8_t *vis;
+    int64_t *cnts;
+    float m[4];
+    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    {
+        if (VEC && (valid[0] | valid[1] | valid[2] | valid[3])) {
+            const uchar4 v = *reinterpret_cast<const uchar4 *>(vis + p0);
+            m[0] = (valid[0] && v.x) ? 1.0f : 0.0f; m[1] = (valid[1] && v.y) ? 1.0f : 0.0f;
+            m[2] = (valid[2] && v.z) ? 1.0f : 0.0f; m[3] = (valid[3] && v.w) ? 1.0f : 0.0f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = (valid[j] && vis[p0 + j]) ? 1.0f : 0.0f;
+        }
+    }
+    __device__ __forceinline__ float x(int j, int) const { return m[j]; }
+    __device__ __forceinline__ void emit(int, int64_t, bool, bool is_head, int, int prev_rid, const float *, const float prev[1])
+    {
+        if (is_head && prev_rid >= 0) cnts[prev_rid] = (int64_t)prev[0];
+    }
+    __device__ __forceinline__ void store(int64_t, const bool *) const {}
+    __device__ __forceinline__ void ray_done(int rid, const float tot[1]) const { cnts[rid] = (int64_t)tot[0]; }
+    __device__ __forceinline__ void empty_ray(int rid) const { cnts[rid] = 0; }
+};
+
+template <bool VEC>
+struct CompactOp : OpBase1 {
+    const uint8_t *vis;
+    const float *ts, *te;
+    const int64_t *out_starts;
+    int64_t *o_ri;
+    float *o_ts, *o_te;
+    float m[4], a[4], b[4];
+    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = (valid[j] && vis[p0 + j]) ? 1.0f : 0.0f;
+        load4<VEC>(ts, p0, valid, 0.0f, a);
+        load4<VEC>(te, p0, valid, 0.0f, b);
+    }
+    __device__ __forceinline__ float x(int j, int) const { return m[j]; }
+    __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int rid, int, const float *, const float prev[1])
+    {
+        if (m[j] != 0.0f) {
+            const int64_t dst = out_starts[rid] + (int64_t)(is_head ? 0.0f : prev[0]);
+            o_ri[dst] = rid; o_ts[dst] = a[j]; o_te[dst] = b[j];
+        }
+    }
+    __device__ __forceinline__ void store(int64_t, const bool *) const {}
+};
+
+// ---- per-ray accumulation of w * values[:, d0:d0+C], volrend.py:532-547
+template <int C, bool VEC>
+struct AccumOp {
+    static constexpr int NCH = C;
+    const float *w, *vals;  // vals may be null (C == 1): accumulate w
+    int32_t D, d0;
+    float *out;
+    int accumulate;
+    float xv[4][C];
+    __device__ __forceinline__ float identity(int) const { return 0.0f; }
+    __device__ __forceinline__ float comb(int, float a, float b) const { return a + b; }
+    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    {
+        float ww[4];
+        load4<VEC>(w, p0, valid, 0.0f, ww);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch)
+                xv[j][ch] = vals ? (valid[j] ? ww[j] * vals[(p0 + j) * D + d0 + ch] : 0.0f) : ww[j];
+    }
+    __device__ __forceinline__ float x(int j, int ch) const { return xv[j][ch]; }
+    __device__ __forceinline__ void put(int rid, const float *tot) const
+    {
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            float *o = out + (int64_t)rid * D + d0 + ch;
+            *o = accumulate ? *o + tot[ch] : tot[ch];
+        }
+    }
+    __device__ __forceinline__ void emit(int, int64_t, bool, bool is_head, int, int prev_rid, const float *, const float prev[C]) const
+    {
+        if (is_head && prev_rid >= 0) put(prev_rid, prev);
+    }
+    __device__ __forceinline__ void store(int64_t, const bool *) const {}
+    __device__ __forceinline__ void ray_done(int rid, const float tot[C]) const { put(rid, tot); }
+    __device__ __forceinline__ void empty_ray(int rid) const
+    {
+        if (!accumulate)
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) out[(int64_t)rid * D + d0 + ch] = 0.0f;
+    }
+};
+
+template <int C, bool VEC>
+struct AccumBwdOp : OpBase1 {
+    const float *w, *vals, *gout;
+    int32_t D, d0;
+    int first;  // first channel group: g_w is written, later groups add to it
+    float *gw, *gv;
+    float ww[4], res[4];
+    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    {
+        load4<VEC>(w, p0, valid, 0.0f, ww);
+        if (gw && !first) load4<VEC>(gw, p0, valid, 0.0f, res);
+        else res[0] = res[1] = res[2] = res[3] = 0.0f;
+    }
+    __device__ __forceinline__ float x(int, int) const { return 0.0f; }
+    __device__ __forceinline__ void emit(int j, int64_t pos, bool valid, bool, int rid, int, const float *, const float *)
+    {
+        if (!valid) return;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            const float go = gout[(int64_t)rid * D + d0 + ch];
+            if (vals) {
+                res[j] += go * vals[pos * D + d0 + ch];
+                if (gv) gv[pos * D + d0 + ch] = go * ww[j];
+            } else {
+                res[j] += go;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(int64_t p0, const bool valid[4])
+    {
+        if (gw) store4<VEC>(gw, p0, valid, res);
+    }
+};
+
+// ---- the three accumulations of `rendering` fused: colours(3), opacity, depth  (volrend.py:140-151)
+template <bool VEC>
+struct RenderAccumOp {
+    static constexpr int NCH = 5;
+    const float *w, *rgb, *ts, *te;
+    float *colors, *opac, *depth;
+    float xv[4][5];
+    __device__ __forceinline__ float identity(int) const { return 0.0f; }
+    __device__ __forceinline__ float comb(int, float a, float b) const { return a + b; }
+    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    {
+        float ww[4], a[4], b[4];
+        load4<VEC>(w, p0, valid, 0.0f, ww);
+        load4<VEC>(ts, p0, valid, 0.0f, a);
+        load4<VEC>(te, p0, valid, 0.0f, b);
+        float c[12];
+        if (VEC && valid[0] && valid[1] && valid[2] && valid[3]) {
+            const float4 *q = reinterpret_cast<const float4 *>(rgb + 3 * p0);
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+            c[0] = q0.x; c[1] = q0.y; c[2] = q0.z; c[3] = q0.w; c[4] = q1.x; c[5] = q1.y;
+            c[6] = q1.z; c[7] = q1.w; c[8] = q2.x; c[9] = q2.y; c[10] = q2.z; c[11] = q2.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) c[3 * j + k] = valid[j] ? rgb[3 * (p0 + j) + k] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xv[j][0] = ww[j] * c[3 * j]; xv[j][1] = ww[j] * c[3 * j + 1]; xv[j][2] = ww[j] * c[3 * j + 2];
+            xv[j][3] = ww[j];
+            xv[j][4] = ww[j] * ((a[j] + b[j]) / 2.0f);
+        }
+    }
+    __device__ __forceinline__ float x(int j, int ch) const { return xv[j][ch]; }
+    __device__ __forceinline__ void put(int rid, const float *t) const
+    {
+        colors[3 * (int64_t)rid] = t[0]; colors[3 * (int64_t)rid + 1] = t[1]; colors[3 * (int64_t)rid + 2] = t[2];
+        opac[rid] = t[3]; depth[rid] = t[4];
+    }
+    __device__ __forceinline__ void emit(int, int64_t, bool, bool is_head, int, int prev_rid, const float *, const float prev[5]) const
+    {
+        if (is_head && prev_rid >= 0) put(prev_rid, prev);
+    }
+    __device__ __forceinline__ void store(int64_t, const bool *) const {}
+    __device__ __forceinline__ void ray_done(int rid, const float t[5]) const { put(rid, t); }
+    __device__ __forceinline__ void empty_ray(int rid) const
+    {
+        const float z[5] = {0, 0, 0, 0, 0};
+        put(rid, z);
+    }
+};
+
+template <bool VEC>
+struct RenderAccumBwdOp : OpBase1 {
+    const float *w, *rgb, *ts, *te, *gc, *go, *gd;
+    float *gw, *grgb;
+    float ww[4], mid[4], res[4], c[12], gr[12];
+    bool full;
+    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    {
+        float a[4], b[4];
+        load4<VEC>(w, p0, valid, 0.0f, ww);
+        load4<VEC>(ts, p0, valid, 0.0f, a);
+        load4<VEC>(te, p0, valid, 0.0f, b);
+        full = VEC && valid[0] && valid[1] && valid[2] && valid[3];
+        if (full) {
+            const float4 *q = reinterpret_cast<const float4 *>(rgb + 3 * p0);
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+            c[0] = q0.x; c[1] = q0.y; c[2] = q0.z; c[3] = q0.w; c[4] = q1.x; c[5] = q1.y;
+            c[6] = q1.z; c[7] = q1.w; c[8] = q2.x; c[9] = q2.y; c[10] = q2.z; c[11] = q2.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) c[3 * j + k] = valid[j] ? rgb[3 * (p0 + j) + k] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mid[j] = (a[j] + b[j]) / 2.0f;
+    }
+    __device__ __forceinline__ float x(int, int) const { return 0.0f; }
+    __device__ __forceinline__ void emit(int j, int64_t, bool valid, bool, int rid, int, const float *, const float *)
+    {
+        float g = 0.0f;
+        gr[3 * j] = gr[3 * j + 1] = gr[3 * j + 2] = 0.0f;
+        if (valid) {
+            if (gc) {
+                const float g0 = gc[3 * (int64_t)rid], g1 = gc[3 * (int64_t)rid + 1], g2 = gc[3 * (int64_t)rid + 2];
+                g += g0 * c[3 * j] + g1 * c[3 * j + 1] + g2 * c[3 * j + 2];
+                gr[3 * j] = g0 * ww[j]; gr[3 * j + 1] = g1 * ww[j]; gr[3 * j + 2] = g2 * ww[j];
+            }
+            if (go) g += go[rid];
+            if (gd) g += gd[rid] * mid[j];
+        }
+        res[j] = g;
+    }
+    __device__ __forceinline__ void store(int64_t p0, const bool valid[4])
+    {
+        if (gw) store4<VEC>(gw, p0, valid, res);
+        if (grgb) {
+            if (full) {
+                float4 *q = reinterpret_cast<float4 *>(grgb + 3 * p0);
+                q[0] = make_float4(gr[0], gr[1], gr[2], gr[3]);
+                q[1] = make_float4(gr[4], gr[5], gr[6], gr[7]);
+                q[2] = make_float4(gr[8], gr[9], gr[10], gr[11]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (valid[j]) {
+                        grgb[3 * (p0 + j)] = gr[3 * j]; grgb[3 * (p0 + j) + 1] = gr[3 * j + 1]; grgb[3 * (p0 + j) + 2] = gr[3 * j + 2];
+                    }
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// Generic fallback: arbitrary (start, count) chunks, one wave per ray (semantics of
+// include/utils_scan.cuh incl. `normalize`).
+template <bool EXCL, bool PROD>
+__global__ __launch_bounds__(256) void generic_scan_kernel(const int64_t *__restrict__ packed_info, int64_t n_rays,
+                                                           const float *__restrict__ in, float *__restrict__ out,
+                                                           int reverse, int normalize)
+{
+    const int lane = lane_id();
+    const float init = PROD ? 1.0f : 0.0f;
+    for (int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < n_rays;
+         r += ((int64_t)blockDim.x * gridDim.x) >> 6) {
+        const int64_t s = packed_info[2 * r], n = packed_info[2 * r + 1];
+        if (n <= 0) continue;
+        float den = 1.0f;
+        if (normalize) {  // utils_scan.cuh:102-110 / :229-237: divide by the row's inclusive total
+            float tot = init;
+            for (int64_t k = lane; k < n; k += 64) tot = PROD ? tot * in[s + k] : tot + in[s + k];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float u = __shfl_xor(tot, off, 64);
+                tot = PROD ? tot * u : tot + u;
+            }
+            den = fmaxf(tot, 1e-10f);
+        }
+        float carry = init;
+        for (int64_t c = 0; c < n; c += 64) {
+            const int64_t k = c + lane;
+            const int64_t pos = reverse ? s + n - 1 - k : s + k;
+            float v = k < n ? in[pos] : init;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float u = __shfl_up(v, off, 64);
+                if (lane >= off) v = PROD ? u * v : u + v;
+            }
+            v = PROD ? carry * v : carry + v;
+            float prevv = __shfl_up(v, 1, 64);
+            if (lane == 0) prevv = carry;
+            if (k < n) {
+                float o = EXCL ? prevv : v;
+                if (normalize && !(EXCL && k == 0)) o /= den;
+                out[pos] = o;
+            }
+            carry = __shfl(v, 63, 64);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void accumulate_atomic_kernel(const float *__restrict__ w, const float *__restrict__ vals,
+                                                                int32_t D, const int64_t *__restrict__ ri, int64_t n_rays,
+                                                                int64_t n, float *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * D; i += (int64_t)blockDim.x * gridDim.x) {
+        const int64_t e = i / D;
+        const int32_t ch = (int32_t)(i - e * D);
+        const int64_t r = ri[e];
+        if (r < 0 || r >= n_rays) continue;
+        const float v = vals ? w[e] * vals[i] : w[e];
+        atomicAdd(out + r * D + ch, v);
+    }
+}
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+template <typename... P>
+static inline bool all_aligned16(P... p) { return (aligned16(p) && ...); }
+
+}  // namespace nfa
+
+using namespace nfa;
+
+#define SEG_COMMON_CHECKS(name)                                                                         \
+    NFA_REQUIRE(n_rays >= 0 && n_elems >= 0, name ": negative size");                                   \
+    NFA_REQUIRE(n_rays < ((int64_t)1 << 31) - 64, name ": too many rays");                              \
+    if (n_elems == 0 && n_rays == 0) return NFA_OK;                                                      \
+    NFA_REQUIRE(packed_info && tiles, name ": packed_info/tiles is null")
+
+extern "C" {
+
+int64_t nfa_seg_num_tiles(int64_t n_elems) { return n_elems / NFA_SEG_TILE + 1; }
+
+int nfa_seg_build_tiles(const int64_t *packed_info, int64_t n_rays, int64_t n_elems, int32_t *tiles, int32_t *flags,
+                        nfa_stream_t stream)
+{
+    NFA_REQUIRE(n_rays >= 0 && n_elems >= 0 && tiles && flags, "seg_build_tiles: bad arguments");
+    NFA_REQUIRE(n_rays == 0 || packed_info, "seg_build_tiles: packed_info is null");
+    NFA_REQUIRE(n_rays < ((int64_t)1 << 31) - 64, "seg_build_tiles: too many rays");
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(flags, 0, sizeof(int32_t), s) != hipSuccess) { set_error("seg_build_tiles: memset failed"); return NFA_EHIP; }
+    const int64_t n_tiles = nfa_seg_num_tiles(n_elems);
+    hipLaunchKernelGGL(seg_build_tiles_kernel, dim3(grid_1d(n_rays + 1, 256)), dim3(256), 0, s, packed_info, n_rays,
+                       n_elems, n_tiles, tiles, flags);
+    NFA_CHECK_LAUNCH("seg_build_tiles");
+    return NFA_OK;
+}
+
+int nfa_packed_scan(int kind, int reverse, const int64_t *packed_info, const int32_t *tiles, int64_t n_rays,
+                    int64_t n_elems, const float *inputs, float *outputs, nfa_stream_t stream)
+{
+    SEG_COMMON_CHECKS("packed_scan");
+    NFA_REQUIRE(kind >= 0 && kind <= 3, "packed_scan: kind must be 0..3");
+    if (n_elems == 0) return NFA_OK;
+    NFA_REQUIRE(inputs && outputs, "packed_scan: null data pointer");
+    hipStream_t s = as_stream(stream);
+    const bool vec = all_aligned16(inputs, outputs);
+#define NFA_SCAN_CASE(EX, PR)                                                                             \
+    do {                                                                                                  \
+        if (vec) { ScanOp<EX, PR, true> op; op.in = inputs; op.out = outputs;                            \
+            if (reverse) launch_seg<-1>(op, packed_info, tiles, n_rays, n_elems, s);                      \
+            else launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); }                             \
+        else { ScanOp<EX, PR, false> op; op.in = inputs; op.out = outputs;                               \
+            if (reverse) launch_seg<-1>(op, packed_info, tiles, n_rays, n_elems, s);                      \
+            else launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); }                             \
+    } while (0)
+    switch (kind) {
+        case 0: NFA_SCAN_CASE(false, false); break;
+        case 1: NFA_SCAN_CASE(true, false); break;
+        case 2: NFA_SCAN_CASE(false, true); break;
+        default: NFA_SCAN_CASE(true, true); break;
+    }
+#undef NFA_SCAN_CASE
+    NFA_CHECK_LAUNCH("packed_scan");
+    return NFA_OK;
+}
+
+int nfa_packed_scan_generic(int kind, int reverse, int normalize, const int64_t *packed_info, int64_t n_rays,
+                            int64_t n_elems, const float *inputs, float *outputs, nfa_stream_t stream)
+{
+    NFA_REQUIRE(kind >= 0 && kind <= 3 && n_rays >= 0 && n_elems >= 0, "packed_scan_generic: bad arguments");
+    if (n_elems == 0 || n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(packed_info && inputs && outputs, "packed_scan_generic: null pointer");
+    hipStream_t s = as_stream(stream);
+    const unsigned grid = grid_1d(n_rays * 64, 256, 1 << 16);
+    switch (kind) {
+        case 0: hipLaunchKernelGGL((generic_scan_kernel<false, false>), dim3(grid), dim3(256), 0, s, packed_info, n_rays, inputs, outputs, reverse, normalize); break;
+        case 1: hipLaunchKernelGGL((generic_scan_kernel<true, false>), dim3(grid), dim3(256), 0, s, packed_info, n_rays, inputs, outputs, reverse, normalize); break;
+        case 2: hipLaunchKernelGGL((generic_scan_kernel<false, true>), dim3(grid), dim3(256), 0, s, packed_info, n_rays, inputs, outputs, reverse, normalize); break;
+        default: hipLaunchKernelGGL((generic_scan_kernel<true, true>), dim3(grid), dim3(256), 0, s, packed_info, n_rays, inputs, outputs, reverse, normalize); break;
+    }
+    NFA_CHECK_LAUNCH("packed_scan_generic");
+    return NFA_OK;
+}
+
+int nfa_packed_prod_backward(int kind, const int64_t *packed_info, const int32_t *tiles, int64_t n_rays,
+                             int64_t n_elems, const float *inputs, const float *outputs, const float *grad_outputs,
+                             float *grad_inputs, nfa_stream_t stream)
+{
+    SEG_COMMON_CHECKS("packed_prod_backward");
+    NFA_REQUIRE(kind == 2 || kind == 3, "packed_prod_backward: kind must be 2 or 3");
+    if (n_elems == 0) return NFA_OK;
+    NFA_REQUIRE(inputs && outputs && grad_outputs && grad_inputs, "packed_prod_backward: null data pointer");
+    hipStream_t s = as_stream(stream);
+    const bool vec = all_aligned16(inputs, outputs, grad_outputs, grad_inputs);
+#define NFA_PB(EX, V)                                                                                      \
+    do { ProdBwdOp<EX, V> op; op.in = inputs; op.outv = outputs; op.g = grad_outputs; op.gin = grad_inputs; \
+         launch_seg<-1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+    if (kind == 2) { if (vec) NFA_PB(false, true); else NFA_PB(false, false); }
+    else           { if (vec) NFA_PB(true, true); else NFA_PB(true, false); }
+#undef NFA_PB
+    NFA_CHECK_LAUNCH("packed_prod_backward");
+    return NFA_OK;
+}
+
+int nfa_render_from_density_fwd(const float *t_starts, const float *t_ends, const float *sigmas,
+                                const float *prefix_trans, const int64_t *packed_info, const int32_t *tiles,
+                                int64_t n_rays, int64_t n_elems, float *weights, float *trans, float *alphas,
+                                nfa_stream_t stream)
+{
+    SEG_COMMON_CHECKS("render_from_density_fwd");
+    if (n_elems == 0) return NFA_OK;
+    NFA_REQUIRE(t_starts && t_ends && sigmas, "render_from_density_fwd: null input");
+    hipStream_t s = as_stream(stream);
+    const bool vec = all_aligned16(t_starts, t_ends, sigmas, prefix_trans, weights, trans, alphas);
+#define NFA_DF(V)                                                                                          \
+    do { DensityFwdOp<V> op; op.ts = t_starts; op.te = t_ends; op.sig = sigmas; op.prefix = prefix_trans;   \
+         op.w = weights; op.tr = trans; op.al = alphas; launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+    if (vec) NFA_DF(true); else NFA_DF(false);
+#undef NFA_DF
+    NFA_CHECK_LAUNCH("render_from_density_fwd");
+    return NFA_OK;
+}
+
+int nfa_render_from_alpha_fwd(const float *alphas, const float *prefix_trans, const int64_t *packed_info,
+                              const int32_t *tiles, int64_t n_rays, int64_t n_elems, float *weights, float *trans,
+                              nfa_stream_t stream)
+{
+    SEG_COMMON_CHECKS("render_from_alpha_fwd");
+    if (n_elems == 0) return NFA_OK;
+    NFA_REQUIRE(alphas, "render_from_alpha_fwd: null input");
+    hipStream_t s = as_stream(stream);
+    const bool vec = all_aligned16(alphas, prefix_trans, weights, trans);
+#define NFA_AF(V)                                                                                          \
+    do { AlphaFwdOp<V> op; op.al = alphas; op.prefix = prefix_trans; op.w = weights; op.tr = trans;          \
+         launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+    if (vec) NFA_AF(true); else NFA_AF(false);
+#undef NFA_AF
+    NFA_CHECK_LAUNCH("render_from_alpha_fwd");
+    return NFA_OK;
+}
+
+int nfa_render_from_density_bwd(const float *t_starts, const float *t_ends, const float *trans, const float *alphas,
+                                const float *g_weights, const float *g_trans, const float *g_alphas,
+                                const int64_t *packed_info, const int32_t *tiles, int64_t n_rays, int64_t n_elems,
+                                float *grad_sigmas, float *grad_x, nfa_stream_t stream)
+{
+    SEG_COMMON_CHECKS("render_from_density_bwd");
+    if (n_elems == 0) return NFA_OK;
+    NFA_REQUIRE(t_starts && t_ends && trans && alphas && (grad_sigmas || grad_x), "render_from_density_bwd: null pointer");
+    hipStream_t s = as_stream(stream);
+    const bool vec = all_aligned16(t_starts, t_ends, trans, alphas, g_weights, g_trans, g_alphas, grad_sigmas, grad_x);
+#define NFA_DB(V)                                                                                          \
+    do { DensityBwdOp<V> op; op.ts = t_starts; op.te = t_ends; op.tr = trans; op.al = alphas; op.gw = g_weights; \
+         op.gt = g_trans; op.ga = g_alphas; op.gsig = grad_sigmas; op.gx = grad_x;                            \
+         launch_seg<-1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+    if (vec) NFA_DB(true); else NFA_DB(false);
+#undef NFA_DB
+    NFA_CHECK_LAUNCH("render_from_density_bwd");
+    return NFA_OK;
+}
+
+int nfa_render_from_alpha_bwd(const float *alphas, const float *trans, const float *g_weights, const float *g_trans,
+                              const int64_t *packed_info, const int32_t *tiles, int64_t n_rays, int64_t n_elems,
+                              float *grad_alphas, nfa_stream_t stream)
+{
+    SEG_COMMON_CHECKS("render_from_alpha_bwd");
+    if (n_elems == 0) return NFA_OK;
+    NFA_REQUIRE(alphas && trans && grad_alphas, "render_from_alpha_bwd: null pointer");
+    hipStream_t s = as_stream(stream);
+    const bool vec = all_aligned16(alphas, trans, g_weights, g_trans, grad_alphas);
+#define NFA_AB(V)                                                                                          \
+    do { AlphaBwdOp<V> op; op.al = alphas; op.tr = trans; op.gw = g_weights; op.gt = g_trans; op.galpha = grad_alphas; \
+         launch_seg<-1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+    if (vec) NFA_AB(true); else NFA_AB(false);
+#undef NFA_AB
+    NFA_CHECK_LAUNCH("render_from_alpha_bwd");
+    return NFA_OK;
+}
+
+int nfa_render_visibility(const float *t_starts, const float *t_ends, const float *sigmas_or_alphas,
+                          const float *prefix_trans, float early_stop_eps, float alpha_thre,
+                          const int64_t *packed_info, const int32_t *tiles, int64_t n_rays, int64_t n_elems,
+                          uint8_t *vis, int64_t *vis_cnts, nfa_stream_t stream)
+{
+    SEG_COMMON_CHECKS("render_visibility");
+    hipStream_t s = as_stream(stream);
+    if (n_elems > 0) {
+        NFA_REQUIRE(sigmas_or_alphas && vis, "render_visibility: null pointer");
+        const bool density = t_starts != nullptr;
+        NFA_REQUIRE(!density || t_ends, "render_visibility: t_ends is null");
+        // the uchar4 mask store needs 4-byte alignment of vis, the float loads 16
+        const bool vec = all_aligned16(t_starts, t_ends, sigmas_or_alphas, prefix_trans) &&
+                         (reinterpret_cast<uintptr_t>(vis) & 3) == 0;
+#define NFA_VIS(DN, V)                                                                                     \
+    do { VisibilityOp<DN, V> op; op.ts = t_starts; op.te = t_ends; op.val = sigmas_or_alphas; op.prefix = prefix_trans; \
+         op.eps = early_stop_eps; op.thre = alpha_thre; op.vis = vis;                 \
+         launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+        if (density) { if (vec) NFA_VIS(true, true); else NFA_VIS(true, false); }
+        else         { if (vec) NFA_VIS(false, true); else NFA_VIS(false, false); }
+#undef NFA_VIS
+    }
+    if (vis_cnts) {
+        const bool vec = n_elems > 0 && (reinterpret_cast<uintptr_t>(vis) & 3) == 0;
+        if (vec) { MaskCountOp<true> op; op.vis = vis; op.cnts = vis_cnts; launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); }
+        else { MaskCountOp<false> op; op.vis = vis; op.cnts = vis_cnts; launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); }
+    }
+    NFA_CHECK_LAUNCH("render_visibility");
+    return NFA_OK;
+}
+
+int nfa_compact_samples(const uint8_t *vis, const float *t_starts, const float *t_ends, const int64_t *packed_info,
+                        const int32_t *tiles, const int64_t *out_starts, int64_t n_rays, int64_t n_elems,
+                        int64_t *out_ray_indices, float *out_t_starts, float *out_t_ends, nfa_stream_t stream)
+{
+    SEG_COMMON_CHECKS("compact_samples");
+    if (n_elems == 0) return NFA_OK;
+    NFA_REQUIRE(vis && t_starts && t_ends && out_starts, "compact_samples: null input");
+    hipStream_t s = as_stream(stream);
+    const bool vec = all_aligned16(t_starts, t_ends);
+#define NFA_CP(V)                                                                                          \
+    do { CompactOp<V> op; op.vis = vis; op.ts = t_starts; op.te = t_ends; op.out_starts = out_starts;       \
+         op.o_ri = out_ray_indices; op.o_ts = out_t_starts; op.o_te = out_t_ends;                           \
+         launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+    if (vec) NFA_CP(true); else NFA_CP(false);
+#undef NFA_CP
+    NFA_CHECK_LAUNCH("compact_samples");
+    return NFA_OK;
+}
+
+int nfa_accumulate_along_rays(const float *weights, const float *values, int32_t D, const int64_t *packed_info,
+                              const int32_t *tiles, int64_t n_rays, int64_t n_elems, int accumulate, float *out,
+                              nfa_stream_t stream)
+{
+    SEG_COMMON_CHECKS("accumulate_along_rays");
+    NFA_REQUIRE(D >= 1 && (values || D == 1), "accumulate_along_rays: bad D");
+    if (n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(out && (n_elems == 0 || weights), "accumulate_along_rays: null pointer");
+    hipStream_t s = as_stream(stream);
+    const bool vec = all_aligned16(weights);
+    for (int32_t d0 = 0; d0 < D;) {
+        const int32_t c = (D - d0 >= 4) ? 4 : (D - d0);
+#define NFA_ACC(C, V)                                                                                      \
+    do { AccumOp<C, V> op; op.w = weights; op.vals = values; op.D = D; op.d0 = d0; op.out = out;             \
+         op.accumulate = accumulate; launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+        if (vec) { if (c == 4) NFA_ACC(4, true); else if (c == 3) NFA_ACC(3, true); else if (c == 2) NFA_ACC(2, true); else NFA_ACC(1, true); }
+        else     { if (c == 4) NFA_ACC(4, false); else if (c == 3) NFA_ACC(3, false); else if (c == 2) NFA_ACC(2, false); else NFA_ACC(1, false); }
+#undef NFA_ACC
+        d0 += c;
+    }
+    NFA_CHECK_LAUNCH("accumulate_along_rays");
+    return NFA_OK;
+}
+
+int nfa_accumulate_along_rays_atomic(const float *weights, const float *values, int32_t D, const int64_t *ray_indices,
+                                     int64_t n_rays, int64_t n_elems, float *out, nfa_stream_t stream)
+{
+    NFA_REQUIRE(D >= 1 && (values || D == 1) && n_rays >= 0 && n_elems >= 0, "accumulate_along_rays_atomic: bad arguments");
+    if (n_elems == 0 || n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(weights && ray_indices && out, "accumulate_along_rays_atomic: null pointer");
+    hipLaunchKernelGGL(accumulate_atomic_kernel, dim3(grid_1d(n_elems * D, 256)), dim3(256), 0, as_stream(stream), weights,
+                       values, D, ray_indices, n_rays, n_elems, out);
+    NFA_CHECK_LAUNCH("accumulate_along_rays_atomic");
+    return NFA_OK;
+}
+
+int nfa_accumulate_along_rays_bwd(const float *weights, const float *values, int32_t D, const float *g_out,
+                                  const int64_t *packed_info, const int32_t *tiles, int64_t n_rays, int64_t n_elems,
+                                  float *g_weights, float *g_values, nfa_stream_t stream)
+{
+    SEG_COMMON_CHECKS("accumulate_along_rays_bwd");
+    NFA_REQUIRE(D >= 1 && (values || D == 1), "accumulate_along_rays_bwd: bad D");
+    if (n_elems == 0) return NFA_OK;
+    NFA_REQUIRE(weights && g_out && (g_weights || g_values), "accumulate_along_rays_bwd: null pointer");
+    hipStream_t s = as_stream(stream);
+    const bool vec = all_aligned16(weights, g_weights);
+    for (int32_t d0 = 0; d0 < D;) {
+        const int32_t c = (D - d0 >= 4) ? 4 : (D - d0);
+#define NFA_ACB(C, V)                                                                                      \
+    do { AccumBwdOp<C, V> op; op.w = weights; op.vals = values; op.gout = g_out; op.D = D; op.d0 = d0;       \
+         op.first = (d0 == 0); op.gw = g_weights; op.gv = g_values;                                          \
+         launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+        if (vec) { if (c == 4) NFA_ACB(4, true); else if (c == 3) NFA_ACB(3, true); else if (c == 2) NFA_ACB(2, true); else NFA_ACB(1, true); }
+        else     { if (c == 4) NFA_ACB(4, false); else if (c == 3) NFA_ACB(3, false); else if (c == 2) NFA_ACB(2, false); else NFA_ACB(1, false); }
+#undef NFA_ACB
+        d0 += c;
+    }
+    NFA_CHECK_LAUNCH("accumulate_along_rays_bwd");
+    return NFA_OK;
+}
+
+int nfa_render_accumulate_fwd(const float *weights, const float *rgbs, const float *t_starts, const float *t_ends,
+                              const int64_t *packed_info, const int32_t *tiles, int64_t n_rays, int64_t n_elems,
+                              float *colors, float *opacities, float *depths, nfa_stream_t stream)
+{
+    SEG_COMMON_CHECKS("render_accumulate_fwd");
+    if (n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(colors && opacities && depths && (n_elems == 0 || (weights && rgbs && t_starts && t_ends)),
+                "render_accumulate_fwd: null pointer");
+    hipStream_t s = as_stream(stream);
+    const bool vec = all_aligned16(weights, rgbs, t_starts, t_ends);
+#define NFA_RA(V)                                                                                          \
+    do { RenderAccumOp<V> op; op.w = weights; op.rgb = rgbs; op.ts = t_starts; op.te = t_ends;               \
+         op.colors = colors; op.opac = opacities; op.depth = depths;                                         \
+         launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+    if (vec) NFA_RA(true); else NFA_RA(false);
+#undef NFA_RA
+    NFA_CHECK_LAUNCH("render_accumulate_fwd");
+    return NFA_OK;
+}
+
+int nfa_render_accumulate_bwd(const float *weights, const float *rgbs, const float *t_starts, const float *t_ends,
+                              const float *g_colors, const float *g_opacities, const float *g_depths,
+                              const int64_t *packed_info, const int32_t *tiles, int64_t n_rays, int64_t n_elems,
+                              float *g_weights, float *g_rgbs, nfa_stream_t stream)
+{
+    SEG_COMMON_CHECKS("render_accumulate_bwd");
+    if (n_elems == 0) return NFA_OK;
+    NFA_REQUIRE(weights && rgbs && t_starts && t_ends && (g_weights || g_rgbs), "render_accumulate_bwd: null pointer");
+    hipStream_t s = as_stream(stream);
+    const bool vec = all_aligned16(weights, rgbs, t_starts, t_ends, g_weights, g_rgbs);
+#define NFA_RB(V)                                                                                          \
+    do { RenderAccumBwdOp<V> op; op.w = weights; op.rgb = rgbs; op.ts = t_starts; op.te = t_ends;            \
+         op.gc = g_colors; op.go = g_opacities; op.gd = g_depths; op.gw = g_weights; op.grgb = g_rgbs;       \
+         launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+    if (vec) NFA_RB(true); else NFA_RB(false);
+#undef NFA_RB
+    NFA_CHECK_LAUNCH("render_accumulate_bwd");
+    return NFA_OK;
+}
+
+}  // extern "C"

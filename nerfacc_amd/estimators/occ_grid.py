@@ -1,0 +1,235 @@
+"""Occupancy-grid estimator (ref: nerfacc/estimators/occ_grid.py).
+
+``sampling`` is the hot path (ref :85-221): traversal -> user density callback -> visibility ->
+compaction.  The reference does this with 5 boolean-index gathers (5 device syncs) and an
+``occs.mean().item()``; here the traversal emits ``(ray_indices, t_starts, t_ends)`` directly,
+visibility and compaction are two fused passes with one size read-back, and the mean occupancy
+is cached per ``occs`` version.  Buffer names / dtypes match the reference so ``state_dict``s
+interchange (``resolution``, ``aabbs``, ``occs``, ``binaries``).
+
+Grid maintenance (``update_every_n_steps`` & co., ref :223-404) is plain torch, as upstream.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple, Union
+
+import torch
+from torch import Tensor
+
+from .. import _backend as B
+from .._segments import SegInfo, tag_ray_indices, tag_trusted
+from ..grid import _enlarge_aabb, _exclusive_cumsum, _traverse_samples
+from ..volrend import _visibility_native
+from .base import AbstractEstimator
+
+
+class OccGridEstimator(AbstractEstimator):
+    """Occupancy grid transmittance estimator for spatial skipping ("Instant-NGP" style).
+
+    Args:
+        roi_aabb: region of interest ``[xmin, ymin, zmin, xmax, ymax, zmax]``.
+        resolution: cells per axis (int, list or tensor of 3). Default 128.
+        levels: number of nested grids, level ``i`` covering ``roi_aabb`` scaled by ``2**i``.
+    """
+
+    DIM: int = 3
+
+    def __init__(self, roi_aabb: Union[List[int], Tensor], resolution: Union[int, List[int], Tensor] = 128,
+                 levels: int = 1, **kwargs) -> None:
+        super().__init__()
+        if "contraction_type" in kwargs:
+            raise ValueError("`contraction_type` is not supported anymore for nerfacc >= 0.4.0.")
+        if isinstance(resolution, int):
+            resolution = [resolution] * self.DIM
+        if isinstance(resolution, (list, tuple)):
+            resolution = torch.tensor(resolution, dtype=torch.int32)
+        assert isinstance(resolution, Tensor), f"Invalid type: {resolution}!"
+        assert resolution.shape[0] == self.DIM, f"Invalid shape: {resolution}!"
+        if isinstance(roi_aabb, (list, tuple)):
+            roi_aabb = torch.tensor(roi_aabb, dtype=torch.float32)
+        assert isinstance(roi_aabb, Tensor), f"Invalid type: {roi_aabb}!"
+        assert roi_aabb.shape[0] == self.DIM * 2, f"Invalid shape: {roi_aabb}!"
+
+        self.levels = levels
+        self.cells_per_lvl = int(resolution.prod().item())
+        aabbs = torch.stack([_enlarge_aabb(roi_aabb, 2 ** i) for i in range(levels)], dim=0)
+        # persistent state (same names as the reference, occ_grid.py:67-75)
+        self.register_buffer("resolution", resolution)
+        self.register_buffer("aabbs", aabbs)
+        self.register_buffer("occs", torch.zeros(levels * self.cells_per_lvl))
+        self.register_buffer("binaries", torch.zeros([levels] + resolution.tolist(), dtype=torch.bool))
+        # derived helpers
+        self.register_buffer("grid_coords", _meshgrid3d(resolution).reshape(self.cells_per_lvl, self.DIM),
+                             persistent=False)
+        self.register_buffer("grid_indices", torch.arange(self.cells_per_lvl), persistent=False)
+        self._occs_mean_cache = None
+
+    # ------------------------------------------------------------------ hot path
+    def _occs_mean(self) -> float:
+        """``self.occs.mean().item()`` (ref :183) cached until ``occs`` changes."""
+        key = (self.occs.data_ptr(), self.occs._version)
+        if self._occs_mean_cache is None or self._occs_mean_cache[0] != key:
+            self._occs_mean_cache = (key, float(self.occs.mean().item()))
+        return self._occs_mean_cache[1]
+
+    @torch.no_grad()
+    def sampling(
+        self,
+        rays_o: Tensor,  # [n_rays, 3]
+        rays_d: Tensor,  # [n_rays, 3]
+        sigma_fn: Optional[Callable] = None,
+        alpha_fn: Optional[Callable] = None,
+        near_plane: float = 0.0,
+        far_plane: float = 1e10,
+        t_min: Optional[Tensor] = None,  # [n_rays]
+        t_max: Optional[Tensor] = None,  # [n_rays]
+        render_step_size: float = 1e-3,
+        early_stop_eps: float = 1e-4,
+        alpha_thre: float = 0.0,
+        stratified: bool = False,
+        cone_angle: float = 0.0,
+    ) -> Tuple[Tensor, Tensor, Tensor]:
+        """Sampling with spatial skipping; not differentiable.
+
+        Arguments as the reference (occ_grid.py:86-148).  Returns ``(ray_indices LongTensor
+        (n_samples,), t_starts (n_samples,), t_ends (n_samples,))``, ray-sorted.  ``sigma_fn`` /
+        ``alpha_fn`` take ``(t_starts, t_ends, ray_indices)`` and return densities / opacities
+        ``(N,)``; when given (and a threshold is active) invisible samples are dropped.
+        """
+        near_planes = torch.full_like(rays_o[..., 0], fill_value=near_plane)
+        far_planes = torch.full_like(rays_o[..., 0], fill_value=far_plane)
+        if t_min is not None:
+            near_planes = torch.clamp(near_planes, min=t_min)
+        if t_max is not None:
+            far_planes = torch.clamp(far_planes, max=t_max)
+        if stratified:
+            near_planes += torch.rand_like(near_planes) * render_step_size
+
+        ray_indices, t_starts, t_ends, packed_info = _traverse_samples(
+            rays_o, rays_d, self.binaries, self.aabbs, near_planes, far_planes, render_step_size, cone_angle)
+
+        if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None or alpha_fn is not None):
+            alpha_thre = min(alpha_thre, self._occs_mean())
+            seg: SegInfo = tag_trusted(packed_info, t_starts.numel())
+            if sigma_fn is not None:
+                if t_starts.shape[0] != 0:
+                    sigmas = sigma_fn(t_starts, t_ends, ray_indices)
+                else:
+                    sigmas = torch.empty((0,), device=t_starts.device)
+                assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
+                vis, cnts = _visibility_native(seg, t_starts, t_ends, sigmas, None, early_stop_eps, alpha_thre, True)
+            else:
+                if t_starts.shape[0] != 0:
+                    alphas = alpha_fn(t_starts, t_ends, ray_indices)
+                else:
+                    alphas = torch.empty((0,), device=t_starts.device)
+                assert alphas.shape == t_starts.shape, "alphas must have shape of (N,)! Got {}".format(alphas.shape)
+                vis, cnts = _visibility_native(seg, None, None, alphas, None, early_stop_eps, alpha_thre, True)
+            ray_indices, t_starts, t_ends = _compact(seg, vis, cnts, t_starts, t_ends)
+        return ray_indices, t_starts, t_ends
+
+    # ------------------------------------------------------------------ grid maintenance (torch)
+    @torch.no_grad()
+    def update_every_n_steps(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2,
+                             ema_decay: float = 0.95, warmup_steps: int = 256, n: int = 16) -> None:
+        """EMA-update the grid every ``n`` training steps (ref :223-259)."""
+        if not self.training:
+            raise RuntimeError(
+                "You should only call this function only during training. "
+                "Please call _update() directly if you want to update the field during inference.")
+        if step % n == 0:
+            self._update(step=step, occ_eval_fn=occ_eval_fn, occ_thre=occ_thre, ema_decay=ema_decay,
+                         warmup_steps=warmup_steps)
+
+    @torch.no_grad()
+    def mark_invisible_cells(self, K: Tensor, c2w: Tensor, width: int, height: int, near_plane: float = 0.0,
+                             chunk: int = 32 ** 3) -> None:
+        """Set ``occs = -1`` for cells no camera sees (or that sit in front of a camera's near
+        plane); run once before training (ref :262-332)."""
+        assert K.dim() == 3 and K.shape[1:] == (3, 3)
+        assert c2w.dim() == 3 and (c2w.shape[1:] == (3, 4) or c2w.shape[1:] == (4, 4))
+        assert K.shape[0] == c2w.shape[0] or K.shape[0] == 1
+        n_cams = c2w.shape[0]
+        rot = c2w[:, :3, :3].transpose(2, 1)       # world -> camera rotation
+        trans = -rot @ c2w[:, :3, 3:]              # world -> camera translation
+        for lvl, indices in enumerate(self._get_all_cells()):
+            coords = self.grid_coords[indices]
+            lo, hi = self.aabbs[lvl, :3], self.aabbs[lvl, 3:]
+            for i in range(0, len(indices), chunk):
+                ids = indices[i:i + chunk]
+                world = (lo + coords[i:i + chunk] / (self.resolution - 1) * (hi - lo)).T  # (3, chunk)
+                uvd = K @ (rot @ world + trans)                                              # (n_cams, 3, chunk)
+                depth = uvd[:, 2]
+                uv = uvd[:, :2] / uvd[:, 2:]
+                in_image = (depth >= 0) & (uv[:, 0] >= 0) & (uv[:, 0] < width) & (uv[:, 1] >= 0) & (uv[:, 1] < height)
+                seen = ((depth >= near_plane) & in_image).sum(0) / n_cams > 0
+                too_near = ((depth < near_plane) & in_image).any(0)
+                self.occs[lvl * self.cells_per_lvl + ids] = torch.where(seen & ~too_near, 0.0, -1.0)
+
+    @torch.no_grad()
+    def _get_all_cells(self) -> List[Tensor]:
+        """Per level, the indices of cells not marked invisible (occs >= 0)."""
+        out = []
+        for lvl in range(self.levels):
+            keep = self.occs[lvl * self.cells_per_lvl + self.grid_indices] >= 0.0
+            out.append(self.grid_indices[keep])
+        return out
+
+    @torch.no_grad()
+    def _sample_uniform_and_occupied_cells(self, n: int) -> List[Tensor]:
+        """Per level: n uniformly drawn (visible) cells plus up to n occupied cells (ref :345-366)."""
+        out = []
+        for lvl in range(self.levels):
+            uni = torch.randint(self.cells_per_lvl, (n,), device=self.device)
+            uni = uni[self.occs[lvl * self.cells_per_lvl + uni] >= 0.0]
+            occ = torch.nonzero(self.binaries[lvl].flatten())[:, 0]
+            if n < len(occ):
+                occ = occ[torch.randint(len(occ), (n,), device=self.device)]
+            out.append(torch.cat([uni, occ], dim=0))
+        return out
+
+    @torch.no_grad()
+    def _update(self, step: int, occ_eval_fn: Callable, occ_thre: float = 0.01, ema_decay: float = 0.95,
+                warmup_steps: int = 256) -> None:
+        """occs = max(occs * decay, occ(x)) at jittered cell positions, then re-binarise (ref :368-404)."""
+        if step < warmup_steps:
+            lvl_indices = self._get_all_cells()
+        else:
+            lvl_indices = self._sample_uniform_and_occupied_cells(self.cells_per_lvl // 4)
+        for lvl, indices in enumerate(lvl_indices):
+            coords = self.grid_coords[indices]
+            unit = (coords + torch.rand_like(coords, dtype=torch.float32)) / self.resolution
+            x = self.aabbs[lvl, :3] + unit * (self.aabbs[lvl, 3:] - self.aabbs[lvl, :3])
+            occ = occ_eval_fn(x).squeeze(-1)
+            cell_ids = lvl * self.cells_per_lvl + indices
+            self.occs[cell_ids] = torch.maximum(self.occs[cell_ids] * ema_decay, occ)
+        thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre)
+        self.binaries = (self.occs > thre).view(self.binaries.shape)
+
+
+def _compact(seg: SegInfo, vis: Tensor, cnts: Tensor, t_starts: Tensor, t_ends: Tensor):
+    """``x[masks]`` for the sampler's three arrays in one pass (ref :216-220), given the mask and
+    the per-ray visible counts.  One device->host read (the output size)."""
+    dev = t_starts.device
+    n = t_starts.numel()
+    with torch.cuda.device(dev):
+        total = torch.empty(1, dtype=torch.int64, device=dev)
+        out_starts = _exclusive_cumsum(cnts, total)
+        m = int(total.item())
+        ri = torch.empty(m, dtype=torch.int64, device=dev)
+        ts = torch.empty(m, dtype=torch.float32, device=dev)
+        te = torch.empty(m, dtype=torch.float32, device=dev)
+        if m > 0:
+            B.call("nfa_compact_samples", B.ptr(vis), B.ptr(t_starts), B.ptr(t_ends), B.ptr(seg.packed_info),
+                   B.ptr(seg.tiles), B.ptr(out_starts), seg.n_rays, n, B.ptr(ri), B.ptr(ts), B.ptr(te), B.stream())
+        packed = torch.stack([out_starts, cnts], dim=-1)
+    info = tag_trusted(packed, m)
+    tag_ray_indices(ri, seg.n_rays, info)
+    return ri, ts, te
+
+
+def _meshgrid3d(res: Tensor, device: Union[torch.device, str] = "cpu") -> Tensor:
+    """Integer cell coordinates of a 3-D grid, shape (rx, ry, rz, 3)."""
+    assert len(res) == 3
+    axes = [torch.arange(int(r), dtype=torch.long) for r in res.tolist()]
+    return torch.stack(torch.meshgrid(axes, indexing="ij"), dim=-1).to(device)

@@ -1,0 +1,154 @@
+"""Proposal-network estimator (ref: nerfacc/estimators/prop_net.py).
+
+``sampling`` (ref :37-129) resamples each ray level by level with the fused inverse-CDF kernel
+(csrc/pdf.hip); ``compute_loss`` / ``_pdf_loss`` (ref :131-154, :232-256) use the native
+``searchsorted``.  Optimiser/scheduler glue is plain torch, as upstream.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+try:
+    from typing import Literal
+except ImportError:  # pragma: no cover
+    from typing_extensions import Literal
+
+import torch
+from torch import Tensor
+
+from ..data_specs import RayIntervals
+from ..pdf import importance_sampling, searchsorted
+from ..volrend import render_transmittance_from_density
+from .base import AbstractEstimator
+
+
+class PropNetEstimator(AbstractEstimator):
+    """Proposal network transmittance estimator ("Mip-NeRF 360").
+
+    Args:
+        optimizer: optimizer of the proposal networks (optional).
+        scheduler: its learning-rate scheduler (optional).
+    """
+
+    def __init__(self, optimizer: Optional[torch.optim.Optimizer] = None,
+                 scheduler: Optional[torch.optim.lr_scheduler._LRScheduler] = None) -> None:
+        super().__init__()
+        self.optimizer = optimizer
+        self.scheduler = scheduler
+        self.prop_cache: List = []
+
+    @torch.no_grad()
+    def sampling(
+        self,
+        prop_sigma_fns: List[Callable],
+        prop_samples: List[int],
+        num_samples: int,
+        n_rays: int,
+        near_plane: float,
+        far_plane: float,
+        sampling_type: Literal["uniform", "lindisp"] = "lindisp",
+        stratified: bool = False,
+        requires_grad: bool = False,
+    ) -> Tuple[Tensor, Tensor]:
+        """Sampling with CDFs from proposal networks -> ``(t_starts, t_ends)`` of shape
+        ``(n_rays, num_samples)``.  With ``requires_grad`` the proposal outputs are cached for
+        :meth:`update_every_n_steps` (same contract as the reference)."""
+        assert len(prop_sigma_fns) == len(prop_samples), (
+            "The number of proposal networks and the number of samples should be the same.")
+        cdfs = torch.cat([torch.zeros((n_rays, 1), device=self.device),
+                          torch.ones((n_rays, 1), device=self.device)], dim=-1)
+        intervals = RayIntervals(vals=cdfs)
+        for level_fn, level_samples in zip(prop_sigma_fns, prop_samples):
+            intervals, _ = importance_sampling(intervals, cdfs, level_samples, stratified)
+            t_vals = _transform_stot(sampling_type, intervals.vals, near_plane, far_plane)
+            t_starts, t_ends = t_vals[..., :-1], t_vals[..., 1:]
+            with torch.set_grad_enabled(requires_grad):
+                sigmas = level_fn(t_starts, t_ends)
+                assert sigmas.shape == t_starts.shape
+                trans, _ = render_transmittance_from_density(t_starts, t_ends, sigmas)
+                cdfs = 1.0 - torch.cat([trans, torch.zeros_like(trans[:, :1])], dim=-1)
+                if requires_grad:
+                    self.prop_cache.append((intervals, cdfs))
+        intervals, _ = importance_sampling(intervals, cdfs, num_samples, stratified)
+        t_vals = _transform_stot(sampling_type, intervals.vals, near_plane, far_plane)
+        t_starts, t_ends = t_vals[..., :-1], t_vals[..., 1:]
+        if requires_grad:
+            self.prop_cache.append((intervals, None))
+        return t_starts, t_ends
+
+    @torch.enable_grad()
+    def compute_loss(self, trans: Tensor, loss_scaler: float = 1.0) -> Tensor:
+        """Proposal loss from the final transmittance ``(n_rays, num_samples)`` (ref :131-154)."""
+        if len(self.prop_cache) == 0:
+            return torch.zeros((), device=self.device)
+        intervals, _ = self.prop_cache.pop()
+        cdfs = 1.0 - torch.cat([trans, torch.zeros_like(trans[:, :1])], dim=-1)
+        cdfs = cdfs.detach()
+        loss = 0.0
+        while self.prop_cache:
+            prop_intervals, prop_cdfs = self.prop_cache.pop()
+            loss += _pdf_loss(intervals, cdfs, prop_intervals, prop_cdfs).mean()
+        return loss * loss_scaler
+
+    @torch.enable_grad()
+    def update_every_n_steps(self, trans: Tensor, requires_grad: bool = False, loss_scaler: float = 1.0) -> float:
+        """Step the proposal networks when ``requires_grad``; returns the loss value (ref :156-178)."""
+        if requires_grad:
+            return self._update(trans=trans, loss_scaler=loss_scaler)
+        if self.scheduler is not None:
+            self.scheduler.step()
+        return 0.0
+
+    @torch.enable_grad()
+    def _update(self, trans: Tensor, loss_scaler: float = 1.0) -> float:
+        assert len(self.prop_cache) > 0
+        assert self.optimizer is not None, "No optimizer is provided."
+        loss = self.compute_loss(trans, loss_scaler)
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        return loss.item()
+
+
+def get_proposal_requires_grad_fn(target: float = 5.0, num_steps: int = 1000) -> Callable:
+    """Schedule deciding on which steps the proposal networks get gradients (ref :194-212)."""
+    since_last = 0
+
+    def proposal_requires_grad_fn(step: int) -> bool:
+        nonlocal since_last
+        wanted_gap = min(step / num_steps, 1.0) * target
+        fire = since_last > wanted_gap
+        if fire:
+            since_last = 0
+        since_last += 1
+        return fire
+
+    return proposal_requires_grad_fn
+
+
+def _transform_stot(transform_type: Literal["uniform", "lindisp"], s_vals: Tensor, t_min, t_max) -> Tensor:
+    """Map normalised distances s in [0,1] to metric t (ref :215-229)."""
+    if transform_type == "uniform":
+        return s_vals * t_max + (1 - s_vals) * t_min
+    if transform_type == "lindisp":
+        return 1 / (s_vals * (1 / t_max) + (1 - s_vals) * (1 / t_min))
+    raise ValueError(f"Unknown transform_type: {transform_type}")
+
+
+def _pdf_loss(segments_query: RayIntervals, cdfs_query: Tensor, segments_key: RayIntervals, cdfs_key: Tensor,
+              eps: float = 1e-7) -> Tensor:
+    """Mip-NeRF-360 interlevel loss ``clip(w - w_outer, 0)^2 / (w + eps)`` (ref :232-256)."""
+    ids_left, ids_right = searchsorted(segments_key, segments_query)
+    if segments_query.vals.dim() > 1:
+        w = cdfs_query[..., 1:] - cdfs_query[..., :-1]
+        ids_left = ids_left[..., :-1]
+        ids_right = ids_right[..., 1:]
+    else:
+        assert segments_query.is_left is not None and segments_query.is_right is not None
+        w = cdfs_query[segments_query.is_right] - cdfs_query[segments_query.is_left]
+        ids_left = ids_left[segments_query.is_left]
+        ids_right = ids_right[segments_query.is_right]
+    w_outer = cdfs_key.gather(-1, ids_right) - cdfs_key.gather(-1, ids_left)
+    return torch.clip(w - w_outer, min=0) ** 2 / (w + eps)

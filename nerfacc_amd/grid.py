@@ -1,0 +1,261 @@
+"""Ray/AABB intersection and occupancy-grid traversal (ref: nerfacc/grid.py).
+
+``ray_aabb_intersect`` and ``traverse_grids`` keep the reference's signatures and return types
+(grid.py:13-51, :93-192).  The host orchestration the reference does in C++
+(cuda/csrc/grid.cu:320-474: count pass, cumsum, ``.item()``, allocation, fill pass) lives here
+in Python over the C ABI; it needs ONE device->host read (both totals at once) instead of the
+reference's two, and none in over-allocate mode.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _backend as B
+from ._segments import tag_ray_indices, tag_trusted
+from .data_specs import RayIntervals, RaySamples
+
+
+@torch.no_grad()
+def ray_aabb_intersect(
+    rays_o: Tensor,
+    rays_d: Tensor,
+    aabbs: Tensor,
+    near_plane: float = -float("inf"),
+    far_plane: float = float("inf"),
+    miss_value: float = float("inf"),
+) -> Tuple[Tensor, Tensor, Tensor]:
+    """Ray-AABB slab test -> (t_mins (n_rays, m), t_maxs (n_rays, m), hits bool (n_rays, m)).
+
+    Same contract as the reference (grid.py:13-51); kernel: csrc/grid.hip.
+    """
+    assert rays_o.ndim == 2 and rays_o.shape[-1] == 3
+    assert rays_d.ndim == 2 and rays_d.shape[-1] == 3
+    assert aabbs.ndim == 2 and aabbs.shape[-1] == 6
+    dev = B.require_device(rays_o, rays_d, aabbs)
+    rays_o, rays_d, aabbs = rays_o.float().contiguous(), rays_d.float().contiguous(), aabbs.float().contiguous()
+    n, m = rays_o.shape[0], aabbs.shape[0]
+    t_mins = torch.empty((n, m), dtype=torch.float32, device=dev)
+    t_maxs = torch.empty((n, m), dtype=torch.float32, device=dev)
+    hits = torch.empty((n, m), dtype=torch.bool, device=dev)
+    with torch.cuda.device(dev):
+        B.call("nfa_ray_aabb_intersect", B.ptr(rays_o), B.ptr(rays_d), n, B.ptr(aabbs), m, float(near_plane),
+               float(far_plane), float(miss_value), B.ptr(t_mins), B.ptr(t_maxs), B.ptr(hits), B.stream())
+    return t_mins, t_maxs, hits
+
+
+def _traverse_args(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indices, hits, near_planes, far_planes,
+                   step_size, cone_angle, limit, mode) -> B.TraverseArgs:
+    a = B.TraverseArgs()
+    a.n_rays = rays_o.shape[0]
+    a.rays_o, a.rays_d, a.rays_mask = B.ptr(rays_o), B.ptr(rays_d), B.ptr(rays_mask)
+    a.n_grids = binaries.shape[0]
+    a.res[0], a.res[1], a.res[2] = binaries.shape[1], binaries.shape[2], binaries.shape[3]
+    a.binaries, a.aabbs = B.ptr(binaries), B.ptr(aabbs)
+    a.hits, a.t_sorted, a.t_indices = B.ptr(hits), B.ptr(t_sorted), B.ptr(t_indices)
+    a.near_planes, a.far_planes = B.ptr(near_planes), B.ptr(far_planes)
+    a.step_size, a.cone_angle = float(step_size), float(cone_angle)
+    a.traverse_steps_limit, a.mode = int(limit), int(mode)
+    return a
+
+
+def _launch(a: B.TraverseArgs) -> None:
+    B.call("nfa_traverse_grids", C.byref(a), B.stream())
+
+
+def _exclusive_cumsum(cnts: Tensor, total_out: Tensor):
+    starts = torch.empty_like(cnts)
+    scratch = B.cumsum_scratch(cnts.numel(), cnts.device)
+    B.call("nfa_exclusive_cumsum_i64", B.ptr(cnts), cnts.numel(), B.ptr(starts), B.ptr(total_out), B.ptr(scratch),
+           B.stream())
+    return starts
+
+
+def _prepare(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, rays_mask, t_sorted, t_indices, hits,
+             allow_fused: bool):
+    dev = B.require_device(rays_o, rays_d, binaries, aabbs)
+    assert rays_o.ndim == 2 and rays_o.shape[-1] == 3 and rays_d.shape == rays_o.shape
+    assert binaries.ndim == 4 and aabbs.ndim == 2 and aabbs.shape == (binaries.shape[0], 6)
+    rays_o, rays_d, aabbs = rays_o.float().contiguous(), rays_d.float().contiguous(), aabbs.float().contiguous()
+    binaries = (binaries if binaries.dtype == torch.bool else binaries.bool()).contiguous()
+    n_rays = rays_o.shape[0]
+    if near_planes is None:
+        near_planes = torch.zeros(n_rays, dtype=torch.float32, device=dev)
+    if far_planes is None:
+        far_planes = torch.full((n_rays,), float("inf"), dtype=torch.float32, device=dev)
+    near_planes, far_planes = near_planes.float().contiguous(), far_planes.float().contiguous()
+    if rays_mask is not None:
+        rays_mask = rays_mask.bool().contiguous()
+    if t_sorted is None or t_indices is None or hits is None:
+        if allow_fused and binaries.shape[0] == 1:
+            t_sorted = t_indices = hits = None  # intersected inside the traversal kernel
+        else:  # grid.py:156-162
+            t_mins, t_maxs, hits = ray_aabb_intersect(rays_o, rays_d, aabbs)
+            t_sorted, t_indices = torch.sort(torch.cat([t_mins, t_maxs], dim=-1), dim=-1)
+    if t_sorted is not None:
+        t_sorted = t_sorted.float().contiguous()
+        t_indices = t_indices.to(torch.int64).contiguous()
+        hits = hits.bool().contiguous()
+    return dev, rays_o, rays_d, binaries, aabbs, near_planes, far_planes, rays_mask, t_sorted, t_indices, hits
+
+
+@torch.no_grad()
+def traverse_grids(
+    rays_o: Tensor,  # [n_rays, 3]
+    rays_d: Tensor,  # [n_rays, 3]
+    binaries: Tensor,  # [m, resx, resy, resz]
+    aabbs: Tensor,  # [m, 6]
+    near_planes: Optional[Tensor] = None,  # [n_rays]
+    far_planes: Optional[Tensor] = None,  # [n_rays]
+    step_size: Optional[float] = 1e-3,
+    cone_angle: Optional[float] = 0.0,
+    traverse_steps_limit: Optional[int] = None,
+    over_allocate: Optional[bool] = False,
+    rays_mask: Optional[Tensor] = None,  # [n_rays]
+    t_sorted: Optional[Tensor] = None,  # [n_rays, n_grids * 2]
+    t_indices: Optional[Tensor] = None,  # [n_rays, n_grids * 2]
+    hits: Optional[Tensor] = None,  # [n_rays, n_grids]
+) -> Tuple[RayIntervals, RaySamples, Tensor]:
+    """Ray traversal within multiple grids (not differentiable).
+
+    Arguments and returns as the reference (grid.py:93-192): a :class:`RayIntervals`, a
+    :class:`RaySamples` and the per-ray termination planes.  ``rays_mask`` is only honoured with
+    ``over_allocate`` (grid.cu:418,450 pass nullptr in two-pass mode).  Entries of the
+    termination planes the reference leaves uninitialised are defined here: the ray's near plane
+    for masked rays, the count pass's value for rays without samples.
+    """
+    if traverse_steps_limit is None:
+        traverse_steps_limit = -1
+    if over_allocate:
+        assert traverse_steps_limit > 0, "traverse_steps_limit must be set if over_allocate is True."
+    (dev, rays_o, rays_d, binaries, aabbs, near_planes, far_planes, rays_mask, t_sorted, t_indices,
+     hits) = _prepare(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, rays_mask, t_sorted, t_indices, hits,
+                      allow_fused=True)
+    n_rays = rays_o.shape[0]
+    i64 = dict(dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        terminate = torch.empty(n_rays, dtype=torch.float32, device=dev)
+        totals = torch.empty(2, **i64)
+        if over_allocate:  # grid.cu:364-404
+            limit = int(traverse_steps_limit)
+            mask_l = torch.ones(n_rays, **i64) if rays_mask is None else rays_mask.to(torch.int64)
+            sm_alloc = mask_l * limit
+            iv_alloc = sm_alloc * 2
+            sm_off = torch.cumsum(sm_alloc, 0) - sm_alloc
+            iv_off = sm_off * 2
+            n_alive = int(mask_l.sum().item()) if rays_mask is not None else n_rays
+            n_sm, n_iv = n_alive * limit, n_alive * limit * 2
+            iv_cnts, sm_cnts = torch.empty(n_rays, **i64), torch.empty(n_rays, **i64)
+            iv_vals = torch.zeros(n_iv, dtype=torch.float32, device=dev)
+            iv_ri = torch.zeros(n_iv, **i64)
+            iv_l = torch.zeros(n_iv, dtype=torch.bool, device=dev)
+            iv_r = torch.zeros(n_iv, dtype=torch.bool, device=dev)
+            sm_vals = torch.zeros(n_sm, dtype=torch.float32, device=dev)
+            sm_ri = torch.zeros(n_sm, **i64)
+            sm_valid = torch.zeros(n_sm, dtype=torch.bool, device=dev)
+            a = _traverse_args(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indices, hits, near_planes,
+                               far_planes, step_size, cone_angle, limit, 2)
+            a.iv_vals, a.iv_ray_indices, a.iv_is_left, a.iv_is_right = B.ptr(iv_vals), B.ptr(iv_ri), B.ptr(iv_l), B.ptr(iv_r)
+            a.iv_starts, a.iv_cnts = B.ptr(iv_off), B.ptr(iv_cnts)
+            a.sm_vals, a.sm_ray_indices, a.sm_is_valid = B.ptr(sm_vals), B.ptr(sm_ri), B.ptr(sm_valid)
+            a.sm_starts, a.sm_cnts = B.ptr(sm_off), B.ptr(sm_cnts)
+            a.terminate_planes = B.ptr(terminate)
+            _launch(a)
+            # chunk_starts from the ACTUAL counts: the layout after the caller compacts with the
+            # masks (grid.cu:401-403, examples/utils.py:362-365).
+            iv_starts = _exclusive_cumsum(iv_cnts, totals[0:1])
+            sm_starts = _exclusive_cumsum(sm_cnts, totals[1:2])
+        else:  # two passes, grid.cu:405-471
+            iv_cnts, sm_cnts = torch.empty(n_rays, **i64), torch.empty(n_rays, **i64)
+            a = _traverse_args(rays_o, rays_d, None, binaries, aabbs, t_sorted, t_indices, hits, near_planes,
+                               far_planes, step_size, cone_angle, traverse_steps_limit, 0)
+            a.iv_cnts, a.sm_cnts, a.terminate_planes = B.ptr(iv_cnts), B.ptr(sm_cnts), B.ptr(terminate)
+            _launch(a)
+            iv_starts = _exclusive_cumsum(iv_cnts, totals[0:1])
+            sm_starts = _exclusive_cumsum(sm_cnts, totals[1:2])
+            n_iv, n_sm = (int(v) for v in totals.tolist())  # the one device->host read
+            iv_vals = torch.empty(n_iv, dtype=torch.float32, device=dev)
+            iv_ri = torch.empty(n_iv, **i64)
+            iv_l = torch.empty(n_iv, dtype=torch.bool, device=dev)
+            iv_r = torch.empty(n_iv, dtype=torch.bool, device=dev)
+            sm_vals = torch.empty(n_sm, dtype=torch.float32, device=dev)
+            sm_ri = torch.empty(n_sm, **i64)
+            sm_valid = torch.empty(n_sm, dtype=torch.bool, device=dev)
+            if n_sm > 0:
+                a.mode = 1
+                a.terminate_planes = None
+                a.iv_vals, a.iv_ray_indices, a.iv_is_left, a.iv_is_right = B.ptr(iv_vals), B.ptr(iv_ri), B.ptr(iv_l), B.ptr(iv_r)
+                a.iv_starts = B.ptr(iv_starts)
+                a.sm_vals, a.sm_ray_indices, a.sm_is_valid = B.ptr(sm_vals), B.ptr(sm_ri), B.ptr(sm_valid)
+                a.sm_starts = B.ptr(sm_starts)
+                _launch(a)
+        iv_packed = torch.stack([iv_starts, iv_cnts], dim=-1)
+        sm_packed = torch.stack([sm_starts, sm_cnts], dim=-1)
+    if not over_allocate:
+        tag_trusted(iv_packed, n_iv)
+        info = tag_trusted(sm_packed, n_sm)
+        tag_ray_indices(sm_ri, n_rays, info)
+    intervals = RayIntervals(vals=iv_vals, packed_info=iv_packed, ray_indices=iv_ri, is_left=iv_l, is_right=iv_r)
+    samples = RaySamples(vals=sm_vals, packed_info=sm_packed, ray_indices=sm_ri, is_valid=sm_valid)
+    return intervals, samples, terminate
+
+
+@torch.no_grad()
+def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size, cone_angle):
+    """Sampler fast path: (ray_indices, t_starts, t_ends, packed_info) straight from the traversal.
+
+    Same values as ``intervals.vals[is_left]``, ``intervals.vals[is_right]``,
+    ``samples.ray_indices``, ``samples.packed_info`` of :func:`traverse_grids`
+    (ref: estimators/occ_grid.py:164-177) without materialising edges and masks and without
+    the two boolean-index syncs."""
+    (dev, rays_o, rays_d, binaries, aabbs, near_planes, far_planes, _, t_sorted, t_indices,
+     hits) = _prepare(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, None, None, None, None,
+                      allow_fused=True)
+    n_rays = rays_o.shape[0]
+    with torch.cuda.device(dev):
+        sm_cnts = torch.empty(n_rays, dtype=torch.int64, device=dev)
+        total = torch.empty(1, dtype=torch.int64, device=dev)
+        a = _traverse_args(rays_o, rays_d, None, binaries, aabbs, t_sorted, t_indices, hits, near_planes, far_planes,
+                           step_size, cone_angle, -1, 0)
+        a.sm_cnts = B.ptr(sm_cnts)
+        _launch(a)
+        sm_starts = _exclusive_cumsum(sm_cnts, total)
+        n_sm = int(total.item())  # the one device->host read of the sampler's traversal
+        t_starts = torch.empty(n_sm, dtype=torch.float32, device=dev)
+        t_ends = torch.empty(n_sm, dtype=torch.float32, device=dev)
+        ray_indices = torch.empty(n_sm, dtype=torch.int64, device=dev)
+        if n_sm > 0:
+            a.mode = 1
+            a.sm_starts = B.ptr(sm_starts)
+            a.sm_t_starts, a.sm_t_ends, a.sm_ray_indices = B.ptr(t_starts), B.ptr(t_ends), B.ptr(ray_indices)
+            _launch(a)
+        packed_info = torch.stack([sm_starts, sm_cnts], dim=-1)
+    info = tag_trusted(packed_info, n_sm)
+    tag_ray_indices(ray_indices, n_rays, info)
+    return ray_indices, t_starts, t_ends, packed_info
+
+
+def _enlarge_aabb(aabb: Tensor, factor: float) -> Tensor:
+    """Scale an aabb about its centre (ref: grid.py:195-198)."""
+    center = (aabb[:3] + aabb[3:]) / 2
+    extent = (aabb[3:] - aabb[:3]) / 2
+    return torch.cat([center - extent * factor, center + extent * factor])
+
+
+def _query(x: Tensor, data: Tensor, base_aabb: Tensor) -> Tuple[Tensor, Tensor]:
+    """Look up multi-level grid values at points ``x`` assuming levels are 2x nested around
+    ``base_aabb`` (same contract as the reference's test helper, grid.py:201-237): returns
+    (values * inside_selector, inside_selector)."""
+    lo, hi = base_aabb[:3], base_aabb[3:]
+    u = (x - lo) / (hi - lo)                                # base box -> [0, 1]^3
+    r = (u - 0.5).abs().amax(dim=-1).clamp_min(0.1)         # Chebyshev radius; avoid frexp(~0)
+    mip = (torch.frexp(r)[1].long() + 1).clamp_min(0)       # 0 inside the base box, +1 per doubling
+    inside = mip < data.shape[0]
+    uu = (u - 0.5) / (2 ** mip)[:, None] + 0.5
+    res = torch.tensor(data.shape[1:], device=x.device)
+    ix = torch.minimum((uu * res).long(), res - 1)
+    lvl = mip.clamp_max(data.shape[0] - 1)
+    return data[lvl, ix[:, 0], ix[:, 1], ix[:, 2]] * inside, inside

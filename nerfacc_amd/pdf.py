@@ -1,0 +1,101 @@
+"""Per-ray ``searchsorted`` and inverse-CDF ``importance_sampling`` (ref: nerfacc/pdf.py)."""
+from __future__ import annotations
+
+from typing import Tuple, Union
+
+import torch
+from torch import Tensor
+
+from . import _backend as B
+from .data_specs import RayIntervals, RaySamples
+
+
+def _philox_seed_offset(device: torch.device, increment: int = 4) -> Tuple[int, int]:
+    """(seed, offset) of the device's default generator, advancing it by ``increment`` -- what
+    ``gen->philox_cuda_state(4)`` does in the reference (cuda/csrc/pdf.cu:376-383)."""
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    seed = int(gen.initial_seed())
+    offset = int(gen.get_offset())
+    gen.set_offset(offset + increment)
+    return seed & 0xFFFFFFFFFFFFFFFF, offset
+
+
+@torch.no_grad()
+def searchsorted(
+    sorted_sequence: Union[RayIntervals, RaySamples],
+    values: Union[RayIntervals, RaySamples],
+) -> Tuple[Tensor, Tensor]:
+    """``ids_left, ids_right`` with ``seq[ids_left] <= values < seq[ids_right]`` per ray; values
+    outside a ray's range get the ids of the clipped value (ref: pdf.py:13-62).
+
+    >>> seq = RayIntervals(vals=tensor([0., 1., 0., 1., 2.]), packed_info=tensor([[0, 2], [2, 3]]))
+    >>> val = RayIntervals(vals=tensor([0.5, 1.5, 2.5]), packed_info=tensor([[0, 1], [1, 2]]))
+    >>> searchsorted(seq, val)
+    (tensor([0, 3, 3]), tensor([1, 4, 4]))
+    """
+    q, k = values._to_spec(), sorted_sequence._to_spec()
+    qv, kv = q["vals"].float().contiguous(), k["vals"].float().contiguous()
+    dev = B.require_device(qv, kv)
+    q_batched, k_batched = qv.dim() > 1, kv.dim() > 1
+    if not q_batched:
+        assert q["packed_info"] is not None or q["ray_indices"] is not None, \
+            "flattened `values` need packed_info or ray_indices"
+    if not k_batched:
+        assert k["packed_info"] is not None, "flattened `sorted_sequence` needs packed_info"
+    ids_left = torch.empty(qv.shape, dtype=torch.int64, device=dev)
+    ids_right = torch.empty(qv.shape, dtype=torch.int64, device=dev)
+    q_pi = None if q_batched else (q["packed_info"] if q["packed_info"] is not None else
+                                   torch.zeros((0, 2), dtype=torch.int64, device=dev))
+    with torch.cuda.device(dev):
+        B.call("nfa_searchsorted", B.ptr(qv), B.ptr(q_pi), None if q_batched else B.ptr(q["ray_indices"]),
+               0 if q_pi is None else q_pi.shape[0], qv.shape[-1] if q_batched else 0, qv.numel(), B.ptr(kv),
+               None if k_batched else B.ptr(k["packed_info"]), kv.shape[-1] if k_batched else 0,
+               B.ptr(ids_left), B.ptr(ids_right), B.stream())
+    return ids_left, ids_right
+
+
+@torch.no_grad()
+def importance_sampling(
+    intervals: RayIntervals,
+    cdfs: Tensor,
+    n_intervals_per_ray: Union[Tensor, int],
+    stratified: bool = False,
+) -> Tuple[RayIntervals, RaySamples]:
+    """Inverse-transform resampling of each ray to ``n_intervals_per_ray`` intervals
+    (ref: pdf.py:65-131; kernels cuda/csrc/pdf.cu:98-241).
+
+    With an int count the outputs are batched: ``intervals.vals`` (n_rays, n+1) and
+    ``samples.vals`` (n_rays, n).  A per-ray Tensor count (packed outputs) is not functional in
+    the reference either (pdf.cu:324 allocates zero samples) and is not implemented here.
+
+    >>> iv = RayIntervals(vals=tensor([0., 1., 0., 1., 2.]), packed_info=tensor([[0, 2], [2, 3]]))
+    >>> out_iv, out_sm = importance_sampling(iv, tensor([0., .5, 0., .5, 1.]), 2)
+    >>> out_iv.vals, out_sm.vals
+    (tensor([[0., .5, 1.], [0., 1., 2.]]), tensor([[.25, .75], [.5, 1.5]]))
+    """
+    if isinstance(n_intervals_per_ray, Tensor):
+        raise NotImplementedError(
+            "importance_sampling with a per-ray Tensor count returns no samples in the reference "
+            "(cuda/csrc/pdf.cu:324,344); pass an int.")
+    S = int(n_intervals_per_ray)
+    if S < 2:
+        raise ValueError("n_intervals_per_ray must be >= 2 (the reference reads out of bounds for 1, pdf.cu:211)")
+    spec = intervals._to_spec()
+    vals = spec["vals"].float().contiguous()
+    cdfs = cdfs.float().contiguous()
+    assert cdfs.numel() == vals.numel()  # pdf.cu:368
+    dev = B.require_device(vals, cdfs)
+    if vals.dim() > 1:
+        lead = vals.shape[:-1]
+        n_rays, per, pi = int(torch.Size(lead).numel()), vals.shape[-1], None
+    else:
+        pi = spec["packed_info"]
+        assert pi is not None, "flattened intervals need packed_info"
+        n_rays, per, lead = pi.shape[0], 0, (pi.shape[0],)
+    out_iv = torch.empty((*lead, S + 1), dtype=torch.float32, device=dev)
+    out_sm = torch.empty((*lead, S), dtype=torch.float32, device=dev)
+    seed, offset = _philox_seed_offset(dev) if stratified else (0, 0)
+    with torch.cuda.device(dev):
+        B.call("nfa_importance_sampling", B.ptr(vals), B.ptr(cdfs), B.ptr(pi), n_rays, per, S, int(bool(stratified)),
+               seed, offset, B.ptr(out_iv), B.ptr(out_sm), B.stream())
+    return RayIntervals(vals=out_iv), RaySamples(vals=out_sm)

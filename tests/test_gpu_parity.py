@@ -1,0 +1,573 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs, against the committed golden fixtures (reference outputs), and -- mirroring the
+reference's own tests -- against torch on equal-length chunks.
+
+Bars (BASELINE.json north_star): bit-exact for ray_indices / packed_info / masks / sample
+positions; <= 1e-5 (relative to magnitude) for fp32 weights, transmittance, colours.
+"""
+import numpy as np
+import pytest
+import torch
+
+import nerfacc_amd as na
+from conftest import assert_close, load_golden, seeded_case
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+# ----------------------------------------------------------------------------- native lib really loaded
+def test_native_library_is_loaded(dev):
+    from nerfacc_amd import _backend as B
+    lib = B.load()
+    import ctypes as C
+    buf = C.create_string_buffer(64)
+    assert lib.nfa_device_arch(buf, 64) == 0
+    assert buf.value.decode().startswith("gfx"), buf.value
+    maps = open("/proc/self/maps").read()
+    assert "libnerfacc_hip.so" in maps
+
+
+# ----------------------------------------------------------------------------- pack / scans
+def test_pack_info(dev, oracle):
+    # tests/test_pack.py:8-18
+    ri = torch.tensor([0, 2, 2, 2, 2], dtype=torch.int64, device=dev)
+    assert na.pack_info(ri, n_rays=3).tolist() == [[0, 1], [1, 0], [1, 4]]
+    assert na.pack_info(torch.tensor([0, 0, 1, 1, 1, 2, 2, 2, 2], device=dev), 3).tolist() == [[0, 2], [2, 3], [5, 4]]
+    rng = np.random.default_rng(3)
+    lens = rng.integers(0, 200, size=5000)
+    lens[rng.random(5000) < 0.3] = 0
+    ri = np.repeat(np.arange(5000), lens).astype(np.int64)
+    assert (na.pack_info(T(ri, dev), 5000).cpu().numpy() == oracle.pack_info(ri, 5000)).all()
+    # n_rays inferred, int32 indices keep their dtype (pack.py:40-41)
+    p = na.pack_info(T(ri.astype(np.int32), dev))
+    assert p.dtype == torch.int32 and p.shape[0] == ri.max() + 1
+    assert na.pack_info(torch.zeros(0, dtype=torch.int64, device=dev), 4).tolist() == [[0, 0]] * 4
+
+
+def _equal_chunks(dev, rows=5, cols=1000):
+    torch.manual_seed(42)
+    data = torch.rand((rows, cols), device=dev, requires_grad=True)
+    starts = torch.arange(0, data.numel(), cols, device=dev, dtype=torch.long)
+    cnts = torch.full((rows,), cols, dtype=torch.long, device=dev)
+    return data, torch.stack([starts, cnts], dim=-1)
+
+
+@pytest.mark.parametrize("name,atol", [("inclusive_sum", 1e-8), ("exclusive_sum", 3e-4), ("inclusive_prod", 1e-8),
+                                       ("exclusive_prod", 1e-8)])
+def test_scans_like_reference_tests(dev, name, atol):
+    # tests/test_scan.py:8-124: packed == batched torch on 5 x 1000, values and gradients
+    fn = getattr(na, name)
+    data, packed_info = _equal_chunks(dev)
+    out1 = fn(data).flatten()
+    out1.sum().backward()
+    g1 = data.grad.clone()
+    data.grad.zero_()
+    out2 = fn(data.flatten(), packed_info=packed_info)
+    out2.sum().backward()
+    g2 = data.grad.clone()
+    assert torch.allclose(out1, out2, atol=max(atol, 1e-8), rtol=1e-5)
+    assert torch.allclose(g1, g2, rtol=1e-4, atol=1e-5)
+
+
+def test_scans_ragged_vs_oracle_and_reference(dev, oracle):
+    g = load_golden("ragged_packed")
+    pi = T(g["packed_info"], dev)
+    gg = T(g["g"], dev)
+    for kind, key in (("inclusive_sum", "x"), ("exclusive_sum", "x"), ("inclusive_prod", "xp"), ("exclusive_prod", "xp")):
+        x = T(g[key], dev).requires_grad_(True)
+        y = getattr(na, kind)(x, pi)
+        (y * gg).sum().backward()
+        assert_close(y, g[kind], atol=1e-5, rtol=1e-5, what=kind + " vs reference")
+        assert_close(y, oracle.packed_scan(kind, g[key], g["packed_info"]), atol=1e-5, rtol=1e-5, what=kind + " vs oracle")
+        assert_close(x.grad, g[kind + "_grad"], atol=2e-5, rtol=1e-4, what=kind + " grad")
+    # docstring vectors scan.py:36-39 ...
+    x = torch.arange(1.0, 10.0, device=dev)
+    p3 = torch.tensor([[0, 2], [2, 3], [5, 4]], device=dev)
+    assert na.inclusive_sum(x, p3).tolist() == [1, 3, 3, 7, 12, 6, 13, 21, 30]
+    assert na.exclusive_sum(x, p3).tolist() == [0, 1, 0, 3, 7, 0, 6, 13, 21]
+    assert na.inclusive_prod(x, p3).tolist() == [1, 2, 3, 12, 60, 6, 42, 336, 3024]
+    assert na.exclusive_prod(x, p3).tolist() == [1, 1, 1, 3, 12, 1, 6, 42, 336]
+
+
+def test_scans_many_tiles_long_and_empty_rays(dev, oracle):
+    rng = np.random.default_rng(9)
+    lens = rng.integers(0, 70, size=20000)
+    lens[100] = 9000          # spans > 4 ownership tiles
+    lens[101] = 0
+    lens[5000:5200] = 0       # a run of empty rays
+    lens[-3:] = 0             # trailing empty rays
+    starts = np.cumsum(lens) - lens
+    pi = np.stack([starts, lens], -1).astype(np.int64)
+    n = int(lens.sum())
+    x = (rng.random(n) * 0.1).astype(np.float32)
+    for kind in ("inclusive_sum", "exclusive_sum"):
+        y = getattr(na, kind)(T(x, dev), T(pi, dev))
+        ref = np.zeros(n, np.float64)
+        for s, l in pi:
+            c = np.cumsum(x[s:s + l].astype(np.float64))
+            ref[s:s + l] = c if kind == "inclusive_sum" else c - x[s:s + l]
+        assert_close(y, ref.astype(np.float32), atol=1e-6, rtol=1e-5, what=kind)
+    xp = (0.97 + 0.03 * rng.random(n)).astype(np.float32)
+    y = na.exclusive_prod(T(xp, dev), T(pi, dev))
+    assert_close(y, oracle.exclusive_prod(xp, pi), atol=1e-30, rtol=2e-5)
+
+
+def test_scans_generic_chunks_and_normalize(dev, oracle):
+    # overlapping / unordered / gapped chunks: only the reference-style per-ray kernel applies
+    x = np.random.default_rng(1).random(100).astype(np.float32)
+    pi = np.array([[50, 10], [0, 20], [15, 30], [90, 0], [99, 1]], np.int64)
+    for kind in ("inclusive_sum", "exclusive_sum", "inclusive_prod", "exclusive_prod"):
+        y = getattr(na, kind)(T(x, dev), T(pi, dev)).cpu().numpy()
+        ref = oracle.packed_scan(kind, x, pi)
+        for s, l in pi[[0, 4]]:  # chunks not overwritten by an overlapping one
+            assert np.allclose(y[s:s + l], ref[s:s + l], rtol=1e-5)
+    pi2 = np.array([[0, 33], [33, 0], [33, 67]], np.int64)
+    for kind in ("inclusive_sum", "exclusive_sum"):
+        y = getattr(na, kind)(T(x, dev), T(pi2, dev), normalize=True)
+        assert_close(y, oracle.packed_scan(kind, x, pi2, normalize=True), atol=1e-6, rtol=1e-5)
+
+
+def test_scans_unaligned_views_and_empty(dev, oracle):
+    rng = np.random.default_rng(2)
+    lens = rng.integers(0, 50, size=300)
+    pi = np.stack([np.cumsum(lens) - lens, lens], -1).astype(np.int64)
+    n = int(lens.sum())
+    x = rng.random(n + 1).astype(np.float32)
+    xt = T(x, dev)[1:]                     # 4-byte aligned only -> scalar path
+    assert xt.data_ptr() % 16 != 0
+    y = na.exclusive_sum(xt, T(pi, dev))
+    assert_close(y, oracle.exclusive_sum(x[1:], pi), atol=1e-5, rtol=1e-5)
+    e = na.inclusive_sum(torch.zeros(0, device=dev), torch.zeros((3, 2), dtype=torch.long, device=dev))
+    assert e.shape == (0,)
+
+
+# ----------------------------------------------------------------------------- volrend
+def test_rendering_reference_vectors(dev):
+    ri = torch.tensor([0, 2, 2, 2, 2], dtype=torch.int64, device=dev)
+    alphas = torch.tensor([0.4, 0.3, 0.8, 0.8, 0.5], device=dev)
+    # tests/test_rendering.py:8-34
+    vis = na.render_visibility_from_alpha(alphas, ray_indices=ri, early_stop_eps=0.03, alpha_thre=0.0)
+    assert vis.tolist() == [True, True, True, True, False] and vis.dtype == torch.bool
+    vis = na.render_visibility_from_alpha(alphas, ray_indices=ri, early_stop_eps=0.05, alpha_thre=0.35)
+    assert vis.tolist() == [True, False, True, True, False]
+    # tests/test_rendering.py:38-57
+    w, _ = na.render_weight_from_alpha(alphas, ray_indices=ri, n_rays=3)
+    assert torch.allclose(w, torch.tensor([0.4, 0.3, 0.7 * 0.8, 0.14 * 0.8, 0.028 * 0.5], device=dev))
+    # tests/test_rendering.py:61-83 density == alpha formulation
+    torch.manual_seed(0)
+    sig = torch.rand(5, device=dev); ts = torch.rand(5, device=dev); te = torch.rand(5, device=dev) + 1.0
+    w1, _, _ = na.render_weight_from_density(ts, te, sig, ray_indices=ri, n_rays=3)
+    w2, _ = na.render_weight_from_alpha(1.0 - torch.exp(-sig * (te - ts)), ray_indices=ri, n_rays=3)
+    assert torch.allclose(w1, w2)
+    # tests/test_rendering.py:87-106
+    vals = torch.rand((5, 2), device=dev)
+    acc = na.accumulate_along_rays(alphas, values=vals, ray_indices=ri, n_rays=3)
+    assert acc.shape == (3, 2) and torch.allclose(acc[0], alphas[0] * vals[0]) and (acc[1] == 0).all()
+    assert torch.allclose(acc[2], (alphas[1:, None] * vals[1:]).sum(0))
+    # docstrings volrend.py:246-253, 403-409
+    a7 = torch.tensor([0.4, 0.8, 0.1, 0.8, 0.1, 0.0, 0.9], device=dev)
+    r7 = torch.tensor([0, 0, 0, 1, 1, 2, 2], device=dev)
+    assert torch.allclose(na.render_transmittance_from_alpha(a7, ray_indices=r7), torch.tensor([1.0, 0.6, 0.12, 1.0, 0.2, 1.0, 1.0], device=dev))
+    assert na.render_visibility_from_alpha(a7, ray_indices=r7, early_stop_eps=0.3, alpha_thre=0.2).tolist() == \
+        [True, True, False, True, False, False, True]
+
+
+def test_grads_reference_vectors(dev):
+    # tests/test_rendering.py:110-193 through all six API spellings
+    ri = torch.tensor([0, 2, 2, 2, 2], dtype=torch.int64, device=dev)
+    pi = torch.tensor([[0, 1], [1, 0], [1, 4]], dtype=torch.long, device=dev)
+    sig = torch.tensor([0.4, 0.8, 0.1, 0.8, 0.1], device=dev, requires_grad=True)
+    ts = torch.rand_like(sig); te = ts + 1.0
+    w_ref = torch.tensor([0.3297, 0.5507, 0.0428, 0.2239, 0.0174], device=dev)
+    g_ref = torch.tensor([0.6703, 0.1653, 0.1653, 0.1653, 0.1653], device=dev)
+
+    def check(weights):
+        weights.sum().backward()
+        g = sig.grad.clone(); sig.grad.zero_()
+        assert torch.allclose(w_ref, weights, atol=1e-4) and torch.allclose(g_ref, g, atol=1e-4)
+
+    for kw in (dict(ray_indices=ri, n_rays=3), dict(packed_info=pi, n_rays=3)):
+        tr, _ = na.render_transmittance_from_density(ts, te, sig, **kw)
+        check(tr * (1.0 - torch.exp(-sig * (te - ts))))
+        check(na.render_weight_from_density(ts, te, sig, **kw)[0])
+        check(na.render_weight_from_alpha(1.0 - torch.exp(-sig * (te - ts)), **kw)[0])
+
+
+def test_volrend_ragged_vs_reference_and_oracle(dev, oracle):
+    g = load_golden("ragged_packed")
+    pi, ri = T(g["packed_info"], dev), T(g["ray_indices"], dev)
+    n_rays = pi.shape[0]
+    ts, te = T(g["ts"], dev), T(g["te"], dev)
+    gw, gt, ga = T(g["gw"], dev), T(g["gt"], dev), T(g["ga"], dev)
+    for kw in (dict(packed_info=pi), dict(ray_indices=ri, n_rays=n_rays)):
+        sig = T(g["sig"], dev).requires_grad_(True)
+        w, tr, al = na.render_weight_from_density(ts, te, sig, **kw)
+        (w * gw + tr * gt + al * ga).sum().backward()
+        assert_close(w, g["rwd_w"], what="w"); assert_close(tr, g["rwd_t"], what="T"); assert_close(al, g["rwd_a"], what="alpha")
+        assert_close(sig.grad, g["rwd_gsig"], atol=2e-5, rtol=1e-4, what="grad sigma")
+    ow, ot, oa = oracle.render_weight_from_density(g["ts"], g["te"], g["sig"], g["packed_info"])
+    assert_close(w, ow); assert_close(tr, ot); assert_close(al, oa)
+    # transmittance-only entry point, prefix_trans
+    tr2, al2 = na.render_transmittance_from_density(ts, te, T(g["sig"], dev), packed_info=pi)
+    assert_close(tr2, g["rwd_t"]); assert_close(al2, g["rwd_a"])
+    wp, tp, _ = na.render_weight_from_density(ts, te, T(g["sig"], dev), packed_info=pi, prefix_trans=T(g["pref"], dev))
+    assert_close(wp, g["rwd_pref_w"]); assert_close(tp, g["rwd_pref_t"])
+    # alpha path + gradient
+    al = T(g["alph"], dev).requires_grad_(True)
+    wa, ta = na.render_weight_from_alpha(al, packed_info=pi)
+    (wa * gw + ta * gt).sum().backward()
+    assert_close(wa, g["rwa_w"]); assert_close(ta, g["rwa_t"])
+    assert_close(al.grad, g["rwa_galpha"], atol=2e-5, rtol=1e-4, what="grad alpha")
+    assert_close(na.render_transmittance_from_alpha(T(g["alph"], dev), packed_info=pi), g["rwa_t"])
+    # gradients w.r.t. t_starts / t_ends (the reference composition is differentiable there too)
+    ts_g, te_g = ts.clone().requires_grad_(True), te.clone().requires_grad_(True)
+    sg = T(g["sig"], dev)
+    w3, _, _ = na.render_weight_from_density(ts_g, te_g, sg, packed_info=pi)
+    (w3 * gw).sum().backward()
+    B_ = oracle.render_weight_from_density_backward(g["ts"], g["te"], g["sig"], g["packed_info"], g["gw"])
+    dt = (g["te"] - g["ts"]).astype(np.float64)
+    g_te = np.where(dt != 0, B_ / np.where(dt != 0, dt, 1) * g["sig"], 0.0)
+    assert_close(te_g.grad, g_te.astype(np.float32), atol=5e-4, rtol=1e-3, what="grad t_ends")
+    assert_close(ts_g.grad, -g_te.astype(np.float32), atol=5e-4, rtol=1e-3, what="grad t_starts")
+    # visibility (ties within 1e-5 of a threshold are platform-dependent: exp ulps)
+    eps_t, thre = float(g["eps_t"]), float(g["thre"])
+    vd = na.render_visibility_from_density(ts, te, T(g["sig"], dev), packed_info=pi, early_stop_eps=eps_t, alpha_thre=thre)
+    va = na.render_visibility_from_alpha(T(g["alph"], dev), ray_indices=ri, n_rays=n_rays, early_stop_eps=eps_t, alpha_thre=thre)
+    assert ((vd.cpu().numpy() == g["vis_d"]) | g["guard_d"]).all() and ((va.cpu().numpy() == g["vis_a"]) | g["guard_a"]).all()
+    # accumulate + its gradients vs torch index_add_
+    wt = T(g["rwd_w"], dev).requires_grad_(True)
+    rgb = T(g["rgb"], dev).requires_grad_(True)
+    acc = na.accumulate_along_rays(wt, rgb, ri, n_rays)
+    go = torch.rand_like(acc)
+    (acc * go).sum().backward()
+    assert_close(acc, g["acc_rgb"], atol=1e-5)
+    wt2, rgb2 = wt.detach().clone().requires_grad_(True), rgb.detach().clone().requires_grad_(True)
+    ref = torch.zeros_like(acc).index_add_(0, ri, wt2[:, None] * rgb2)
+    (ref * go).sum().backward()
+    assert_close(wt.grad, wt2.grad, atol=1e-6); assert_close(rgb.grad, rgb2.grad, atol=1e-6)
+    assert_close(na.accumulate_along_rays(wt.detach(), None, ri, n_rays), g["acc_w"], atol=1e-5)
+    v7 = torch.rand((wt.numel(), 7), device=dev)                # D > 4: several channel groups
+    assert_close(na.accumulate_along_rays(wt.detach(), v7, ri, n_rays),
+                 torch.zeros((n_rays, 7), device=dev).index_add_(0, ri, wt.detach()[:, None] * v7), atol=1e-5)
+    # in-place version, sorted and unsorted indices
+    out = torch.ones((n_rays, 3), device=dev)
+    na.volrend.accumulate_along_rays_(wt.detach(), rgb.detach(), ri, out)
+    assert_close(out, g["acc_rgb"] + 1.0, atol=1e-5)
+    perm = torch.randperm(wt.numel(), device=dev)
+    out2 = torch.zeros((n_rays, 3), device=dev)
+    na.volrend.accumulate_along_rays_(wt.detach()[perm], rgb.detach()[perm], ri[perm], out2)
+    assert_close(out2, g["acc_rgb"], atol=1e-5)
+    assert_close(na.accumulate_along_rays(wt.detach()[perm], rgb.detach()[perm], ri[perm], n_rays), g["acc_rgb"], atol=1e-5)
+
+
+def test_rendering_composite(dev):
+    g = load_golden("ragged_packed")
+    ri = T(g["ray_indices"], dev)
+    n_rays = g["packed_info"].shape[0]
+    ts, te = T(g["ts"], dev), T(g["te"], dev)
+    rgb = T(g["rgb"], dev).requires_grad_(True)
+    sig = T(g["sig"], dev).requires_grad_(True)
+    colors, opac, depth, extras = na.rendering(ts, te, ri, n_rays, rgb_sigma_fn=lambda a, b, c: (rgb, sig),
+                                               render_bkgd=T(g["bkgd"], dev))
+    assert_close(colors, g["rend_colors"], atol=1e-5); assert_close(depth, g["rend_depths"], atol=1e-5, rtol=1e-4)
+    assert_close(opac, g["acc_w"], atol=1e-5)
+    assert set(extras) == {"weights", "alphas", "trans", "sigmas", "rgbs"}
+    (colors.sum() + 0.3 * depth.sum() + opac.sum()).backward()
+    # same thing through the reference's composition (torch autograd over our scans)
+    rgb2, sig2 = rgb.detach().clone().requires_grad_(True), sig.detach().clone().requires_grad_(True)
+    sdt = sig2 * (te - ts)
+    tr = torch.exp(-na.exclusive_sum(sdt, T(g["packed_info"], dev)))
+    w = tr * (1 - torch.exp(-sdt))
+    z = lambda d: torch.zeros((n_rays, d), device=dev)
+    c2 = z(3).index_add_(0, ri, w[:, None] * rgb2)
+    o2 = z(1).index_add_(0, ri, w[:, None])
+    d2 = z(1).index_add_(0, ri, w[:, None] * ((ts + te)[:, None] / 2.0)) / o2.clamp_min(torch.finfo(torch.float32).eps)
+    c2 = c2 + T(g["bkgd"], dev) * (1.0 - o2)
+    (c2.sum() + 0.3 * d2.sum() + o2.sum()).backward()
+    assert_close(sig.grad, sig2.grad, atol=3e-5, rtol=1e-4); assert_close(rgb.grad, rgb2.grad, atol=1e-6)
+    # empty input (volrend.py:91-93) and rgb_alpha_fn
+    e = torch.zeros(0, device=dev)
+    c, o, d, _ = na.rendering(e, e, torch.zeros(0, dtype=torch.long, device=dev), 4,
+                              rgb_sigma_fn=lambda a, b, c: (None, None))
+    assert c.shape == (4, 3) and (c == 0).all() and (o == 0).all()
+    al = T(g["alph"], dev)
+    c3, o3, _, ex = na.rendering(ts, te, ri, n_rays, rgb_alpha_fn=lambda a, b, c: (rgb.detach(), al))
+    assert_close(o3, torch.zeros((n_rays, 1), device=dev).index_add_(0, ri, T(g["rwa_w"], dev)[:, None]), atol=1e-5)
+    assert set(ex) == {"weights", "trans", "rgbs", "alphas"}
+
+
+# ----------------------------------------------------------------------------- grid
+def test_ray_aabb_intersect(dev, oracle):
+    g = load_golden("ray_aabb")
+    tm, tM, hit = na.ray_aabb_intersect(T(g["rays_o"], dev), T(g["rays_d"], dev), T(g["aabbs"], dev))
+    assert (hit.cpu().numpy() == g["hits"]).all()
+    assert np.allclose(tm.cpu().numpy(), g["t_mins"]) and np.allclose(tM.cpu().numpy(), g["t_maxs"])
+    o = oracle.ray_aabb_intersect(g["rays_o"], g["rays_d"], g["aabbs"], 0.3, 1.1, -1.0)
+    h = na.ray_aabb_intersect(T(g["rays_o"], dev), T(g["rays_d"], dev), T(g["aabbs"], dev), 0.3, 1.1, -1.0)
+    for a, b in zip(h, o):
+        assert (a.cpu().numpy() == b).all()  # bit-exact vs the oracle
+    # mid-points of hits are inside the boxes (tests/test_grid.py:29-35)
+    tmid = torch.clamp((tm + tM) / 2, min=0.0)
+    pts = tmid[:, :, None] * T(g["rays_d"], dev)[:, None, :] + T(g["rays_o"], dev)[:, None, :]
+    ab = T(g["aabbs"], dev)
+    inside = ((pts >= ab[None, :, :3]) & (pts <= ab[None, :, 3:])).all(-1)
+    assert (inside == hit).all()
+
+
+def _cmp_traversal(res, ref):
+    iv, sm, term = res
+    riv, rsm, rterm = ref
+    assert (iv.packed_info.cpu().numpy() == riv["packed_info"]).all(), "interval packed_info"
+    assert (sm.packed_info.cpu().numpy() == rsm["packed_info"]).all(), "sample packed_info"
+    assert (iv.vals.cpu().numpy() == riv["vals"]).all(), "interval vals (bit-exact)"
+    assert (iv.is_left.cpu().numpy() == riv["is_left"]).all() and (iv.is_right.cpu().numpy() == riv["is_right"]).all()
+    assert (iv.ray_indices.cpu().numpy() == riv["ray_indices"]).all()
+    assert (sm.vals.cpu().numpy() == rsm["vals"]).all() and (sm.ray_indices.cpu().numpy() == rsm["ray_indices"]).all()
+    assert (sm.is_valid.cpu().numpy() == rsm["is_valid"]).all()
+    assert (term.cpu().numpy() == rterm).all(), "terminate planes"
+
+
+def test_traverse_grids_multilevel_bit_exact(dev, oracle):
+    g = load_golden("traversal")
+    binaries = np.unpackbits(g["a_binaries"]).astype(bool).reshape(4, 32, 32, 32)
+    o, d, ab = g["a_rays_o"], g["a_rays_d"], g["a_aabbs"]
+    res = na.traverse_grids(T(o, dev), T(d, dev), T(binaries, dev), T(ab, dev))
+    ref = oracle.traverse_grids(o, d, binaries, ab)
+    _cmp_traversal(res, ref)
+    assert (res[0].packed_info.cpu().numpy() == g["a64_iv_packed"]).all()  # committed golden counts
+    assert (res[1].packed_info.cpu().numpy() == g["a64_sm_packed"]).all()
+    # the reference's property test (tests/test_grid.py:57-68) on the first 8 rays
+    iv, sm, _ = res
+    ts, te = iv.vals[iv.is_left], iv.vals[iv.is_right]
+    ri = sm.ray_indices
+    sel8 = ri < 8
+    pos = T(o, dev)[ri] + T(d, dev)[ri] * (ts + te)[:, None] / 2.0
+    occ, selector = na.grid._query(pos[sel8], T(binaries, dev), T(np.array([-1, -1, -1, 1, 1, 1], np.float32), dev))
+    assert selector.all() and occ.float().mean() > 0.9999
+
+
+@pytest.mark.parametrize("tag", ["cfg1", "cfg1b", "cone", "percell"])
+def test_traverse_grids_seeded_cases_bit_exact(dev, oracle, tag):
+    g = load_golden("traversal")
+    o, d, b, ab, nearp, step, cone = seeded_case(g[f"{tag}_params"])
+    res = na.traverse_grids(T(o, dev), T(d, dev), T(b, dev), T(ab, dev), near_planes=T(nearp, dev), step_size=step,
+                            cone_angle=cone)
+    ref = oracle.traverse_grids(o, d, b, ab, near_planes=nearp, step_size=step, cone_angle=cone)
+    _cmp_traversal(res, ref)
+    assert res[1].vals.numel() == int(g[f"{tag}_M"]) and res[0].vals.numel() == int(g[f"{tag}_E"])
+    # explicit intersections (the non-fused kernel) give the same thing for one grid
+    if b.shape[0] == 1:
+        tm, tM, hits = na.ray_aabb_intersect(T(o, dev), T(d, dev), T(ab, dev))
+        t_sorted, t_idx = torch.sort(torch.cat([tm, tM], -1), -1)
+        res2 = na.traverse_grids(T(o, dev), T(d, dev), T(b, dev), T(ab, dev), near_planes=T(nearp, dev),
+                                 step_size=step, cone_angle=cone, t_sorted=t_sorted, t_indices=t_idx, hits=hits)
+        _cmp_traversal(res2, ref)
+
+
+def test_traverse_near_far_planes(dev, oracle):
+    # tests/test_grid.py:135-159
+    ro = torch.tensor([[-1.0, 0.0, 0.0]], device=dev)
+    rd = torch.tensor([[1.0, 0.01, 0.01]], device=dev); rd = rd / rd.norm(dim=-1, keepdim=True)
+    binaries = torch.ones((1, 1, 1, 1), dtype=torch.bool, device=dev)
+    aabbs = torch.tensor([[0.0, 0.0, 0.0, 1.0, 1.0, 1.0]], device=dev)
+    near, far, step = torch.tensor([1.2], device=dev), torch.tensor([1.5], device=dev), 0.05
+    iv, sm, _ = na.traverse_grids(ro, rd, binaries, aabbs, step_size=step, near_planes=near, far_planes=far)
+    assert iv.vals.numel() > 0
+    assert (iv.vals >= (near - step / 2)).all() and (iv.vals <= (far + step / 2)).all()
+    g = load_golden("traversal")
+    assert (iv.vals.cpu().numpy() == g["c_vals"]).all() and (iv.is_left.cpu().numpy() == g["c_left"]).all()
+
+
+def test_traverse_test_mode_over_allocate(dev, oracle):
+    # tests/test_grid.py:72-131 plus bit-exactness of every chunk against the oracle
+    g = load_golden("traversal")
+    binaries = np.unpackbits(g["a_binaries"]).astype(bool).reshape(4, 32, 32, 32)
+    o, d, ab = g["a_rays_o"], g["a_rays_d"], g["a_aabbs"]
+    to, td, tb, tab = T(o, dev), T(d, dev), T(binaries, dev), T(ab, dev)
+    n = o.shape[0]
+    one = na.traverse_grids(to, td, tb, tab)
+    tp = mask = None
+    otp = omask = None
+    total = torch.zeros(n, dtype=torch.long, device=dev)
+    for it in range(8):
+        iv, sm, tp = na.traverse_grids(to, td, tb, tab, near_planes=tp, traverse_steps_limit=4000, over_allocate=True,
+                                       rays_mask=mask)
+        oiv, osm, otp = oracle.traverse_grids(o, d, binaries, ab, near_planes=otp, traverse_steps_limit=4000,
+                                              over_allocate=True, rays_mask=omask)
+        _cmp_traversal((iv, sm, tp), (oiv, osm, otp))
+        assert iv.vals.numel() == (int(mask.sum()) if mask is not None else n) * 8000
+        mask = sm.packed_info[:, 1] == 4000
+        omask = osm["packed_info"][:, 1] == 4000
+        total += sm.packed_info[:, 1]
+        assert (sm.ray_indices[sm.is_valid].cpu().numpy() == osm["ray_indices"][osm["is_valid"]]).all()
+        if not mask.any():
+            break
+    assert (~mask).all()
+    assert ((total - one[1].packed_info[:, 1]).abs() <= 2).all()  # see oracle/gen_golden.py (resume re-seeds the DDA)
+
+
+def test_sampling_bit_exact_and_properties(dev, oracle):
+    # tests/test_grid.py:163-203 recipe, compared with the oracle's restatement of occ_grid.py:85-221
+    rng = np.random.default_rng(42)
+    n_rays, levels, res, step = 256, 4, 32, 0.01
+    o = (rng.random((n_rays, 3)) * 2 - 1).astype(np.float32)
+    d = rng.random((n_rays, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    b = rng.random((levels, res, res, res)) > 0.5
+    t_min = rng.random(n_rays).astype(np.float32); t_max = (t_min + rng.random(n_rays)).astype(np.float32)
+    est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=res, levels=levels).to(dev)
+    est.binaries = T(b, dev)
+    ri, ts, te = est.sampling(T(o, dev), T(d, dev), near_plane=0.15, far_plane=0.85, t_min=T(t_min, dev),
+                              t_max=T(t_max, dev), render_step_size=step)
+    assert (ts >= (T(t_min, dev)[ri] - step / 2)).all() and (te <= (T(t_max, dev)[ri] + step / 2)).all()
+    ab = est.aabbs.cpu().numpy()
+    ori, ots, ote = oracle.occgrid_sampling(o, d, b, ab, near_plane=0.15, far_plane=0.85, t_min=t_min, t_max=t_max,
+                                            render_step_size=step)
+    assert (ri.cpu().numpy() == ori).all() and (ts.cpu().numpy() == ots).all() and (te.cpu().numpy() == ote).all()
+
+    # with a density callback: visibility + compaction.  sigma is an exactly representable function
+    # of the ray index, so only exp() ulps can differ; samples within the guard band may flip.
+    def sigma_np(ts_, te_, ri_):
+        return (1.0 + (ri_ % 7)).astype(np.float32) * 8.0
+
+    est.occs.fill_(0.5)
+    ri2, ts2, te2 = est.sampling(T(o, dev), T(d, dev), sigma_fn=lambda a, b_, c: (1.0 + (c % 7)).float() * 8.0,
+                                 render_step_size=step, early_stop_eps=1e-2, alpha_thre=0.1)
+    (ori2, ots2, ote2), (fri, fts, fte, fpi) = oracle.occgrid_sampling(
+        o, d, b, ab, sigma_fn=sigma_np, render_step_size=step, early_stop_eps=1e-2, alpha_thre=0.1, occs_mean=0.5,
+        return_all=True)
+    tr, al = oracle.render_transmittance_from_density(fts, fte, sigma_np(fts, fte, fri), fpi)
+    thre = min(0.1, 0.5)
+    guard = (np.abs(tr - 1e-2) < 1e-6) | (np.abs(al - thre) < 1e-6)
+    if not guard.any():
+        assert (ri2.cpu().numpy() == ori2).all() and (ts2.cpu().numpy() == ots2).all() and (te2.cpu().numpy() == ote2).all()
+    else:  # every non-guarded sample must agree
+        keep = ~guard
+        vis = oracle.render_visibility_from_density(fts, fte, sigma_np(fts, fte, fri), fpi, 1e-2, thre)
+        exp = set(zip(fri[vis & keep].tolist(), fts[vis & keep].tolist()))
+        got = set(zip(ri2.cpu().numpy().tolist(), ts2.cpu().numpy().tolist()))
+        assert exp <= got and len(got) - len(exp) <= int(guard.sum())
+    assert (ri2[1:] >= ri2[:-1]).all()
+    # alpha_fn spelling
+    ri3, ts3, te3 = est.sampling(T(o, dev), T(d, dev), alpha_fn=lambda a, b_, c: torch.full_like(a, 0.05),
+                                 render_step_size=step, early_stop_eps=0.5, alpha_thre=0.0)
+    cnt = torch.bincount(ri3, minlength=n_rays)
+    assert cnt.max() <= 14  # 0.95^k >= 0.5  =>  k <= 13 samples kept per ray (+1)
+    # empty result
+    est.binaries = torch.zeros_like(est.binaries)
+    r0, t0, t1 = est.sampling(T(o, dev), T(d, dev), sigma_fn=lambda a, b_, c: a, render_step_size=step)
+    assert r0.numel() == 0 and t0.numel() == 0 and r0.dtype == torch.int64
+
+
+# ----------------------------------------------------------------------------- pdf
+def test_importance_sampling_and_searchsorted(dev, oracle):
+    g = load_golden("pdf")
+    for tag in "abc":
+        iv = na.RayIntervals(vals=T(g[f"{tag}_vals"], dev))
+        out_iv, out_sm = na.importance_sampling(iv, T(g[f"{tag}_cdfs"], dev), int(g[f"{tag}_S"]), False)
+        assert_close(out_iv.vals, g[f"{tag}_twin_edges"], atol=1e-4, rtol=0)       # tests/test_pdf.py:93-94
+        assert_close(out_sm.vals, g[f"{tag}_twin_centres"], atol=1e-4, rtol=0)
+        assert_close(out_iv.vals, g[f"{tag}_oracle_edges"], atol=1e-6, rtol=1e-6)
+        assert_close(out_sm.vals, g[f"{tag}_oracle_centres"], atol=1e-6, rtol=1e-6)
+    # docstring examples pdf.py:108-120 (packed input), :40-56
+    iv = na.RayIntervals(vals=torch.tensor([0.0, 1.0, 0.0, 1.0, 2.0], device=dev),
+                         packed_info=torch.tensor([[0, 2], [2, 3]], device=dev))
+    o_iv, o_sm = na.importance_sampling(iv, torch.tensor([0.0, 0.5, 0.0, 0.5, 1.0], device=dev), 2)
+    assert torch.allclose(o_iv.vals, torch.tensor([[0, 0.5, 1.0], [0, 1.0, 2.0]], device=dev))
+    assert torch.allclose(o_sm.vals, torch.tensor([[0.25, 0.75], [0.5, 1.5]], device=dev))
+    vals = na.RayIntervals(vals=torch.tensor([0.5, 1.5, 2.5], device=dev), packed_info=torch.tensor([[0, 1], [1, 2]], device=dev))
+    l, r = na.searchsorted(iv, vals)
+    assert l.tolist() == [0, 3, 3] and r.tolist() == [1, 4, 4]
+    # batched searchsorted vs torch (tests/test_pdf.py:46-62) and vs the oracle
+    key, query = T(g["loss_k_vals"], dev), T(g["loss_q_vals"], dev)
+    il, ir = na.searchsorted(na.RayIntervals(vals=key), na.RayIntervals(vals=query))
+    ref = torch.clamp(torch.searchsorted(key, query, right=True), 0, key.shape[-1] - 1)
+    assert (ir == ref).all() and (il.cpu().numpy() == g["loss_ids_left"]).all()
+    # RaySamples as query (broken in the reference, data_specs.py:57)
+    il2, _ = na.searchsorted(na.RayIntervals(vals=key), na.RaySamples(vals=query))
+    assert (il2 == il).all()
+    # _pdf_loss == reference's _lossfun_outer where both are defined (tests/test_pdf.py:98-127)
+    from nerfacc_amd.estimators.prop_net import _pdf_loss
+    loss = _pdf_loss(na.RayIntervals(vals=query), T(g["loss_q_cdfs"], dev), na.RayIntervals(vals=key), T(g["loss_k_cdfs"], dev))
+    inside = g["loss_inside"]
+    assert np.allclose(loss.cpu().numpy()[inside], g["loss_ref"][inside], atol=1e-4)
+    # long rows (S > 64) and stratified determinism / statistics
+    rng = np.random.default_rng(8)
+    v = np.sort(rng.random((33, 300)), -1).astype(np.float32); c = np.sort(rng.random((33, 300)), -1).astype(np.float32)
+    o_iv, o_sm = na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), 150)
+    e_iv, e_sm = oracle.importance_sampling(v, c, 150)
+    assert_close(o_iv.vals, e_iv, atol=1e-6, rtol=1e-6); assert_close(o_sm.vals, e_sm, atol=1e-6, rtol=1e-6)
+    torch.manual_seed(123)
+    gen = torch.cuda.default_generators[0]
+    seed, off = gen.initial_seed(), gen.get_offset()
+    s_iv, s_sm = na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), 16, stratified=True)
+    assert gen.get_offset() == off + 4                                  # pdf.cu:376-383
+    e_iv, e_sm = oracle.importance_sampling(v, c, 16, True, seed=seed, offset=off)
+    assert_close(s_sm.vals, e_sm, atol=1e-6, rtol=1e-6)                # same Philox stream as the oracle
+    s2_iv, _ = na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), 16, stratified=True)
+    assert not torch.equal(s_iv.vals, s2_iv.vals)                       # generator advanced
+    with pytest.raises(ValueError):
+        na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), 1)
+    with pytest.raises(NotImplementedError):
+        na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), torch.tensor([3] * 33, device=dev))
+
+
+def test_propnet_sampling_and_loss(dev):
+    est = na.PropNetEstimator().to(dev)
+    n_rays = 257
+    fn = lambda ts, te: torch.exp(-((ts + te) * 0.5 - 4.0) ** 2) * 3.0
+    ts, te = est.sampling([fn, fn], [64, 32], 16, n_rays, 2.0, 6.0, sampling_type="uniform")
+    assert ts.shape == (n_rays, 16) and (te > ts).all() and (ts >= 2.0 - 1e-5).all() and (te <= 6.0 + 1e-5).all()
+    assert (ts[:, 1:] == te[:, :-1]).all()
+    # samples concentrate where the proposal density is high
+    assert ((ts + te) * 0.5 - 4.0).abs().median() < 0.8
+    ts2, te2 = est.sampling([fn], [48], 24, n_rays, 2.0, 6.0, sampling_type="lindisp", stratified=True)
+    assert ts2.shape == (n_rays, 24) and (te2 > ts2).all()
+    # training path: cached proposals + loss gradient reaches the proposal parameters
+    p = torch.nn.Parameter(torch.tensor(3.0, device=dev))
+    est2 = na.PropNetEstimator(optimizer=torch.optim.SGD([p], lr=1e-2)).to(dev)
+    pfn = lambda ts, te: torch.exp(-((ts + te) * 0.5 - 4.0) ** 2) * p
+    ts, te = est2.sampling([pfn], [64], 16, n_rays, 2.0, 6.0, sampling_type="uniform", requires_grad=True)
+    sig = fn(ts, te)
+    trans, _ = na.render_transmittance_from_density(ts, te, sig)
+    loss = est2.update_every_n_steps(trans, requires_grad=True)
+    assert np.isfinite(loss) and len(est2.prop_cache) == 0 and float(p) != 3.0
+
+
+# ----------------------------------------------------------------------------- full-size properties (BASELINE cfg 2)
+def test_full_size_properties(dev):
+    """1024x1024 rays through a 128^3 grid at ~10% occupancy: size-independent invariants."""
+    import bench
+    w = bench.make_workload(dev, n_rays=1024 * 1024, res=128)
+    est = w["estimator"]
+    ri, ts, te = est.sampling(w["rays_o"], w["rays_d"], sigma_fn=w["sigma_fn"], render_step_size=w["step"],
+                              early_stop_eps=1e-4, alpha_thre=0.0)
+    n = w["rays_o"].shape[0]
+    assert ri.dtype == torch.int64 and (ri[1:] >= ri[:-1]).all() and ri.min() >= 0 and ri.max() < n
+    assert (te > ts).all() and (ts >= 0).all()
+    pi = na.pack_info(ri, n)
+    assert int(pi[:, 1].sum()) == ri.numel() and (pi[1:, 0] == pi[:-1, 0] + pi[:-1, 1]).all()
+    assert int(pi[:, 1].max()) <= 1024
+    # same ray: samples are ordered and disjoint
+    same = ri[1:] == ri[:-1]
+    assert (ts[1:][same] >= te[:-1][same] - 1e-6).all()
+    sig = w["sigma_fn"](ts, te, ri)
+    wts, tr, al = na.render_weight_from_density(ts, te, sig, ray_indices=ri, n_rays=n)
+    opac = na.accumulate_along_rays(wts, None, ri, n)
+    assert (opac <= 1.0 + 1e-4).all() and (wts >= 0).all() and (tr <= 1.0).all()
+    # telescoping identity: sum_k w_k = 1 - T_last * (1 - alpha_last)
+    last = torch.zeros(n, dtype=torch.bool, device=dev); has = pi[:, 1] > 0
+    idx_last = (pi[:, 0] + pi[:, 1] - 1)[has]
+    resid = 1.0 - tr[idx_last] * (1.0 - al[idx_last])
+    assert torch.allclose(opac[has, 0], resid, atol=2e-5)
+    # linearity of the accumulation
+    v = torch.rand((ri.numel(), 3), device=dev)
+    a1 = na.accumulate_along_rays(wts, v, ri, n); a2 = na.accumulate_along_rays(wts, 2 * v, ri, n)
+    assert torch.allclose(a2, 2 * a1, atol=1e-5)
+    # checksum against torch's atomics path
+    ref = torch.zeros((n, 3), device=dev).index_add_(0, ri, wts[:, None] * v)
+    assert torch.allclose(a1, ref, atol=2e-5)
+    del last

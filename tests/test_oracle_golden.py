@@ -1,0 +1,117 @@
+"""CPU: the oracle (oracle/nerfacc_oracle.c) against the committed golden fixtures (outputs of
+the imported reference, oracle/gen_golden.py) and against the reference's own hard-coded test
+vectors."""
+import hashlib
+
+import numpy as np
+import torch
+
+from conftest import assert_close, load_golden, seeded_case
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_reference_known_answers(oracle):
+    O = oracle
+    # tests/test_pack.py:11-18
+    assert O.pack_info([0, 2, 2, 2, 2], 3).tolist() == [[0, 1], [1, 0], [1, 4]]
+    pi = np.array([[0, 1], [1, 0], [1, 4]])
+    alphas = np.array([0.4, 0.3, 0.8, 0.8, 0.5], np.float32)
+    # tests/test_rendering.py:11-34
+    assert O.render_visibility_from_alpha(alphas, pi, 0.03, 0.0).tolist() == [True, True, True, True, False]
+    assert O.render_visibility_from_alpha(alphas, pi, 0.05, 0.35).tolist() == [True, False, True, True, False]
+    # tests/test_rendering.py:41-57
+    w, _ = O.render_weight_from_alpha(alphas, pi)
+    assert np.allclose(w, [0.4, 0.3, 0.7 * 0.8, 0.14 * 0.8, 0.028 * 0.5])
+    # tests/test_rendering.py:117-133 (test_grads), t_ends = t_starts + 1
+    sig = np.array([0.4, 0.8, 0.1, 0.8, 0.1], np.float32)
+    ts = np.random.default_rng(0).random(5).astype(np.float32)
+    w, _, _ = O.render_weight_from_density(ts, ts + 1, sig, pi)
+    assert np.allclose(w, [0.3297, 0.5507, 0.0428, 0.2239, 0.0174], atol=1e-4)
+    g = O.render_weight_from_density_backward(ts, ts + 1, sig, pi, np.ones(5))
+    assert np.allclose(g, [0.6703, 0.1653, 0.1653, 0.1653, 0.1653], atol=1e-4)
+    # docstrings scan.py:36-39,78-81,127-130,170-173
+    x = np.arange(1, 10, dtype=np.float32)
+    p3 = np.array([[0, 2], [2, 3], [5, 4]])
+    assert O.inclusive_sum(x, p3).tolist() == [1, 3, 3, 7, 12, 6, 13, 21, 30]
+    assert O.exclusive_sum(x, p3).tolist() == [0, 1, 0, 3, 7, 0, 6, 13, 21]
+    assert O.inclusive_prod(x, p3).tolist() == [1, 2, 3, 12, 60, 6, 42, 336, 3024]
+    assert O.exclusive_prod(x, p3).tolist() == [1, 1, 1, 3, 12, 1, 6, 42, 336]
+    # docstrings volrend.py:192-195, 298-302
+    a7 = np.array([0.4, 0.8, 0.1, 0.8, 0.1, 0.0, 0.9], np.float32)
+    p7 = O.pack_info([0, 0, 0, 1, 1, 2, 2], 3)
+    assert np.allclose(O.render_transmittance_from_alpha(a7, p7), [1.0, 0.6, 0.12, 1.0, 0.2, 1.0, 1.0])
+    assert np.allclose(O.render_weight_from_alpha(a7, p7)[0], [0.4, 0.48, 0.012, 0.8, 0.02, 0.0, 0.9])
+    assert O.render_visibility_from_alpha(a7, p7, 0.3, 0.2).tolist() == [True, True, False, True, False, False, True]
+    # Philox4x32-10 known-answer vectors (Random123 kat_vectors)
+    assert [hex(v) for v in O.philox4x32_10([0] * 4, [0] * 2)] == ['0x6627e8d5', '0xe169c58d', '0xbc57ac4c', '0x9b00dbd8']
+    assert [hex(v) for v in O.philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2)] == \
+        ['0x408f276d', '0x41c83b0e', '0xa20bc7c6', '0x6d5451fd']
+    assert [hex(v) for v in O.philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])] == \
+        ['0xd16cfe09', '0x94fdcceb', '0x5001e420', '0x24126ea1']
+
+
+def test_ragged_packed_vs_reference(oracle):
+    O, g = oracle, load_golden("ragged_packed")
+    pi = g["packed_info"]
+    for kind, inp in (("inclusive_sum", g["x"]), ("exclusive_sum", g["x"]), ("inclusive_prod", g["xp"]),
+                      ("exclusive_prod", g["xp"])):
+        y = O.packed_scan(kind, inp, pi)
+        assert_close(y, g[kind], atol=1e-5, rtol=2e-5, what=kind)
+        gi = O.sum_backward(kind, g["g"], pi) if kind.endswith("sum") else O.prod_backward(kind, inp, y, g["g"], pi)
+        assert_close(gi, g[kind + "_grad"], atol=2e-5, rtol=1e-4, what=kind + " grad")
+    w, t, a = O.render_weight_from_density(g["ts"], g["te"], g["sig"], pi)
+    assert_close(w, g["rwd_w"]); assert_close(t, g["rwd_t"]); assert_close(a, g["rwd_a"])
+    gs = O.render_weight_from_density_backward(g["ts"], g["te"], g["sig"], pi, g["gw"], g["gt"], g["ga"])
+    assert_close(gs, g["rwd_gsig"], atol=2e-5, rtol=1e-4)
+    w2, t2, _ = O.render_weight_from_density(g["ts"], g["te"], g["sig"], pi, prefix_trans=g["pref"])
+    assert_close(w2, g["rwd_pref_w"]); assert_close(t2, g["rwd_pref_t"])
+    wa, ta = O.render_weight_from_alpha(g["alph"], pi)
+    assert_close(wa, g["rwa_w"]); assert_close(ta, g["rwa_t"])
+    vd = O.render_visibility_from_density(g["ts"], g["te"], g["sig"], pi, float(g["eps_t"]), float(g["thre"]))
+    va = O.render_visibility_from_alpha(g["alph"], pi, float(g["eps_t"]), float(g["thre"]))
+    assert ((vd == g["vis_d"]) | g["guard_d"]).all() and ((va == g["vis_a"]) | g["guard_a"]).all()
+    n_rays = pi.shape[0]
+    assert_close(O.accumulate_along_rays(g["rwd_w"], g["rgb"], g["ray_indices"], n_rays), g["acc_rgb"], atol=1e-5)
+    c, o, d, _ = O.rendering(g["ts"], g["te"], g["ray_indices"], n_rays, g["rgb"], sigmas=g["sig"], render_bkgd=g["bkgd"])
+    assert_close(c, g["rend_colors"], atol=1e-5); assert_close(d, g["rend_depths"], atol=1e-5, rtol=1e-4)
+    assert (O.pack_info(g["ray_indices"], n_rays) == pi).all()
+
+
+def test_ray_aabb_vs_reference_twin(oracle):
+    g = load_golden("ray_aabb")
+    tm, tM, hit = oracle.ray_aabb_intersect(g["rays_o"], g["rays_d"], g["aabbs"])
+    assert (hit == g["hits"]).all()
+    assert np.allclose(tm, g["t_mins"]) and np.allclose(tM, g["t_maxs"])  # tests/test_grid.py:25-27
+
+
+def test_pdf_vs_reference_twin(oracle):
+    O, g = oracle, load_golden("pdf")
+    for tag in "abc":
+        iv, sm = O.importance_sampling(g[f"{tag}_vals"], g[f"{tag}_cdfs"], int(g[f"{tag}_S"]), False)
+        assert_close(iv, g[f"{tag}_twin_edges"], atol=1e-4, rtol=0)  # tests/test_pdf.py:93-94
+        assert_close(sm, g[f"{tag}_twin_centres"], atol=1e-4, rtol=0)
+        assert (iv == g[f"{tag}_oracle_edges"]).all() and (sm == g[f"{tag}_oracle_centres"]).all()
+    il, ir = O.searchsorted(g["loss_k_vals"], g["loss_q_vals"])
+    ref = torch.clamp(torch.searchsorted(torch.from_numpy(g["loss_k_vals"]), torch.from_numpy(g["loss_q_vals"]), right=True),
+                      0, g["loss_k_vals"].shape[-1] - 1).numpy()
+    assert (ir == ref).all()  # tests/test_pdf.py:57-62
+    assert (il == g["loss_ids_left"]).all()
+
+
+def test_traversal_golden(oracle):
+    O, g = oracle, load_golden("traversal")
+    binaries = np.unpackbits(g["a_binaries"]).astype(bool).reshape(4, 32, 32, 32)
+    iv, sm, term = O.traverse_grids(g["a_rays_o"][:8], g["a_rays_d"][:8], binaries, g["a_aabbs"])
+    assert (iv["vals"] == g["a8_iv_vals"]).all() and (iv["is_left"] == g["a8_iv_left"]).all()
+    assert (iv["is_right"] == g["a8_iv_right"]).all() and (iv["packed_info"] == g["a8_iv_packed"]).all()
+    assert (sm["packed_info"] == g["a8_sm_packed"]).all() and (term == g["a8_term"]).all()
+    for tag in ("cfg1", "cone", "percell"):
+        o, d, b, ab, nearp, step, cone = seeded_case(g[f"{tag}_params"])
+        iv, sm, term = O.traverse_grids(o, d, b, ab, near_planes=nearp, step_size=step, cone_angle=cone)
+        assert len(sm["vals"]) == int(g[f"{tag}_M"]) and len(iv["vals"]) == int(g[f"{tag}_E"])
+        assert sha(sm["packed_info"]) == str(g[f"{tag}_sm_cnts_sha"])
+        assert sha(iv["vals"]) == str(g[f"{tag}_iv_vals_sha"])
+        assert sha(term) == str(g[f"{tag}_term_sha"])
