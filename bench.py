@@ -12,7 +12,7 @@ One "step" = one pass of the hot path over one synthetic batch (cf
 
 Rank 0 prints ONE JSON line.  Inputs are resident in HBM before the timed region.  Rays shard
 across ranks (independent batches, weak scaling); the only collective is the all-reduce of the
-tiny parameter gradient.
+2-float parameter gradient.
 """
 from __future__ import annotations
 
@@ -78,7 +78,10 @@ def make_workload(dev, n_rays: int = 1024 * 1024, res: int = 128, grid: str = "s
     est.binaries = torch.from_numpy(b).to(dev)
     est.occs = torch.from_numpy(b.reshape(-1).astype(np.float32)).to(dev)
     step = 2 * math.sqrt(3) / 1024                          # <= 1024 samples per ray
-    params = torch.nn.Parameter(torch.tensor([1.0, 1.0, 1.0, 1.0], device=dev))   # [sigma scale, r, g, b]
+    # two scalar parameters (density scale, colour scale): the "network" of this synthetic step.
+    # (scalar leaves keep the user-side backward to flat reductions; a [M,3]->[3] column
+    # reduction in torch costs more than the whole native pipeline.)
+    params = torch.nn.Parameter(torch.tensor([1.0, 1.0], device=dev))
 
     def base_sigma(ts, te):
         return 4.0 * (0.5 + 0.5 * torch.sin(20.0 * (ts + te)))
@@ -87,7 +90,7 @@ def make_workload(dev, n_rays: int = 1024 * 1024, res: int = 128, grid: str = "s
         return base_sigma(ts, te)
 
     def rgb_sigma_fn(ts, te, ri):                            # used inside rendering (with grad)
-        rgbs = ts[:, None] * params[1:][None, :]
+        rgbs = torch.stack([ts, ts, ts], dim=-1) * params[1]
         return rgbs, base_sigma(ts, te) * params[0]
 
     return dict(estimator=est, rays_o=torch.from_numpy(o).to(dev), rays_d=torch.from_numpy(d).to(dev),
@@ -105,7 +108,7 @@ def run_step(w, world_size: int = 1):
     w["params"].grad = None
     loss.backward()
     if world_size > 1:
-        torch.distributed.all_reduce(w["params"].grad)      # RCCL over xGMI: 16 bytes
+        torch.distributed.all_reduce(w["params"].grad)      # RCCL over xGMI: 8 bytes
     return ri.numel(), loss
 
 
@@ -157,6 +160,8 @@ def algorithmic_bytes(R, M, Mv, res, G=1):
     return {
         "nfa_traverse_grids[mode=0]": R * (24 + 8) + grid + R * 8,                 # rays + planes, grid, counts
         "nfa_traverse_grids[mode=1]": R * (24 + 8) + grid + M * (4 + 4 + 8) + R * 16,  # + samples, packed_info
+        "nfa_traverse_runs": R * (24 + 8) + grid + R * 8,                            # one DDA walk: rays, grid, counts
+        "nfa_expand_runs": M * (4 + 4 + 8) + R * 16,                                 # the sampler's output, once
         "nfa_render_visibility": M * (4 + 4 + 4) + R * 16 + M * 1 + R * 8,
         "nfa_compact_samples": M * (1 + 4 + 4) + R * 24 + Mv * 16,
         "nfa_render_from_density_fwd": Mv * (12 + 12) + R * 16,

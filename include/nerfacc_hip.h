@@ -109,8 +109,31 @@ typedef struct nfa_traverse_args {
     float *sm_t_starts; float *sm_t_ends;       /* sample-only fast path */
     int64_t *sm_starts; int64_t *sm_cnts;
     float *terminate_planes;    /* [n_rays] or NULL */
+    /* optional ray filter (mode 1): only rays with ray_filter[r] > ray_filter_min are processed */
+    const int32_t *ray_filter;
+    int32_t ray_filter_min;
 } nfa_traverse_args;
 int nfa_traverse_grids(const nfa_traverse_args *args, nfa_stream_t stream);
+
+/* Run-length traversal used by the sampler when step_size > 0 and cone_angle == 0 (same results
+ * as nfa_traverse_grids' sample-only path, one DDA walk instead of two, coalesced output):
+ *   nfa_pack_bricks    torch.bool grid -> 4x4x4-cell 64-bit bricks + 1 bit per brick ("coarse");
+ *                      bricks has nfa_bricks_words() entries, coarse (words+31)/32 uint32.
+ *   nfa_traverse_runs  per ray: sample count (args->sm_cnts), terminate plane, run count and up to
+ *                      max_runs (<= 32) runs {t_first:f32 | n:31, continues_previous:1}; rays with
+ *                      more runs are counted in *overflow_count and must be filled with
+ *                      nfa_traverse_grids(mode 1, ray_filter = run_cnts, ray_filter_min = max_runs).
+ *                      args->mode: 0 = all rays, 2 = honour rays_mask (+ traverse_steps_limit).
+ *   nfa_expand_runs    runs + exclusive cumsum of the counts -> t_starts, t_ends, ray_indices. */
+int64_t nfa_bricks_words(int32_t n_grids, const int32_t *res);
+int nfa_pack_bricks(const uint8_t *binaries, int32_t n_grids, const int32_t *res, uint64_t *bricks,
+                    uint32_t *coarse, nfa_stream_t stream);
+int nfa_traverse_runs(const nfa_traverse_args *args, const uint64_t *bricks, const uint32_t *coarse,
+                      int32_t *run_cnts, uint64_t *runs, int32_t max_runs, int32_t *overflow_count,
+                      nfa_stream_t stream);
+int nfa_expand_runs(int64_t n_rays, float step_size, const int32_t *run_cnts, const uint64_t *runs,
+                    int32_t max_runs, const int64_t *sm_starts, const int64_t *sm_cnts, float *t_starts,
+                    float *t_ends, int64_t *ray_indices, nfa_stream_t stream);
 
 /* ------------------------------------------------------------------ packed segments */
 

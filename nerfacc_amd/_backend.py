@@ -36,6 +36,7 @@ class TraverseArgs(C.Structure):
         ("sm_vals", _vp), ("sm_ray_indices", _vp), ("sm_is_valid", _vp),
         ("sm_t_starts", _vp), ("sm_t_ends", _vp), ("sm_starts", _vp), ("sm_cnts", _vp),
         ("terminate_planes", _vp),
+        ("ray_filter", _vp), ("ray_filter_min", _i32),
     ]
 
 
@@ -46,6 +47,10 @@ _SIGS = {
     "nfa_pack_bits": [_vp, _i64, _vp, _vp],
     "nfa_ray_aabb_intersect": [_vp, _vp, _i64, _vp, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
     "nfa_traverse_grids": [C.POINTER(TraverseArgs), _vp],
+    "nfa_bricks_words": [_i32, C.POINTER(_i32)],
+    "nfa_pack_bricks": [_vp, _i32, C.POINTER(_i32), _vp, _vp, _vp],
+    "nfa_traverse_runs": [C.POINTER(TraverseArgs), _vp, _vp, _vp, _vp, _i32, _vp, _vp],
+    "nfa_expand_runs": [_i64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "nfa_seg_build_tiles": [_vp, _i64, _i64, _vp, _vp, _vp],
     "nfa_packed_scan": [_int, _int, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
     "nfa_packed_scan_generic": [_int, _int, _int, _vp, _i64, _i64, _vp, _vp, _vp],
@@ -69,7 +74,7 @@ _SIGS = {
     "nfa_version": [],
     "nfa_device_arch": [C.c_char_p, _int],
 }
-_RESTYPES = {"nfa_cumsum_scratch_bytes": _i64, "nfa_seg_num_tiles": _i64, "nfa_last_error": C.c_char_p}
+_RESTYPES = {"nfa_bricks_words": _i64, "nfa_cumsum_scratch_bytes": _i64, "nfa_seg_num_tiles": _i64, "nfa_last_error": C.c_char_p}
 
 EXPORTED_SYMBOLS = tuple(_SIGS)
 SEG_TILE = 2048  # NFA_SEG_TILE

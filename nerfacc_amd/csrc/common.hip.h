@@ -33,7 +33,7 @@ void set_error(const char *fmt, ...);
 
 static inline hipStream_t as_stream(nfa_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
-static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Grid for 1-D grid-stride kernels: enough workgroups to fill 256 CUs x 8 blocks.
 static inline unsigned grid_1d(int64_t n, int block, int64_t cap = 256 * 16)

@@ -12,6 +12,7 @@
 #include <stdarg.h>
 
 #include "common.hip.h"
+#include "march.h"
 
 namespace nfa {
 
@@ -72,25 +73,7 @@ __global__ __launch_bounds__(256) void ray_aabb_kernel(const float *__restrict__
 // ------------------------------------------------------------------------------------------
 // Traversal, grid.cu:68-282; helpers include/utils_grid.cuh:58-142.
 
-__device__ __forceinline__ float calc_dt(float t, float cone_angle, float step)
-{
-    return fmaxf(step, fminf(t * cone_angle, 1e10f));  // grid.cu:23-28, utils_math.cuh:1167
-}
-
-// March t_last in whole steps until the step's mid-point reaches `target`
-// (grid.cu:153-163, :196-205).  dt is evaluated once, as in the reference.
-__device__ __forceinline__ float fast_forward(float t_last, float target, float step, float cone_angle)
-{
-    if (step <= 0.0f) return target;
-    const float dt = calc_dt(t_last, cone_angle, step);
-    const float half = dt * 0.5f;
-    while (t_last + half < target) {
-        const float t_new = t_last + dt;
-        if (t_new == t_last) { t_last = target; break; }  // no progress: the reference would spin
-        t_last = t_new;
-    }
-    return t_last;
-}
+// calc_dt / fast_forward: march.h (exact O(#binades) form of the loops at grid.cu:153-163, :196-205)
 
 enum { EMIT_NONE = 0, EMIT_API = 1, EMIT_DIRECT = 2 };
 
@@ -219,6 +202,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(const nfa_traverse_args a
             if (HAS_SM) a.sm_cnts[tid] = 0;
             continue;
         }
+        if (a.ray_filter != nullptr && a.ray_filter[tid] <= a.ray_filter_min) continue;
         int64_t iv_base = 0, sm_base = 0;
         if (EMIT != EMIT_NONE) {
             if (a.mode == 1) {  // grid.cu:103-106: nothing to fill for empty rays

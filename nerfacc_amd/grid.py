@@ -4,7 +4,7 @@
 (grid.py:13-51, :93-192).  The host orchestration the reference does in C++
 (cuda/csrc/grid.cu:320-474: count pass, cumsum, ``.item()``, allocation, fill pass) lives here
 in Python over the C ABI; it needs ONE device->host read (both totals at once) instead of the
-reference's two, and none in over-allocate mode.
+reference's two.
 """
 from __future__ import annotations
 
@@ -203,6 +203,28 @@ def traverse_grids(
     return intervals, samples, terminate
 
 
+MAX_RUNS = 32  # runs kept per ray by the run-length traversal (csrc/traverse2.hip)
+
+
+def _get_bricks(binaries: Tensor):
+    """Brick-packed copy of ``binaries`` (derived cache, keyed on the tensor's version counter;
+    never serialised -- the state_dict keeps the reference's torch.bool buffer)."""
+    cached = getattr(binaries, "_nfa_bricks", None)
+    if cached is not None and cached[0] == binaries._version:
+        return cached[1], cached[2]
+    dev = binaries.device
+    res = (C.c_int32 * 3)(*binaries.shape[1:])
+    words = int(B.load().nfa_bricks_words(binaries.shape[0], res))
+    bricks = torch.empty(words, dtype=torch.int64, device=dev)
+    coarse = torch.empty((words + 31) // 32, dtype=torch.int32, device=dev)
+    B.call("nfa_pack_bricks", B.ptr(binaries), binaries.shape[0], res, B.ptr(bricks), B.ptr(coarse), B.stream())
+    try:
+        binaries._nfa_bricks = (binaries._version, bricks, coarse)
+    except Exception:  # pragma: no cover
+        pass
+    return bricks, coarse
+
+
 @torch.no_grad()
 def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size, cone_angle):
     """Sampler fast path: (ray_indices, t_starts, t_ends, packed_info) straight from the traversal.
@@ -210,28 +232,43 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
     Same values as ``intervals.vals[is_left]``, ``intervals.vals[is_right]``,
     ``samples.ray_indices``, ``samples.packed_info`` of :func:`traverse_grids`
     (ref: estimators/occ_grid.py:164-177) without materialising edges and masks and without
-    the two boolean-index syncs."""
+    the two boolean-index syncs.  Constant-step marching (``cone_angle == 0``) takes the
+    run-length path: one DDA walk per ray + a fully parallel, coalesced expansion."""
     (dev, rays_o, rays_d, binaries, aabbs, near_planes, far_planes, _, t_sorted, t_indices,
      hits) = _prepare(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, None, None, None, None,
                       allow_fused=True)
     n_rays = rays_o.shape[0]
+    use_runs = float(step_size) > 0.0 and float(cone_angle) == 0.0
     with torch.cuda.device(dev):
         sm_cnts = torch.empty(n_rays, dtype=torch.int64, device=dev)
-        total = torch.empty(1, dtype=torch.int64, device=dev)
+        meta = torch.zeros(2, dtype=torch.int64, device=dev)  # [total samples, rays with too many runs]
         a = _traverse_args(rays_o, rays_d, None, binaries, aabbs, t_sorted, t_indices, hits, near_planes, far_planes,
                            step_size, cone_angle, -1, 0)
         a.sm_cnts = B.ptr(sm_cnts)
-        _launch(a)
-        sm_starts = _exclusive_cumsum(sm_cnts, total)
-        n_sm = int(total.item())  # the one device->host read of the sampler's traversal
+        if use_runs:
+            bricks, coarse = _get_bricks(binaries)
+            run_cnts = torch.empty(n_rays, dtype=torch.int32, device=dev)
+            runs = torch.empty((n_rays, MAX_RUNS), dtype=torch.int64, device=dev)
+            B.call("nfa_traverse_runs", C.byref(a), B.ptr(bricks), B.ptr(coarse), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
+                   B.ptr(meta[1:2]), B.stream())
+        else:
+            _launch(a)
+        sm_starts = _exclusive_cumsum(sm_cnts, meta[0:1])
+        n_sm, n_overflow = (int(v) for v in meta.tolist())  # the one device->host read of the traversal
         t_starts = torch.empty(n_sm, dtype=torch.float32, device=dev)
         t_ends = torch.empty(n_sm, dtype=torch.float32, device=dev)
         ray_indices = torch.empty(n_sm, dtype=torch.int64, device=dev)
         if n_sm > 0:
-            a.mode = 1
-            a.sm_starts = B.ptr(sm_starts)
-            a.sm_t_starts, a.sm_t_ends, a.sm_ray_indices = B.ptr(t_starts), B.ptr(t_ends), B.ptr(ray_indices)
-            _launch(a)
+            if use_runs:
+                B.call("nfa_expand_runs", n_rays, float(step_size), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
+                       B.ptr(sm_starts), B.ptr(sm_cnts), B.ptr(t_starts), B.ptr(t_ends), B.ptr(ray_indices), B.stream())
+            if not use_runs or n_overflow > 0:
+                a.mode = 1
+                a.sm_starts = B.ptr(sm_starts)
+                a.sm_t_starts, a.sm_t_ends, a.sm_ray_indices = B.ptr(t_starts), B.ptr(t_ends), B.ptr(ray_indices)
+                if use_runs:  # only the rays whose runs did not fit
+                    a.ray_filter, a.ray_filter_min = B.ptr(run_cnts), MAX_RUNS
+                _launch(a)
         packed_info = torch.stack([sm_starts, sm_cnts], dim=-1)
     info = tag_trusted(packed_info, n_sm)
     tag_ray_indices(ray_indices, n_rays, info)

@@ -462,6 +462,38 @@ def test_sampling_bit_exact_and_properties(dev, oracle):
     assert r0.numel() == 0 and t0.numel() == 0 and r0.dtype == torch.int64
 
 
+@pytest.mark.parametrize("tag", ["cfg1", "cfg1b"])
+def test_sampler_run_length_path_bit_exact(dev, oracle, tag):
+    """OccGridEstimator.sampling's traversal (brick grid + runs + parallel expansion, with the
+    serial fill for rays that have more than 32 runs) == oracle's two-pass traversal, bit for bit."""
+    g = load_golden("traversal")
+    o, d, b, ab, nearp, step, cone = seeded_case(g[f"{tag}_params"])
+    ri, ts, te, pi = na.grid._traverse_samples(T(o, dev), T(d, dev), T(b, dev), T(ab, dev), T(nearp, dev),
+                                               torch.full((o.shape[0],), 1e10, device=dev), step, cone)
+    iv, sm, _ = oracle.traverse_grids(o, d, b, ab, near_planes=nearp, far_planes=np.full(o.shape[0], 1e10, np.float32),
+                                      step_size=step, cone_angle=cone)
+    assert (pi.cpu().numpy() == sm["packed_info"]).all()
+    assert (ri.cpu().numpy() == sm["ray_indices"]).all()
+    assert (ts.cpu().numpy() == iv["vals"][iv["is_left"]]).all() and (te.cpu().numpy() == iv["vals"][iv["is_right"]]).all()
+    assert ri.numel() == int(g[f"{tag}_M"])
+
+
+def test_sampler_odd_resolution_global_brick_mask(dev, oracle):
+    """Resolution not a multiple of 4 and a brick mask too large for LDS (65^3 bricks)."""
+    rng = np.random.default_rng(5)
+    R, res = 2048, 258
+    o = rng.standard_normal((R, 3)).astype(np.float32) * 0.7
+    d = rng.standard_normal((R, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    b = rng.random((1, res, res - 3, res + 1)) < 0.03
+    ab = np.array([[-1, -1.5, -1, 1, 1, 1.25]], np.float32)
+    near = np.zeros(R, np.float32); far = np.full(R, 1e10, np.float32)
+    ri, ts, te, pi = na.grid._traverse_samples(T(o, dev), T(d, dev), T(b, dev), T(ab, dev), T(near, dev), T(far, dev),
+                                               3e-3, 0.0)
+    iv, sm, _ = oracle.traverse_grids(o, d, b, ab, near_planes=near, far_planes=far, step_size=3e-3)
+    assert (pi.cpu().numpy() == sm["packed_info"]).all() and (ri.cpu().numpy() == sm["ray_indices"]).all()
+    assert (ts.cpu().numpy() == iv["vals"][iv["is_left"]]).all() and (te.cpu().numpy() == iv["vals"][iv["is_right"]]).all()
+
+
 # ----------------------------------------------------------------------------- pdf
 def test_importance_sampling_and_searchsorted(dev, oracle):
     g = load_golden("pdf")
