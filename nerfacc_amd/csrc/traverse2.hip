@@ -9,10 +9,13 @@
 //   runs pass     ONE DDA walk per ray (thread per ray).  The brick mask lives in LDS, a brick
 //                 word is fetched (8 B, L2) only when the ray enters a non-empty brick, and the
 //                 current word is cached in registers, so most cells cost no memory access.
-//                 Marching is the exact O(#binades) fast-forward of march.h, deferred across runs
-//                 of empty cells (legal for a constant step: see flush_pending).  Instead of
-//                 samples the pass emits RUNS: (t_first, n) for n consecutive samples with one
-//                 exact fp32 increment -- typically 3-10 per ray (8 B each).
+//                 The walk does no marching: it records one typed threshold per run of cells of
+//                 one kind (a handful per ray, in LDS).  A second, lock-step phase marches through
+//                 those thresholds with the exact O(#binades) jumps of march.h -- skipping and
+//                 sample emission are the same code path, emission being "count the steps" -- so
+//                 there is no per-sample loop and no per-cell divergence.  Instead of samples the
+//                 pass emits RUNS: (t_first, n) for n consecutive samples with one exact fp32
+//                 increment -- typically 2-10 per ray (8 B each).
 //   expand pass   after the device-side cumsum of the sample counts, every output element is
 //                 computed independently: t_start = t_first + k*inc, t_end = t_first + (k+1)*inc
 //                 (exact: multiples of one ulp inside a binade), ray index from the run.  A wave
@@ -27,7 +30,7 @@ namespace nfa {
 
 constexpr int EXP_RPW = 32;        // rays per wave batch in the expansion
 constexpr int EXP_QMAX = 1024;     // runs staged per batch (EXP_RPW * max_runs)
-constexpr int COARSE_LDS_WORDS = 8192;  // 32 KiB: up to 64^3 bricks (256^3 cells) per level set
+constexpr int COARSE_LDS_WORDS = 8192;  // 32 KiB: up to 64^3 bricks (256^3 cells); next to the 32 KiB event lists
 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_bricks_kernel(const uint8_t *__restrict__ binaries, int32_t n_grids,
@@ -69,10 +72,19 @@ struct RunsParams {
     int32_t *overflow;           // [1] number of rays with more runs than max_runs
 };
 
+// Events recorded by the cell walk (phase 1) and consumed by the marcher (phase 2).  Along a ray
+// the thresholds are non-decreasing and "advance while the step's mid-point is before the
+// threshold" is monotone in the threshold, so consecutive cells of one kind collapse into one
+// event carrying the last cell's exit distance:
+//   EV_EMPTY(thr)  skip steps while mid < thr              (grid.cu:193-206, continuous = false)
+//   EV_OCC(thr)    emit steps while mid < thr              (grid.cu:207-262)
+//   EV_SPAN(thr)   start of a grid span: skip to thr only if the previous step was not emitted
+//                  (grid.cu:153-163, `if (!continuous)`)
+constexpr int EV_MAX = 32;
+enum { EV_EMPTY = 0, EV_OCC = 1, EV_SPAN = 2, EV_NONE = 3 };
+
 struct RunState {
     float t_last;
-    float pend;          // deferred fast-forward target (valid when has_pend)
-    bool has_pend;
     bool continuous;
     int32_t n_samples, n_runs;
     // open run
@@ -82,6 +94,11 @@ struct RunState {
     // brick cache
     int32_t brick_id;
     unsigned long long brick_word;
+    // event list: open (unmerged) entry in registers, closed entries in LDS
+    int32_t ev_cnt;
+    unsigned long long ev_types;  // 2 bits per closed entry
+    int32_t open_type;
+    float open_thr;
 };
 
 __device__ __forceinline__ void close_run(RunState &st, const RunsParams &p, int64_t tid)
@@ -94,29 +111,96 @@ __device__ __forceinline__ void close_run(RunState &st, const RunsParams &p, int
     st.open = false;
 }
 
-// Consecutive fast-forwards with non-decreasing targets and one constant dt collapse into a single
-// one to the last target (the loop `while (t + dt/2 < target) t += dt` is monotone in target), so
-// empty cells only record the target and the marching happens once per run of empty cells.
-__device__ __forceinline__ void flush_pending(RunState &st, float dt)
+// Advance t_last while the step's mid-point is before `thr`; with `emit` every step is a sample
+// and is appended to the ray's run list.  Same arithmetic as march.h's fast_forward_exact
+// (observed serial steps + exact in-binade jumps), plus the sample budget of traverse_steps_limit.
+__device__ __forceinline__ void march(RunState &st, float thr, float dt, float half, bool emit, int32_t limit,
+                                      const RunsParams &p, int64_t tid)
 {
-    if (st.has_pend) {
-        st.t_last = fast_forward_exact(st.t_last, st.pend, dt);
-        st.has_pend = false;
+    uint32_t prev_q = 0;
+    for (;;) {
+        if (!(st.t_last + half < thr)) return;
+        if (emit && limit > 0 && st.n_samples >= limit) return;
+        const float t = st.t_last;
+        float tn = t + dt;
+        if (tn == t) {  // no progress (see oracle): skipping jumps to the target, emission stops
+            if (!emit) st.t_last = thr;
+            return;
+        }
+        const uint32_t bt = f32_bits(t), bn = f32_bits(tn);
+        uint32_t q = 0;
+        float nf = 0.0f;
+        if ((bt >> 23) == (bn >> 23) && (int32_t)bt > 0 && (bt >> 23) != 0) {
+            q = bn - bt;
+            const uint32_t Bb = (bn | 0x7FFFFFu) + 1u;
+            if (q == prev_q && (Bb >> 23) < 255u) {
+                const float nx = (float)(Bb - bn - 1u) / (float)q;
+                const float ny = ((thr - half) - tn) / (tn - t);
+                nf = fminf(nx, ny) * 0.99999f - 4.0f;
+            }
+        }
+        if (emit) {  // the observed step t -> tn is a sample
+            const float inc = tn - t;  // exact (Sterbenz)
+            if (st.open && st.continuous && inc == st.run_inc) {
+                st.run_n++;
+            } else {
+                close_run(st, p, tid);
+                st.open = true; st.run_t0 = t; st.run_inc = inc; st.run_n = 1; st.run_cont = st.continuous;
+            }
+            st.n_samples++;
+            st.continuous = true;
+            if (limit > 0) nf = fminf(nf, (float)(limit - st.n_samples));
+        }
+        if (nf >= 1.0f) {  // jump: every skipped step has the bit-pattern increment q
+            const uint32_t n = (uint32_t)nf;
+            tn = bits_f32(bn + n * q);
+            if (emit) { st.run_n += (int32_t)n; st.n_samples += (int32_t)n; }
+        }
+        prev_q = q;
+        st.t_last = tn;
     }
+}
+
+// Phase 2: consume the closed entries of this lane's list (all lanes loop over the entry index in
+// lock-step; one code path for all three kinds).
+__device__ __forceinline__ void process_events(RunState &st, const float *ev_thr /*LDS, [EV_MAX][256]*/, float dt,
+                                               int32_t limit, const RunsParams &p, int64_t tid)
+{
+    const float half = dt * 0.5f;
+    for (int k = 0; k < st.ev_cnt; ++k) {
+        const int type = (int)((st.ev_types >> (2 * k)) & 3ull);
+        const float thr = ev_thr[k * 256 + threadIdx.x];
+        if (limit > 0 && st.n_samples >= limit) break;  // grid.cu:184: nothing moves once the limit is hit
+        if (type == EV_SPAN && st.continuous) continue;
+        march(st, thr, dt, half, type == EV_OCC, limit, p, tid);
+        if (type == EV_EMPTY) st.continuous = false;
+    }
+    st.ev_cnt = 0;
+    st.ev_types = 0ull;
+}
+
+__device__ __forceinline__ void push_closed(RunState &st, float *ev_thr, int type, float thr)
+{
+    ev_thr[st.ev_cnt * 256 + threadIdx.x] = thr;
+    st.ev_types |= (unsigned long long)type << (2 * st.ev_cnt);
+    st.ev_cnt++;
 }
 
 template <bool COARSE_LDS>
 __device__ __forceinline__ void runs_span(const nfa_traverse_args &a, const RunsParams &p, const uint32_t *coarse_lds,
-                                          int64_t tid, const float o[3], const float d[3], const float inv[3],
-                                          int32_t level, float this_tmin, float this_tmax, RunState &st)
+                                          float *ev_thr, int64_t tid, const float o[3], const float d[3],
+                                          const float inv[3], int32_t level, float this_tmin, float this_tmax,
+                                          RunState &st)
 {
     const float eps = 1e-6f;
-    const float dt = a.step_size, half = dt * 0.5f;
+    const float dt = a.step_size;
     const int32_t limit = a.traverse_steps_limit;
-    if (!st.continuous) {  // grid.cu:153-163, deferred
-        st.pend = st.has_pend ? fmaxf(st.pend, this_tmin) : this_tmin;
-        st.has_pend = true;
-    }
+    // span start: the (conditional) skip to this_tmin becomes the open entry; the first cell closes it.
+    if (st.ev_cnt >= EV_MAX - 1) process_events(st, ev_thr, dt, limit, p, tid);
+    if (st.open_type != EV_NONE) push_closed(st, ev_thr, st.open_type, st.open_thr);
+    st.open_type = EV_SPAN;
+    st.open_thr = this_tmin;
+
     const float *bmin = a.aabbs + 6 * level, *bmax = bmin + 3;
     float tdist[3], delta[3];
     int32_t step[3], cur[3], overflow[3];
@@ -144,73 +228,48 @@ __device__ __forceinline__ void runs_span(const nfa_traverse_args &a, const Runs
     const int32_t lvl_brick_base = level * p.bx * p.by * p.bz;
     int32_t cells_left = a.res[0] + a.res[1] + a.res[2] + 3;
 
-    auto occupied = [&]() -> bool {  // occupancy of the current cell through the brick cache
-        const int32_t bid = lvl_brick_base + ((cur[0] >> 2) * p.by + (cur[1] >> 2)) * p.bz + (cur[2] >> 2);
-        if (bid != st.brick_id) {
-            st.brick_id = bid;
-            const uint32_t cw = COARSE_LDS ? coarse_lds[bid >> 5] : p.coarse[bid >> 5];
-            st.brick_word = ((cw >> (bid & 31)) & 1u) ? p.bricks[bid] : 0ull;
-        }
-        const int bit = ((cur[0] & 3) << 4) | ((cur[1] & 3) << 2) | (cur[2] & 3);
-        return (st.brick_word >> bit) & 1ull;
-    };
-    auto advance = [&]() -> bool {  // single_traversal, include/utils_grid.cuh:116-142; false at the end
-        const int ax = (tdist[0] < tdist[1] && tdist[0] < tdist[2]) ? 0 : (tdist[1] < tdist[2] ? 1 : 2);
-        bool done;
-        if (ax == 0)      { cur[0] += step[0]; tdist[0] += delta[0]; done = cur[0] == overflow[0]; }
-        else if (ax == 1) { cur[1] += step[1]; tdist[1] += delta[1]; done = cur[1] == overflow[1]; }
-        else              { cur[2] += step[2]; tdist[2] += delta[2]; done = cur[2] == overflow[2]; }
-        return !(done || --cells_left <= 0);
-    };
-
-    // The reference's cell loop (grid.cu:184-272) in lock-step phases, so that a wave runs the
-    // expensive part (marching + emission) once per RUN of occupied cells instead of once per cell
-    // iteration in which any lane happens to need it:
-    //   A: walk empty cells (cheap DDA steps), only recording the marching target;
-    //   B: march once, then emit samples through consecutive occupied cells.
-    bool alive = true;
-    while (alive && (limit <= 0 || st.n_samples < limit)) {
-        // ---- phase A
-        bool occ = false;
-        while (alive) {
-            occ = occupied();
-            if (occ) break;
-            st.pend = fminf(fminf(tdist[0], fminf(tdist[1], tdist[2])), this_tmax);  // non-decreasing along the ray
-            st.has_pend = true;
-            st.continuous = false;
-            alive = advance();
-        }
-        if (!occ) break;
-        // ---- phase B
-        flush_pending(st, dt);
-        while (limit <= 0 || st.n_samples < limit) {
-            const float t_traverse = fminf(fminf(tdist[0], fminf(tdist[1], tdist[2])), this_tmax);
-            while (limit <= 0 || st.n_samples < limit) {  // grid.cu:208-261
-                if (st.t_last + half >= t_traverse) break;
-                const float t_next = st.t_last + dt;
-                if (t_next == st.t_last) break;
-                const float inc = t_next - st.t_last;  // exact (Sterbenz)
-                if (st.open && st.continuous && inc == st.run_inc) {
-                    st.run_n++;
-                } else {
-                    close_run(st, p, tid);
-                    st.open = true; st.run_t0 = st.t_last; st.run_inc = inc; st.run_n = 1; st.run_cont = st.continuous;
-                }
-                st.n_samples++;
-                st.continuous = true;
-                st.t_last = t_next;
-                if (t_next >= t_traverse) break;
+    // Phase 1: the reference's cell loop (grid.cu:184-272) reduced to the DDA and one event per run of
+    // cells of one kind.  Straight-line predicated code: the only branches are the brick reload and
+    // the loop exit (span end, or list full -> consume it and resume).  Row EV_MAX of the LDS list is
+    // a dummy slot that absorbs the write when the kind did not change.
+    bool span_done = false;
+    while (!span_done) {
+        for (;;) {
+            const int32_t bid = lvl_brick_base + ((cur[0] >> 2) * p.by + (cur[1] >> 2)) * p.bz + (cur[2] >> 2);
+            if (bid != st.brick_id) {
+                st.brick_id = bid;
+                const uint32_t cw = COARSE_LDS ? coarse_lds[bid >> 5] : p.coarse[bid >> 5];
+                st.brick_word = ((cw >> (bid & 31)) & 1u) ? p.bricks[bid] : 0ull;
             }
-            alive = advance();
-            if (!alive || !occupied()) break;  // an empty cell: back to phase A (it re-tests the cell)
+            const int bit = ((cur[0] & 3) << 4) | ((cur[1] & 3) << 2) | (cur[2] & 3);
+            const int type = (int)((st.brick_word >> bit) & 1ull);  // EV_EMPTY / EV_OCC
+            const bool changed = type != st.open_type;
+            ev_thr[(changed ? st.ev_cnt : EV_MAX) * 256 + threadIdx.x] = st.open_thr;
+            st.ev_types |= changed ? ((unsigned long long)st.open_type << (2 * st.ev_cnt)) : 0ull;
+            st.ev_cnt += changed ? 1 : 0;
+            st.open_type = type;
+            st.open_thr = fminf(fminf(tdist[0], fminf(tdist[1], tdist[2])), this_tmax);  // t_traverse, non-decreasing
+            // single_traversal (include/utils_grid.cuh:116-142), branch-free
+            const bool s0 = (tdist[0] < tdist[1]) && (tdist[0] < tdist[2]);
+            const bool s1 = !s0 && (tdist[1] < tdist[2]);
+            const bool s2 = !s0 && !s1;
+            cur[0] += s0 ? step[0] : 0; tdist[0] += s0 ? delta[0] : 0.0f;
+            cur[1] += s1 ? step[1] : 0; tdist[1] += s1 ? delta[1] : 0.0f;
+            cur[2] += s2 ? step[2] : 0; tdist[2] += s2 ? delta[2] : 0.0f;
+            const bool done = s0 ? (cur[0] == overflow[0]) : (s1 ? (cur[1] == overflow[1]) : (cur[2] == overflow[2]));
+            span_done = done || (--cells_left <= 0);
+            if (span_done || st.ev_cnt == EV_MAX) break;
         }
+        if (!span_done) process_events(st, ev_thr, dt, limit, p, tid);
     }
 }
 
 template <bool FUSED, bool COARSE_LDS>
 __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, const RunsParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t coarse_lds[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
+    float *ev_thr = reinterpret_cast<float *>(lds_raw);          // [EV_MAX + 1][256], last row = dummy slot
+    uint32_t *coarse_lds = lds_raw + (EV_MAX + 1) * 256;          // [n_coarse_words] (COARSE_LDS only)
     if (COARSE_LDS) {
         for (int i = threadIdx.x; i < p.n_coarse_words; i += blockDim.x) coarse_lds[i] = p.coarse[i];
         __syncthreads();
@@ -228,9 +287,10 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
         const float d[3] = {a.rays_d[3 * tid], a.rays_d[3 * tid + 1], a.rays_d[3 * tid + 2]};
         const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
         RunState st;
-        st.t_last = near_plane; st.has_pend = false; st.pend = 0.f; st.continuous = false;
+        st.t_last = near_plane; st.continuous = false;
         st.n_samples = 0; st.n_runs = 0; st.open = false; st.run_cont = false; st.run_t0 = 0.f; st.run_inc = 0.f;
         st.run_n = 0; st.brick_id = -1; st.brick_word = 0ull;
+        st.ev_cnt = 0; st.ev_types = 0ull; st.open_type = EV_NONE; st.open_thr = 0.f;
         if (FUSED) {
             float tmin, tmax, lo, hi;
             bool hit = true;
@@ -250,7 +310,8 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
             }
             if (hit) {
                 const float this_tmin = fmaxf(tmin, near_plane), this_tmax = fminf(tmax, far_plane);
-                if (this_tmin < this_tmax) runs_span<COARSE_LDS>(a, p, coarse_lds, tid, o, d, inv, 0, this_tmin, this_tmax, st);
+                if (this_tmin < this_tmax)
+                    runs_span<COARSE_LDS>(a, p, coarse_lds, ev_thr, tid, o, d, inv, 0, this_tmin, this_tmax, st);
             }
         } else {
             const int32_t G = a.n_grids;
@@ -269,10 +330,14 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
                 }
                 const float this_tmin = fmaxf(ts[i], near_plane), this_tmax = fminf(ts[i + 1], far_plane);
                 if (this_tmin >= this_tmax) continue;
-                runs_span<COARSE_LDS>(a, p, coarse_lds, tid, o, d, inv, level, this_tmin, this_tmax, st);
+                runs_span<COARSE_LDS>(a, p, coarse_lds, ev_thr, tid, o, d, inv, level, this_tmin, this_tmax, st);
             }
         }
-        flush_pending(st, a.step_size);
+        if (st.open_type != EV_NONE) {
+            if (st.ev_cnt == EV_MAX) process_events(st, ev_thr, a.step_size, a.traverse_steps_limit, p, tid);
+            push_closed(st, ev_thr, st.open_type, st.open_thr);
+        }
+        process_events(st, ev_thr, a.step_size, a.traverse_steps_limit, p, tid);
         close_run(st, p, tid);
         if (a.terminate_planes) a.terminate_planes[tid] = st.t_last;
         a.sm_cnts[tid] = st.n_samples;
@@ -447,14 +512,14 @@ int nfa_traverse_runs(const nfa_traverse_args *pa, const uint64_t *bricks, const
     p.max_runs = max_runs;
     p.overflow = overflow_count;
     const bool lds = p.n_coarse_words <= COARSE_LDS_WORDS;
-    const size_t shmem = lds ? (size_t)p.n_coarse_words * 4 : 0;
+    const size_t shmem = (size_t)(EV_MAX + 1) * 256 * 4 + (lds ? (size_t)p.n_coarse_words * 4 : 0);
     const unsigned grid = grid_1d(a.n_rays, 256, 1 << 20);
     if (fused) {
         if (lds) hipLaunchKernelGGL((runs_kernel<true, true>), dim3(grid), dim3(256), shmem, s, a, p);
-        else     hipLaunchKernelGGL((runs_kernel<true, false>), dim3(grid), dim3(256), 0, s, a, p);
+        else     hipLaunchKernelGGL((runs_kernel<true, false>), dim3(grid), dim3(256), shmem, s, a, p);
     } else {
         if (lds) hipLaunchKernelGGL((runs_kernel<false, true>), dim3(grid), dim3(256), shmem, s, a, p);
-        else     hipLaunchKernelGGL((runs_kernel<false, false>), dim3(grid), dim3(256), 0, s, a, p);
+        else     hipLaunchKernelGGL((runs_kernel<false, false>), dim3(grid), dim3(256), shmem, s, a, p);
     }
     NFA_CHECK_LAUNCH("traverse_runs");
     return NFA_OK;
