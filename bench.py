@@ -90,7 +90,7 @@ def make_workload(dev, n_rays: int = 1024 * 1024, res: int = 128, grid: str = "s
         return base_sigma(ts, te)
 
     def rgb_sigma_fn(ts, te, ri):                            # used inside rendering (with grad)
-        rgbs = torch.stack([ts, ts, ts], dim=-1) * params[1]
+        rgbs = (ts * params[1])[:, None].expand(-1, 3)       # grey ramp; made contiguous by rendering()
         return rgbs, base_sigma(ts, te) * params[0]
 
     return dict(estimator=est, rays_o=torch.from_numpy(o).to(dev), rays_d=torch.from_numpy(d).to(dev),

@@ -137,20 +137,21 @@ int nfa_expand_runs(int64_t n_rays, float step_size, const int32_t *run_cnts, co
 
 /* ------------------------------------------------------------------ packed segments */
 
-/* Ownership table for the flat segmented kernels: tile b (NFA_SEG_TILE consecutive element
- * offsets) owns the rays whose chunk starts inside it.  Requires contiguous chunks
- * (starts[r+1] == starts[r] + cnts[r]); flags[0] is set to 1 when they are not, in which case
- * the caller must use the *_generic entry points.  tiles has nfa_seg_num_tiles(n)+1 entries. */
-#define NFA_SEG_TILE 2048
-int64_t nfa_seg_num_tiles(int64_t n_elems);
+/* Ownership table for the flat segmented kernels: the element range is cut into n_tiles tiles of
+ * tile_elems element offsets (nfa_seg_plan picks both); a tile OWNS the rays whose chunk starts
+ * inside it.  tiles holds (n_tiles + 1) {first ray, first element} int64 pairs.  Requires
+ * contiguous chunks (starts[r+1] == starts[r] + cnts[r]); flags[0] is set to 1 when they are not,
+ * in which case the caller must use the *_generic entry points. */
+void nfa_seg_plan(int64_t n_elems, int64_t *tile_elems, int64_t *n_tiles);
 int nfa_seg_build_tiles(const int64_t *packed_info /*[n_rays,2]*/, int64_t n_rays, int64_t n_elems,
-                        int32_t *tiles, int32_t *flags, nfa_stream_t stream);
+                        int64_t tile_elems, int64_t n_tiles, int64_t *tiles /*[2*(n_tiles+1)]*/,
+                        int32_t *flags, nfa_stream_t stream);
 
 /* kind: 0 inclusive_sum 1 exclusive_sum 2 inclusive_prod 3 exclusive_prod.
  * reverse != 0 scans each chunk from its last element to its first: the reverse-iterator
  * launches of ref: cuda/csrc/scan.cu:41-51,100-110 (backward of the sums).
  * ref: cuda/csrc/scan.cu:9-165,217-257; kernels include/utils_scan.cuh:28-263. */
-int nfa_packed_scan(int kind, int reverse, const int64_t *packed_info, const int32_t *tiles,
+int nfa_packed_scan(int kind, int reverse, const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles,
                     int64_t n_rays, int64_t n_elems, const float *inputs, float *outputs,
                     nfa_stream_t stream);
 /* Any (start,count) chunks (overlapping, unordered, gaps), one wave per ray; also implements
@@ -160,7 +161,7 @@ int nfa_packed_scan_generic(int kind, int reverse, int normalize, const int64_t 
                             nfa_stream_t stream);
 /* grad_in = reverse_{incl|excl}_sum(grad_out * outputs) / max(inputs, 1e-10)
  * ref: cuda/csrc/scan.cu:169-214 (inclusive), :259-304 (exclusive). kind: 2 or 3. */
-int nfa_packed_prod_backward(int kind, const int64_t *packed_info, const int32_t *tiles,
+int nfa_packed_prod_backward(int kind, const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles,
                              int64_t n_rays, int64_t n_elems, const float *inputs,
                              const float *outputs, const float *grad_outputs, float *grad_inputs,
                              nfa_stream_t stream);
@@ -169,22 +170,22 @@ int nfa_packed_prod_backward(int kind, const int64_t *packed_info, const int32_t
  * :200-206,305-309 (alpha).  Any of weights/trans/alphas may be NULL. */
 int nfa_render_from_density_fwd(const float *t_starts, const float *t_ends, const float *sigmas,
                                 const float *prefix_trans /*NULL ok*/, const int64_t *packed_info,
-                                const int32_t *tiles, int64_t n_rays, int64_t n_elems,
+                                const int64_t *tiles, int64_t n_tiles, int64_t n_rays, int64_t n_elems,
                                 float *weights, float *trans, float *alphas, nfa_stream_t stream);
 int nfa_render_from_alpha_fwd(const float *alphas, const float *prefix_trans, const int64_t *packed_info,
-                              const int32_t *tiles, int64_t n_rays, int64_t n_elems,
+                              const int64_t *tiles, int64_t n_tiles, int64_t n_rays, int64_t n_elems,
                               float *weights, float *trans, nfa_stream_t stream);
 /* Backward of the fused density op given the forward's saved trans/alphas:
  *   B_k = g_w_k T_k (1-a_k) + g_a_k (1-a_k) - sum_{i>k}(g_w_i w_i + g_T_i T_i)
  *   grad_sigmas = (t_ends - t_starts) * B,  grad_x = B  (either may be NULL). */
 int nfa_render_from_density_bwd(const float *t_starts, const float *t_ends, const float *trans,
                                 const float *alphas, const float *g_weights, const float *g_trans,
-                                const float *g_alphas, const int64_t *packed_info, const int32_t *tiles,
+                                const float *g_alphas, const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles,
                                 int64_t n_rays, int64_t n_elems, float *grad_sigmas, float *grad_x,
                                 nfa_stream_t stream);
 /*   grad_alphas_k = g_w_k T_k - sum_{i>k}(g_w_i w_i + g_T_i T_i) / max(1 - a_k, 1e-10) */
 int nfa_render_from_alpha_bwd(const float *alphas, const float *trans, const float *g_weights,
-                              const float *g_trans, const int64_t *packed_info, const int32_t *tiles,
+                              const float *g_trans, const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles,
                               int64_t n_rays, int64_t n_elems, float *grad_alphas, nfa_stream_t stream);
 
 /* Visibility mask (ref: volrend.py:412-418,474-480) fused with the per-ray visible count that
@@ -192,11 +193,11 @@ int nfa_render_from_alpha_bwd(const float *alphas, const float *trans, const flo
  * sigmas_or_alphas is sigma when t_starts != NULL, alpha otherwise. vis_cnts may be NULL. */
 int nfa_render_visibility(const float *t_starts, const float *t_ends, const float *sigmas_or_alphas,
                           const float *prefix_trans, float early_stop_eps, float alpha_thre,
-                          const int64_t *packed_info, const int32_t *tiles, int64_t n_rays,
+                          const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles, int64_t n_rays,
                           int64_t n_elems, uint8_t *vis, int64_t *vis_cnts, nfa_stream_t stream);
 /* Boolean-mask compaction of (ray_indices, t_starts, t_ends) with known per-ray output offsets. */
 int nfa_compact_samples(const uint8_t *vis, const float *t_starts, const float *t_ends,
-                        const int64_t *packed_info, const int32_t *tiles, const int64_t *out_starts,
+                        const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles, const int64_t *out_starts,
                         int64_t n_rays, int64_t n_elems, int64_t *out_ray_indices,
                         float *out_t_starts, float *out_t_ends, nfa_stream_t stream);
 
@@ -204,7 +205,7 @@ int nfa_compact_samples(const uint8_t *vis, const float *t_starts, const float *
  * values NULL => D = 1 and out = sum w.  accumulate != 0 adds to `out` (accumulate_along_rays_).
  * ref: volrend.py:483-573 (index_add_). */
 int nfa_accumulate_along_rays(const float *weights, const float *values, int32_t D,
-                              const int64_t *packed_info, const int32_t *tiles, int64_t n_rays,
+                              const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles, int64_t n_rays,
                               int64_t n_elems, int accumulate, float *out, nfa_stream_t stream);
 /* Fallback for unsorted ray_indices: atomics, same contract as index_add_. out must be initialised. */
 int nfa_accumulate_along_rays_atomic(const float *weights, const float *values, int32_t D,
@@ -212,18 +213,18 @@ int nfa_accumulate_along_rays_atomic(const float *weights, const float *values, 
                                      float *out, nfa_stream_t stream);
 /* g_w[i] = sum_c g_out[ray(i),c] v[i,c];  g_v[i,c] = g_out[ray(i),c] w[i]. */
 int nfa_accumulate_along_rays_bwd(const float *weights, const float *values, int32_t D,
-                                  const float *g_out, const int64_t *packed_info, const int32_t *tiles,
+                                  const float *g_out, const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles,
                                   int64_t n_rays, int64_t n_elems, float *g_weights, float *g_values,
                                   nfa_stream_t stream);
 /* The three accumulations of `rendering` in one pass (ref: volrend.py:140-156):
  * colors[r,3] = sum w rgb, opacities[r] = sum w, depths[r] = sum w (ts+te)/2 (un-normalised). */
 int nfa_render_accumulate_fwd(const float *weights, const float *rgbs, const float *t_starts,
-                              const float *t_ends, const int64_t *packed_info, const int32_t *tiles,
+                              const float *t_ends, const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles,
                               int64_t n_rays, int64_t n_elems, float *colors, float *opacities,
                               float *depths, nfa_stream_t stream);
 int nfa_render_accumulate_bwd(const float *weights, const float *rgbs, const float *t_starts,
                               const float *t_ends, const float *g_colors, const float *g_opacities,
-                              const float *g_depths, const int64_t *packed_info, const int32_t *tiles,
+                              const float *g_depths, const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles,
                               int64_t n_rays, int64_t n_elems, float *g_weights, float *g_rgbs,
                               nfa_stream_t stream);
 

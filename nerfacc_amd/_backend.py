@@ -51,33 +51,32 @@ _SIGS = {
     "nfa_pack_bricks": [_vp, _i32, C.POINTER(_i32), _vp, _vp, _vp],
     "nfa_traverse_runs": [C.POINTER(TraverseArgs), _vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "nfa_expand_runs": [_i64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
-    "nfa_seg_build_tiles": [_vp, _i64, _i64, _vp, _vp, _vp],
-    "nfa_packed_scan": [_int, _int, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
+    "nfa_seg_plan": [_i64, C.POINTER(_i64), C.POINTER(_i64)],
+    "nfa_seg_build_tiles": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
+    "nfa_packed_scan": [_int, _int, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],
     "nfa_packed_scan_generic": [_int, _int, _int, _vp, _i64, _i64, _vp, _vp, _vp],
-    "nfa_packed_prod_backward": [_int, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp],
-    "nfa_render_from_density_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
-    "nfa_render_from_alpha_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
-    "nfa_render_from_density_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
-    "nfa_render_from_alpha_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp],
-    "nfa_render_visibility": [_vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
-    "nfa_compact_samples": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
-    "nfa_accumulate_along_rays": [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _int, _vp, _vp],
+    "nfa_packed_prod_backward": [_int, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp],
+    "nfa_render_from_density_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
+    "nfa_render_from_alpha_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],
+    "nfa_render_from_density_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],
+    "nfa_render_from_alpha_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp],
+    "nfa_render_visibility": [_vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],
+    "nfa_compact_samples": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
+    "nfa_accumulate_along_rays": [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _i64, _int, _vp, _vp],
     "nfa_accumulate_along_rays_atomic": [_vp, _vp, _i32, _vp, _i64, _i64, _vp, _vp],
-    "nfa_accumulate_along_rays_bwd": [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
-    "nfa_render_accumulate_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
-    "nfa_render_accumulate_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
+    "nfa_accumulate_along_rays_bwd": [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],
+    "nfa_render_accumulate_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
+    "nfa_render_accumulate_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],
     "nfa_importance_sampling": [_vp, _vp, _vp, _i64, _i64, _i64, _int, _u64, _u64, _vp, _vp, _vp],
     "nfa_searchsorted": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp],
     "nfa_cumsum_scratch_bytes": [_i64],
-    "nfa_seg_num_tiles": [_i64],
     "nfa_last_error": [],
     "nfa_version": [],
     "nfa_device_arch": [C.c_char_p, _int],
 }
-_RESTYPES = {"nfa_bricks_words": _i64, "nfa_cumsum_scratch_bytes": _i64, "nfa_seg_num_tiles": _i64, "nfa_last_error": C.c_char_p}
+_RESTYPES = {"nfa_bricks_words": _i64, "nfa_cumsum_scratch_bytes": _i64, "nfa_seg_plan": None, "nfa_last_error": C.c_char_p}
 
 EXPORTED_SYMBOLS = tuple(_SIGS)
-SEG_TILE = 2048  # NFA_SEG_TILE
 
 
 def library_path() -> str:
@@ -103,7 +102,7 @@ def load() -> C.CDLL:
         for name, argtypes in _SIGS.items():
             fn = getattr(lib, name)  # AttributeError => header and library disagree
             fn.argtypes = argtypes
-            fn.restype = _RESTYPES.get(name, _int)
+            fn.restype = _RESTYPES[name] if name in _RESTYPES else _int
         _lib = lib
     return _lib
 
@@ -147,8 +146,11 @@ def require_device(*tensors: Optional[torch.Tensor]) -> torch.device:
     return dev
 
 
-def seg_num_tiles(n_elems: int) -> int:
-    return n_elems // SEG_TILE + 1
+def seg_plan(n_elems: int):
+    """(tile_elems, n_tiles) chosen by the library for an array of n_elems samples."""
+    t, n = _i64(0), _i64(0)
+    load().nfa_seg_plan(n_elems, C.byref(t), C.byref(n))
+    return int(t.value), int(n.value)
 
 
 def cumsum_scratch(n: int, device) -> torch.Tensor:

@@ -23,9 +23,10 @@ class SegInfo:
     packed_info: Tensor          # int64 [n_rays, 2], contiguous
     n_rays: int
     n_elems: int
-    tiles: Optional[Tensor]      # int32 [num_tiles + 1]; None when chunks are not contiguous
+    tiles: Optional[Tensor]      # int64 [n_tiles + 1, 2] {first ray, first element}; None when chunks are not contiguous
     contiguous: bool             # starts[r+1] == starts[r] + cnts[r]  (flat kernels usable)
     sorted_indices: bool = True  # for infos derived from ray_indices
+    n_tiles: int = 0
 
 
 _ATTR = "_nfa_seg"
@@ -36,11 +37,13 @@ def _build_tiles(packed_info: Tensor, n_elems: int, trusted: bool) -> SegInfo:
     dev = B.require_device(packed_info)
     n_rays = packed_info.shape[0]
     with torch.cuda.device(dev):
-        tiles = torch.empty(B.seg_num_tiles(n_elems) + 1, dtype=torch.int32, device=dev)
+        tile_elems, n_tiles = B.seg_plan(n_elems)
+        tiles = torch.empty((n_tiles + 1, 2), dtype=torch.int64, device=dev)
         flag = torch.empty(1, dtype=torch.int32, device=dev)
-        B.call("nfa_seg_build_tiles", B.ptr(packed_info), n_rays, n_elems, B.ptr(tiles), B.ptr(flag), B.stream())
+        B.call("nfa_seg_build_tiles", B.ptr(packed_info), n_rays, n_elems, tile_elems, n_tiles, B.ptr(tiles), B.ptr(flag),
+               B.stream())
         ok = True if trusted else (int(flag.item()) == 0)  # one read-back for foreign packed_info
-    return SegInfo(packed_info, n_rays, n_elems, tiles if ok else None, ok)
+    return SegInfo(packed_info, n_rays, n_elems, tiles if ok else None, ok, n_tiles=n_tiles)
 
 
 def seginfo_from_packed(packed_info: Tensor, n_elems: int, trusted: bool = False) -> SegInfo:

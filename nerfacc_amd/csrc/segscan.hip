@@ -19,6 +19,8 @@
 //
 // Reverse scans (the reference's reverse-iterator launches, scan.cu:41-51) are the same engine
 // with the lane/element order mirrored (DIR = -1).
+#include <stdlib.h>
+
 #include "common.hip.h"
 
 namespace nfa {
@@ -28,15 +30,17 @@ constexpr int SEG_WAVES_PER_BLOCK = 4;
 
 // ------------------------------------------------------------------------------------------
 // tile ownership table
+// tiles[b] = {first ray owned by tile b, its first element}; tiles[n_tiles] is the end sentinel
+// {n_rays, end of the last ray}.  Tile b covers element offsets [b*tile_elems, (b+1)*tile_elems).
 __global__ __launch_bounds__(256) void seg_build_tiles_kernel(const int64_t *__restrict__ packed_info, int64_t n_rays,
-                                                              int64_t n_elems, int64_t n_tiles,
-                                                              int32_t *__restrict__ tiles, int32_t *__restrict__ flags)
+                                                              int64_t n_elems, int64_t tile_elems, int64_t n_tiles,
+                                                              longlong2 *__restrict__ tiles, int32_t *__restrict__ flags)
 {
     // thread r (0..n_rays): ray r is the first ray of every tile b with
-    // floor(start[r-1]/TILE) < b <= floor(start[r]/TILE); r == n_rays is the sentinel.
+    // floor(start[r-1]/T) < b <= floor(start[r]/T); r == n_rays is the sentinel.
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n_rays;
          r += (int64_t)blockDim.x * gridDim.x) {
-        int64_t b_lo, b_hi;
+        int64_t b_lo, b_hi, e_first;
         bool bad = false;
         if (r < n_rays) {
             const int64_t s = packed_info[2 * r], n = packed_info[2 * r + 1];
@@ -48,46 +52,57 @@ __global__ __launch_bounds__(256) void seg_build_tiles_kernel(const int64_t *__r
             }
             bad |= (n < 0) || (s < 0) || (s + n > n_elems);
             if (bad) { atomicOr(flags, 1); continue; }
-            b_lo = (s_prev < 0) ? 0 : s_prev / NFA_SEG_TILE + 1;
-            b_hi = s / NFA_SEG_TILE;
+            b_lo = (s_prev < 0) ? 0 : s_prev / tile_elems + 1;
+            b_hi = s / tile_elems;
+            e_first = s;
         } else {
             const int64_t s_prev = n_rays > 0 ? packed_info[2 * n_rays - 2] : -1;
-            b_lo = (s_prev < 0) ? 0 : s_prev / NFA_SEG_TILE + 1;
-            b_hi = n_tiles;  // tiles[n_tiles] is the end sentinel
+            const int64_t n_prev = n_rays > 0 ? packed_info[2 * n_rays - 1] : 0;
+            b_lo = (s_prev < 0) ? 0 : s_prev / tile_elems + 1;
+            b_hi = n_tiles;
+            e_first = (s_prev < 0) ? 0 : s_prev + n_prev;
             if (s_prev > n_elems) { atomicOr(flags, 1); continue; }
         }
-        for (int64_t b = b_lo; b <= b_hi && b <= n_tiles; ++b) tiles[b] = (int32_t)r;
+        for (int64_t b = b_lo; b <= b_hi && b <= n_tiles; ++b) tiles[b] = make_longlong2(r, e_first);
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // 16-byte vector helpers (addresses are 16 B aligned when VEC is true)
+// Loads are UNCONDITIONAL and RAW: a lane without valid elements reads the step's base address `ps`
+// (always inside the array), and the validity selects are applied where the values are consumed
+// (sel4).  A load inside an `if`, or a select right behind it, makes the compiler wait for that one
+// load on the spot, which serialises the 3-7 array loads of a step (one memory latency each) and
+// defeats the one-step-ahead prefetch.
+struct F4 { float v[4]; };
+
 template <bool VEC>
-__device__ __forceinline__ void load4(const float *__restrict__ p, int64_t p0, const bool valid[4], float fill,
-                                      float out[4])
+__device__ __forceinline__ void ld4(const float *__restrict__ p, int64_t p0, int64_t ps, const bool valid[4], F4 &out)
 {
     if (VEC) {
-        if (valid[0] | valid[1] | valid[2] | valid[3]) {
-            const float4 v = *reinterpret_cast<const float4 *>(p + p0);
-            out[0] = valid[0] ? v.x : fill; out[1] = valid[1] ? v.y : fill;
-            out[2] = valid[2] ? v.z : fill; out[3] = valid[3] ? v.w : fill;
-        } else {
-            out[0] = out[1] = out[2] = out[3] = fill;
-        }
+        const bool any = valid[0] | valid[1] | valid[2] | valid[3];
+        const float4 v = *reinterpret_cast<const float4 *>(p + (any ? p0 : ps));
+        out.v[0] = v.x; out.v[1] = v.y; out.v[2] = v.z; out.v[3] = v.w;
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) out[j] = valid[j] ? p[p0 + j] : fill;
+        for (int j = 0; j < 4; ++j) out.v[j] = p[valid[j] ? p0 + j : ps];
     }
 }
+__device__ __forceinline__ float sel(const F4 &r, int j, const bool valid[4], float fill) { return valid[j] ? r.v[j] : fill; }
+
+// Full lanes store one 16-byte vector.  The per-element path (a lane straddling a range end) goes
+// through a volatile pointer: otherwise the compiler if-converts both paths into dwordx3 + dword
+// stores for EVERY lane, which halves the store rate.
 template <bool VEC>
 __device__ __forceinline__ void store4(float *__restrict__ p, int64_t p0, const bool valid[4], const float v[4])
 {
     if (VEC && valid[0] && valid[1] && valid[2] && valid[3]) {
         *reinterpret_cast<float4 *>(p + p0) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
+        volatile float *pv = p;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (valid[j]) p[p0 + j] = v[j];
+            if (valid[j]) pv[p0 + j] = v[j];
     }
 }
 
@@ -96,7 +111,9 @@ __device__ __forceinline__ void store4(float *__restrict__ p, int64_t p0, const 
 //   static constexpr int NCH;                       scan channels
 //   __device__ float identity(int ch);
 //   __device__ float comb(int ch, float a, float b);   a = earlier in scan order
-//   __device__ void  load(int64_t p0, const bool valid[4]);
+//   struct Raw;                                      registers filled straight from memory
+//   __device__ void  fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const;   loads only
+//   __device__ void  load(const Raw &r, const bool valid[4]);              derive scan inputs
 //   __device__ float x(int j, int ch);                scan input of element j
 //   __device__ void  emit(int j, int64_t pos, bool valid, bool is_head, int rid, int prev_rid,
 //                         const float incl[NCH], const float prev[NCH]);
@@ -106,19 +123,19 @@ __device__ __forceinline__ void store4(float *__restrict__ p, int64_t p0, const 
 //   __device__ void  store(int64_t p0, const bool valid[4]);
 //   __device__ void  ray_done(int rid, const float total[NCH]);   last ray of the tile
 //   __device__ void  empty_ray(int rid);
-template <int DIR, class Op>
+template <int DIR, bool PIPE, class Op>
 __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__ packed_info,
-                                             const int32_t *__restrict__ tiles, int64_t n_rays, int64_t tile,
+                                             const longlong2 *__restrict__ tiles, int64_t n_rays, int64_t tile,
                                              int32_t *__restrict__ hid /* LDS, SEG_CHUNK ints, wave private */)
 {
     constexpr int NCH = Op::NCH;
     const int lane = lane_id();
     const int alane = DIR > 0 ? lane : 63 - lane;  // lane in address order
-    const int32_t r_lo = tiles[tile], r_hi = tiles[tile + 1];
+    const longlong2 t_lo = tiles[tile], t_hi = tiles[tile + 1];  // one 32-byte read: no dependent chain
+    const int32_t r_lo = (int32_t)t_lo.x, r_hi = (int32_t)t_hi.x;
     if (r_lo >= r_hi) return;
     const int32_t n_own = r_hi - r_lo;
-    const int64_t e_lo = packed_info[2 * (int64_t)r_lo];
-    const int64_t e_hi = packed_info[2 * (int64_t)(r_hi - 1)] + packed_info[2 * (int64_t)(r_hi - 1) + 1];
+    const int64_t e_lo = t_lo.y, e_hi = t_hi.y;  // chunks are contiguous: the last owned ray ends where the next tile begins
 
     // window of packed_info rows, in walk order v = 0..n_own-1: ray(v) = r_lo + v (fwd) / r_hi-1-v (rev)
     int32_t v_next = 0, win_base = 0;
@@ -141,8 +158,31 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
     const int64_t c_first = DIR > 0 ? (e_lo / SEG_CHUNK) * SEG_CHUNK : ((e_hi - 1) / SEG_CHUNK) * SEG_CHUNK;
     const int64_t n_chunks = e_hi > e_lo ? ((e_hi - 1) / SEG_CHUNK - e_lo / SEG_CHUNK + 1) : 0;
 
+    // Software pipeline: the loads of step i+1 are issued before step i is computed and stored, so a
+    // wave always has a step's worth of loads in flight and never waits for its own stores
+    // (vmcnt retires in order: loads issued BEFORE the stores can be waited for without them).
+    auto chunk_base = [&](int64_t ci) { return c_first + (DIR > 0 ? ci : -ci) * SEG_CHUNK; };
+    // an address every lane may read: the first in-range multiple of 4 of the step
+    auto ld_safe = [&](int64_t c) { return c > e_lo ? c : (e_lo / 4) * 4; };
+    auto chunk_valid = [&](int64_t p0, bool valid[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) valid[j] = (p0 + j >= e_lo) && (p0 + j < e_hi);
+    };
+    typename Op::Raw raw_cur, raw_next;
+    if (n_chunks > 0) {
+        bool v0[4];
+        const int64_t p0 = chunk_base(0) + 4 * alane;
+        chunk_valid(p0, v0);
+        op.fetch(p0, ld_safe(chunk_base(0)), v0, raw_cur);
+    }
     for (int64_t ci = 0; ci < n_chunks; ++ci) {
-        const int64_t c = c_first + (DIR > 0 ? ci : -ci) * SEG_CHUNK;
+        const int64_t c = chunk_base(ci);
+        if (PIPE && ci + 1 < n_chunks) {
+            bool vn[4];
+            const int64_t pn = chunk_base(ci + 1) + 4 * alane;
+            chunk_valid(pn, vn);
+            op.fetch(pn, ld_safe(chunk_base(ci + 1)), vn, raw_next);
+        }
         // ---- segment heads of this chunk -> LDS
         *reinterpret_cast<int4 *>(hid + 4 * lane) = make_int4(-1, -1, -1, -1);
         __builtin_amdgcn_wave_barrier();
@@ -166,12 +206,12 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
         __builtin_amdgcn_wave_barrier();
         const int32_t hj[4] = {h4.x, h4.y, h4.z, h4.w};
 
-        // ---- load
+        // ---- this step's data
         const int64_t p0 = c + 4 * alane;
         bool valid[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) valid[j] = (p0 + j >= e_lo) && (p0 + j < e_hi);
-        op.load(p0, valid);
+        chunk_valid(p0, valid);
+        if (!PIPE && ci > 0) op.fetch(p0, ld_safe(c), valid, raw_cur);
+        op.load(raw_cur, valid);
 
         // ---- lane-local inclusive segmented scan, scan order k (address j = DIR>0 ? k : 3-k)
         float li[4][NCH];
@@ -247,6 +287,7 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
         carry_rid = __shfl(prev_rid, 63, NFA_WAVE);
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) carry[ch] = __shfl(prev[ch], 63, NFA_WAVE);
+        if (PIPE) raw_cur = raw_next;
     }
     // remaining owned rays are all empty (their start equals e_hi / e_lo)
     for (;;) {
@@ -260,30 +301,36 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
     if (carry_rid >= 0 && lane == 0) op.ray_done(carry_rid, carry);
 }
 
-template <int DIR, class Op>
+template <int DIR, bool PIPE, class Op>
 __global__ __launch_bounds__(64 * SEG_WAVES_PER_BLOCK) void seg_kernel(Op op, const int64_t *__restrict__ packed_info,
-                                                                       const int32_t *__restrict__ tiles,
+                                                                       const longlong2 *__restrict__ tiles,
                                                                        int64_t n_rays, int64_t n_tiles)
 {
     __shared__ __attribute__((aligned(16))) int32_t hid_all[SEG_WAVES_PER_BLOCK * SEG_CHUNK];
     const int wave = threadIdx.x >> 6;
     const int64_t tile = (int64_t)blockIdx.x * SEG_WAVES_PER_BLOCK + wave;
     if (tile >= n_tiles) return;
-    seg_run_tile<DIR>(op, packed_info, tiles, n_rays, tile, hid_all + wave * SEG_CHUNK);
+    seg_run_tile<DIR, PIPE>(op, packed_info, tiles, n_rays, tile, hid_all + wave * SEG_CHUNK);
 }
 
 template <int DIR, class Op>
-static void launch_seg(const Op &op, const int64_t *packed_info, const int32_t *tiles, int64_t n_rays, int64_t n_elems,
+static void launch_seg(const Op &op, const int64_t *packed_info, const int64_t *tiles_raw, int64_t n_rays, int64_t n_tiles,
                        hipStream_t s)
 {
-    const int64_t n_tiles = nfa_seg_num_tiles(n_elems);
+    const longlong2 *tiles = reinterpret_cast<const longlong2 *>(tiles_raw);
     const unsigned grid = (unsigned)ceil_div64(n_tiles, SEG_WAVES_PER_BLOCK);
-    hipLaunchKernelGGL((seg_kernel<DIR, Op>), dim3(grid), dim3(64 * SEG_WAVES_PER_BLOCK), 0, s, op, packed_info, tiles,
-                       n_rays, n_tiles);
+    static const bool pipe = getenv("NFA_SEG_PIPELINE") ? atoi(getenv("NFA_SEG_PIPELINE")) != 0 : true;
+    if (pipe)
+        hipLaunchKernelGGL((seg_kernel<DIR, true, Op>), dim3(grid), dim3(64 * SEG_WAVES_PER_BLOCK), 0, s, op, packed_info, tiles,
+                           n_rays, n_tiles);
+    else
+        hipLaunchKernelGGL((seg_kernel<DIR, false, Op>), dim3(grid), dim3(64 * SEG_WAVES_PER_BLOCK), 0, s, op, packed_info, tiles,
+                           n_rays, n_tiles);
 }
 
 // ------------------------------------------------------------------------------------------
-// Ops.  Each keeps its per-step registers as members (fully unrolled, register resident).
+// Ops.  `Raw` holds what one step loads (fetched one step ahead by the engine); the per-step
+// working registers are members (fully unrolled, register resident).
 
 struct OpBase1 {  // one additive channel
     static constexpr int NCH = 1;
@@ -297,12 +344,18 @@ struct OpBase1 {  // one additive channel
 template <bool EXCL, bool PROD, bool VEC>
 struct ScanOp {
     static constexpr int NCH = 1;
+    struct Raw { F4 x; };
     const float *in;
     float *out;
     float xin[4], res[4];
     __device__ __forceinline__ float identity(int) const { return PROD ? 1.0f : 0.0f; }
     __device__ __forceinline__ float comb(int, float a, float b) const { return PROD ? a * b : a + b; }
-    __device__ __forceinline__ void load(int64_t p0, const bool valid[4]) { load4<VEC>(in, p0, valid, identity(0), xin); }
+    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const { ld4<VEC>(in, p0, ps, valid, r.x); }
+    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xin[j] = sel(r.x, j, valid, identity(0));
+    }
     __device__ __forceinline__ float x(int j, int) const { return xin[j]; }
     __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int, int, const float incl[1], const float prev[1])
     {
@@ -317,17 +370,20 @@ struct ScanOp {
 //      scan.cu:169-214, :259-304
 template <bool EXCL, bool VEC>
 struct ProdBwdOp : OpBase1 {
+    struct Raw { F4 o, g, in; };
     const float *in, *outv, *g;
     float *gin;
     float q[4], den[4], res[4];
-    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
     {
-        float o[4], gg[4];
-        load4<VEC>(outv, p0, valid, 0.0f, o);
-        load4<VEC>(g, p0, valid, 0.0f, gg);
-        load4<VEC>(in, p0, valid, 1.0f, den);
+        ld4<VEC>(outv, p0, ps, valid, r.o);
+        ld4<VEC>(g, p0, ps, valid, r.g);
+        ld4<VEC>(in, p0, ps, valid, r.in);
+    }
+    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) q[j] = gg[j] * o[j];
+        for (int j = 0; j < 4; ++j) { q[j] = sel(r.g, j, valid, 0.0f) * sel(r.o, j, valid, 0.0f); den[j] = sel(r.in, j, valid, 1.0f); }
     }
     __device__ __forceinline__ float x(int j, int) const { return q[j]; }
     __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int, int, const float incl[1], const float prev[1])
@@ -341,18 +397,24 @@ struct ProdBwdOp : OpBase1 {
 // ---- transmittance / alpha / weights from density, volrend.py:256-264, :358-362
 template <bool VEC>
 struct DensityFwdOp : OpBase1 {
+    struct Raw { F4 a, b, s, pf; };
     const float *ts, *te, *sig, *prefix;
     float *w, *tr, *al;
     float xs[4], pf[4], rw[4], rt[4], ra[4];
-    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
     {
-        float a[4], b[4], s[4];
-        load4<VEC>(ts, p0, valid, 0.0f, a);
-        load4<VEC>(te, p0, valid, 0.0f, b);
-        load4<VEC>(sig, p0, valid, 0.0f, s);
-        if (prefix) load4<VEC>(prefix, p0, valid, 1.0f, pf);
+        ld4<VEC>(ts, p0, ps, valid, r.a);
+        ld4<VEC>(te, p0, ps, valid, r.b);
+        ld4<VEC>(sig, p0, ps, valid, r.s);
+        if (prefix) ld4<VEC>(prefix, p0, ps, valid, r.pf);
+    }
+    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xs[j] = s[j] * (b[j] - a[j]);
+        for (int j = 0; j < 4; ++j) {
+            xs[j] = valid[j] ? r.s.v[j] * (r.b.v[j] - r.a.v[j]) : 0.0f;
+            pf[j] = prefix ? r.pf.v[j] : 1.0f;
+        }
     }
     __device__ __forceinline__ float x(int j, int) const { return xs[j]; }
     __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int, int, const float *, const float prev[1])
@@ -375,15 +437,21 @@ struct DensityFwdOp : OpBase1 {
 template <bool VEC>
 struct AlphaFwdOp {
     static constexpr int NCH = 1;
+    struct Raw { F4 a, pf; };
     const float *al, *prefix;
     float *w, *tr;
     float a4[4], pf[4], rw[4], rt[4];
     __device__ __forceinline__ float identity(int) const { return 1.0f; }
     __device__ __forceinline__ float comb(int, float a, float b) const { return a * b; }
-    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
     {
-        load4<VEC>(al, p0, valid, 0.0f, a4);
-        if (prefix) load4<VEC>(prefix, p0, valid, 1.0f, pf);
+        ld4<VEC>(al, p0, ps, valid, r.a);
+        if (prefix) ld4<VEC>(prefix, p0, ps, valid, r.pf);
+    }
+    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a4[j] = sel(r.a, j, valid, 0.0f); pf[j] = prefix ? r.pf.v[j] : 1.0f; }
     }
     __device__ __forceinline__ float x(int j, int) const { return 1.0f - a4[j]; }
     __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int, int, const float *, const float prev[1])
@@ -404,23 +472,30 @@ struct AlphaFwdOp {
 // ---- backward of the fused density op (reverse scan), SURVEY App. A.7
 template <bool VEC>
 struct DensityBwdOp : OpBase1 {
+    struct Raw { F4 a, b, T, A, gw, gt, ga; };
     const float *ts, *te, *tr, *al, *gw, *gt, *ga;
     float *gsig, *gx;
     float T[4], A[4], GW[4], GA[4], dlt[4], q[4], rs[4], rx[4];
-    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
     {
-        float a[4], b[4], GT[4];
-        load4<VEC>(ts, p0, valid, 0.0f, a);
-        load4<VEC>(te, p0, valid, 0.0f, b);
-        load4<VEC>(tr, p0, valid, 0.0f, T);
-        load4<VEC>(al, p0, valid, 0.0f, A);
-        if (gw) load4<VEC>(gw, p0, valid, 0.0f, GW); else GW[0] = GW[1] = GW[2] = GW[3] = 0.0f;
-        if (gt) load4<VEC>(gt, p0, valid, 0.0f, GT); else GT[0] = GT[1] = GT[2] = GT[3] = 0.0f;
-        if (ga) load4<VEC>(ga, p0, valid, 0.0f, GA); else GA[0] = GA[1] = GA[2] = GA[3] = 0.0f;
+        ld4<VEC>(ts, p0, ps, valid, r.a);
+        ld4<VEC>(te, p0, ps, valid, r.b);
+        ld4<VEC>(tr, p0, ps, valid, r.T);
+        ld4<VEC>(al, p0, ps, valid, r.A);
+        if (gw) ld4<VEC>(gw, p0, ps, valid, r.gw);
+        if (gt) ld4<VEC>(gt, p0, ps, valid, r.gt);
+        if (ga) ld4<VEC>(ga, p0, ps, valid, r.ga);
+    }
+    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            dlt[j] = b[j] - a[j];
-            q[j] = GW[j] * (T[j] * A[j]) + GT[j] * T[j];
+            T[j] = sel(r.T, j, valid, 0.0f); A[j] = sel(r.A, j, valid, 0.0f);
+            GW[j] = (gw && valid[j]) ? r.gw.v[j] : 0.0f;
+            const float GT = (gt && valid[j]) ? r.gt.v[j] : 0.0f;
+            GA[j] = (ga && valid[j]) ? r.ga.v[j] : 0.0f;
+            dlt[j] = r.b.v[j] - r.a.v[j];
+            q[j] = GW[j] * (T[j] * A[j]) + GT * T[j];
         }
     }
     __device__ __forceinline__ float x(int j, int) const { return q[j]; }
@@ -441,18 +516,26 @@ struct DensityBwdOp : OpBase1 {
 // ---- backward of the fused alpha op: g_a = g_w T - sum_{i>k}(g_w_i w_i + g_T_i T_i) / max(1-a, 1e-10)
 template <bool VEC>
 struct AlphaBwdOp : OpBase1 {
+    struct Raw { F4 T, A, gw, gt; };
     const float *al, *tr, *gw, *gt;
     float *galpha;
     float T[4], A[4], GW[4], q[4], res[4];
-    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
     {
-        float GT[4];
-        load4<VEC>(tr, p0, valid, 0.0f, T);
-        load4<VEC>(al, p0, valid, 0.0f, A);
-        if (gw) load4<VEC>(gw, p0, valid, 0.0f, GW); else GW[0] = GW[1] = GW[2] = GW[3] = 0.0f;
-        if (gt) load4<VEC>(gt, p0, valid, 0.0f, GT); else GT[0] = GT[1] = GT[2] = GT[3] = 0.0f;
+        ld4<VEC>(tr, p0, ps, valid, r.T);
+        ld4<VEC>(al, p0, ps, valid, r.A);
+        if (gw) ld4<VEC>(gw, p0, ps, valid, r.gw);
+        if (gt) ld4<VEC>(gt, p0, ps, valid, r.gt);
+    }
+    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) q[j] = (GW[j] * A[j] + GT[j]) * T[j];
+        for (int j = 0; j < 4; ++j) {
+            T[j] = sel(r.T, j, valid, 0.0f); A[j] = sel(r.A, j, valid, 0.0f);
+            GW[j] = (gw && valid[j]) ? r.gw.v[j] : 0.0f;
+            const float GT = (gt && valid[j]) ? r.gt.v[j] : 0.0f;
+            q[j] = (GW[j] * A[j] + GT) * T[j];
+        }
     }
     __device__ __forceinline__ float x(int j, int) const { return q[j]; }
     __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int, int, const float *, const float prev[1])
@@ -468,6 +551,7 @@ struct AlphaBwdOp : OpBase1 {
 template <bool DENSITY, bool VEC>
 struct VisibilityOp {
     static constexpr int NCH = 1;
+    struct Raw { F4 s, pf, a, b; };
     const float *ts, *te, *val, *prefix;
     float eps, thre;
     uint8_t *vis;
@@ -475,20 +559,23 @@ struct VisibilityOp {
     uint8_t m[4];
     __device__ __forceinline__ float identity(int) const { return DENSITY ? 0.0f : 1.0f; }
     __device__ __forceinline__ float comb(int, float a, float b) const { return DENSITY ? a + b : a * b; }
-    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
     {
-        float s[4];
-        load4<VEC>(val, p0, valid, 0.0f, s);
-        if (prefix) load4<VEC>(prefix, p0, valid, 1.0f, pf);
+        ld4<VEC>(val, p0, ps, valid, r.s);
+        if (prefix) ld4<VEC>(prefix, p0, ps, valid, r.pf);
         if (DENSITY) {
-            float a[4], b[4];
-            load4<VEC>(ts, p0, valid, 0.0f, a);
-            load4<VEC>(te, p0, valid, 0.0f, b);
+            ld4<VEC>(ts, p0, ps, valid, r.a);
+            ld4<VEC>(te, p0, ps, valid, r.b);
+        }
+    }
+    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { x0[j] = s[j] * (b[j] - a[j]); a4[j] = 1.0f - expf(-x0[j]); }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { a4[j] = s[j]; x0[j] = 1.0f - s[j]; }
+        for (int j = 0; j < 4; ++j) {
+            pf[j] = prefix ? r.pf.v[j] : 1.0f;
+            const float sv = sel(r.s, j, valid, 0.0f);
+            if (DENSITY) { x0[j] = valid[j] ? sv * (r.b.v[j] - r.a.v[j]) : 0.0f; a4[j] = 1.0f - expf(-x0[j]); }
+            else { a4[j] = sv; x0[j] = 1.0f - sv; }
         }
     }
     __device__ __forceinline__ float x(int j, int) const { return x0[j]; }
@@ -505,31 +592,46 @@ struct VisibilityOp {
         if (VEC && valid[0] && valid[1] && valid[2] && valid[3]) {
             *reinterpret_cast<uchar4 *>(vis + p0) = make_uchar4(m[0], m[1], m[2], m[3]);
         } else {
+            volatile uint8_t *pv = vis;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (valid[j]) vis[p0 + j] = m[j];
+                if (valid[j]) pv[p0 + j] = m[j];
         }
     }
     __device__ __forceinline__ void ray_done(int, const float *) const {}
     __device__ __forceinline__ void empty_ray(int) const {}
 };
 
+struct U4 { uint32_t w; };  // 4 mask bytes, raw
+__device__ __forceinline__ void load_mask4(const uint8_t *vis, bool vec, int64_t p0, int64_t ps, const bool valid[4], U4 &m)
+{
+    if (vec) {
+        const bool any = valid[0] | valid[1] | valid[2] | valid[3];
+        m.w = *reinterpret_cast<const uint32_t *>(vis + (any ? p0 : ps));
+    } else {
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w |= (uint32_t)vis[valid[j] ? p0 + j : ps] << (8 * j);
+        m.w = w;
+    }
+}
+__device__ __forceinline__ float mask_sel(const U4 &m, int j, const bool valid[4])
+{
+    return (valid[j] && ((m.w >> (8 * j)) & 0xFFu)) ? 1.0f : 0.0f;
+}
+
 // ---- per-ray count of set mask bytes (second pass input of the compaction) and the compaction
 template <bool VEC>
 struct MaskCountOp : OpBase1 {
+    struct Raw { U4 m; };
     const uint8_t *vis;
     int64_t *cnts;
     float m[4];
-    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const { load_mask4(vis, VEC, p0, ps, valid, r.m); }
+    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
     {
-        if (VEC && (valid[0] | valid[1] | valid[2] | valid[3])) {
-            const uchar4 v = *reinterpret_cast<const uchar4 *>(vis + p0);
-            m[0] = (valid[0] && v.x) ? 1.0f : 0.0f; m[1] = (valid[1] && v.y) ? 1.0f : 0.0f;
-            m[2] = (valid[2] && v.z) ? 1.0f : 0.0f; m[3] = (valid[3] && v.w) ? 1.0f : 0.0f;
-        } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) m[j] = (valid[j] && vis[p0 + j]) ? 1.0f : 0.0f;
-        }
+        for (int j = 0; j < 4; ++j) m[j] = mask_sel(r.m, j, valid);
     }
     __device__ __forceinline__ float x(int j, int) const { return m[j]; }
     __device__ __forceinline__ void emit(int, int64_t, bool, bool is_head, int, int prev_rid, const float *, const float prev[1])
@@ -543,18 +645,24 @@ struct MaskCountOp : OpBase1 {
 
 template <bool VEC>
 struct CompactOp : OpBase1 {
+    struct Raw { U4 m; F4 a, b; };
     const uint8_t *vis;
+    int vis_vec;
     const float *ts, *te;
     const int64_t *out_starts;
     int64_t *o_ri;
     float *o_ts, *o_te;
     float m[4], a[4], b[4];
-    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
+    {
+        load_mask4(vis, vis_vec != 0, p0, ps, valid, r.m);
+        ld4<VEC>(ts, p0, ps, valid, r.a);
+        ld4<VEC>(te, p0, ps, valid, r.b);
+    }
+    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
     {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m[j] = (valid[j] && vis[p0 + j]) ? 1.0f : 0.0f;
-        load4<VEC>(ts, p0, valid, 0.0f, a);
-        load4<VEC>(te, p0, valid, 0.0f, b);
+        for (int j = 0; j < 4; ++j) { m[j] = mask_sel(r.m, j, valid); a[j] = r.a.v[j]; b[j] = r.b.v[j]; }
     }
     __device__ __forceinline__ float x(int j, int) const { return m[j]; }
     __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int rid, int, const float *, const float prev[1])
@@ -571,6 +679,7 @@ struct CompactOp : OpBase1 {
 template <int C, bool VEC>
 struct AccumOp {
     static constexpr int NCH = C;
+    struct Raw { F4 w; float v[4][C]; };
     const float *w, *vals;  // vals may be null (C == 1): accumulate w
     int32_t D, d0;
     float *out;
@@ -578,15 +687,22 @@ struct AccumOp {
     float xv[4][C];
     __device__ __forceinline__ float identity(int) const { return 0.0f; }
     __device__ __forceinline__ float comb(int, float a, float b) const { return a + b; }
-    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
     {
-        float ww[4];
-        load4<VEC>(w, p0, valid, 0.0f, ww);
+        ld4<VEC>(w, p0, ps, valid, r.w);
+        if (vals) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) r.v[j][ch] = vals[(valid[j] ? p0 + j : ps) * D + d0 + ch];
+        }
+    }
+    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int ch = 0; ch < C; ++ch)
-                xv[j][ch] = vals ? (valid[j] ? ww[j] * vals[(p0 + j) * D + d0 + ch] : 0.0f) : ww[j];
+            for (int ch = 0; ch < C; ++ch) xv[j][ch] = valid[j] ? (vals ? r.w.v[j] * r.v[j][ch] : r.w.v[j]) : 0.0f;
     }
     __device__ __forceinline__ float x(int j, int ch) const { return xv[j][ch]; }
     __device__ __forceinline__ void put(int rid, const float *tot) const
@@ -613,16 +729,32 @@ struct AccumOp {
 
 template <int C, bool VEC>
 struct AccumBwdOp : OpBase1 {
+    struct Raw { F4 w, g; float v[4][C]; };
     const float *w, *vals, *gout;
     int32_t D, d0;
     int first;  // first channel group: g_w is written, later groups add to it
     float *gw, *gv;
-    float ww[4], res[4];
-    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    float ww[4], res[4], vv[4][C];
+    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
     {
-        load4<VEC>(w, p0, valid, 0.0f, ww);
-        if (gw && !first) load4<VEC>(gw, p0, valid, 0.0f, res);
-        else res[0] = res[1] = res[2] = res[3] = 0.0f;
+        ld4<VEC>(w, p0, ps, valid, r.w);
+        if (gw && !first) ld4<VEC>(gw, p0, ps, valid, r.g);
+        if (vals) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) r.v[j][ch] = vals[(valid[j] ? p0 + j : ps) * D + d0 + ch];
+        }
+    }
+    __device__ __forceinline__ void load(const Raw &r, const bool *)
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ww[j] = r.w.v[j];
+            res[j] = (gw && !first) ? r.g.v[j] : 0.0f;
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) vv[j][ch] = vals ? r.v[j][ch] : 0.0f;
+        }
     }
     __device__ __forceinline__ float x(int, int) const { return 0.0f; }
     __device__ __forceinline__ void emit(int j, int64_t pos, bool valid, bool, int rid, int, const float *, const float *)
@@ -632,7 +764,7 @@ struct AccumBwdOp : OpBase1 {
         for (int ch = 0; ch < C; ++ch) {
             const float go = gout[(int64_t)rid * D + d0 + ch];
             if (vals) {
-                res[j] += go * vals[pos * D + d0 + ch];
+                res[j] += go * vv[j][ch];
                 if (gv) gv[pos * D + d0 + ch] = go * ww[j];
             } else {
                 res[j] += go;
@@ -645,38 +777,70 @@ struct AccumBwdOp : OpBase1 {
     }
 };
 
+// 4 x rgb (12 consecutive floats at 3*p), raw.  With VEC the 48 bytes are three aligned 16 B loads from
+// p0 when all 4 elements are valid, else from the step's base (always inside the array); the few
+// lanes that straddle a range end re-read their valid elements one by one in fix_rgb12.
+__device__ __forceinline__ void load_rgb12(const float *rgb, bool vec, int64_t p0, int64_t ps, const bool valid[4], float c[12])
+{
+    if (vec) {
+        const bool all = valid[0] & valid[1] & valid[2] & valid[3];
+        const float4 *q = reinterpret_cast<const float4 *>(rgb + 3 * (all ? p0 : ps));
+        const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+        c[0] = q0.x; c[1] = q0.y; c[2] = q0.z; c[3] = q0.w; c[4] = q1.x; c[5] = q1.y;
+        c[6] = q1.z; c[7] = q1.w; c[8] = q2.x; c[9] = q2.y; c[10] = q2.z; c[11] = q2.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) c[3 * j + k] = rgb[3 * (valid[j] ? p0 + j : ps) + k];
+    }
+}
+__device__ __forceinline__ void fix_rgb12(const float *rgb, bool vec, int64_t p0, const bool valid[4], const float raw[12], float c[12])
+{
+    const bool all = valid[0] & valid[1] & valid[2] & valid[3];
+    const bool any = valid[0] | valid[1] | valid[2] | valid[3];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) c[k] = raw[k];
+    if (vec && any && !all) {  // rare: first / last lane of a range
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) c[3 * j + k] = valid[j] ? rgb[3 * (p0 + j) + k] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) c[3 * j + k] = valid[j] ? c[3 * j + k] : 0.0f;
+}
+
 // ---- the three accumulations of `rendering` fused: colours(3), opacity, depth  (volrend.py:140-151)
 template <bool VEC>
 struct RenderAccumOp {
     static constexpr int NCH = 5;
+    struct Raw { F4 w, a, b; float c[12]; int64_t p0; };
     const float *w, *rgb, *ts, *te;
     float *colors, *opac, *depth;
     float xv[4][5];
     __device__ __forceinline__ float identity(int) const { return 0.0f; }
     __device__ __forceinline__ float comb(int, float a, float b) const { return a + b; }
-    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
     {
-        float ww[4], a[4], b[4];
-        load4<VEC>(w, p0, valid, 0.0f, ww);
-        load4<VEC>(ts, p0, valid, 0.0f, a);
-        load4<VEC>(te, p0, valid, 0.0f, b);
+        ld4<VEC>(w, p0, ps, valid, r.w);
+        ld4<VEC>(ts, p0, ps, valid, r.a);
+        ld4<VEC>(te, p0, ps, valid, r.b);
+        load_rgb12(rgb, VEC, p0, ps, valid, r.c);
+        r.p0 = p0;
+    }
+    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    {
         float c[12];
-        if (VEC && valid[0] && valid[1] && valid[2] && valid[3]) {
-            const float4 *q = reinterpret_cast<const float4 *>(rgb + 3 * p0);
-            const float4 q0 = q[0], q1 = q[1], q2 = q[2];
-            c[0] = q0.x; c[1] = q0.y; c[2] = q0.z; c[3] = q0.w; c[4] = q1.x; c[5] = q1.y;
-            c[6] = q1.z; c[7] = q1.w; c[8] = q2.x; c[9] = q2.y; c[10] = q2.z; c[11] = q2.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) c[3 * j + k] = valid[j] ? rgb[3 * (p0 + j) + k] : 0.0f;
-        }
+        fix_rgb12(rgb, VEC, r.p0, valid, r.c, c);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            xv[j][0] = ww[j] * c[3 * j]; xv[j][1] = ww[j] * c[3 * j + 1]; xv[j][2] = ww[j] * c[3 * j + 2];
-            xv[j][3] = ww[j];
-            xv[j][4] = ww[j] * ((a[j] + b[j]) / 2.0f);
+            const float ww = sel(r.w, j, valid, 0.0f);
+            xv[j][0] = ww * c[3 * j]; xv[j][1] = ww * c[3 * j + 1]; xv[j][2] = ww * c[3 * j + 2];
+            xv[j][3] = ww;
+            xv[j][4] = ww * ((r.a.v[j] + r.b.v[j]) / 2.0f);
         }
     }
     __device__ __forceinline__ float x(int j, int ch) const { return xv[j][ch]; }
@@ -700,30 +864,25 @@ struct RenderAccumOp {
 
 template <bool VEC>
 struct RenderAccumBwdOp : OpBase1 {
+    struct Raw { F4 w, a, b; float c[12]; int64_t p0; };
     const float *w, *rgb, *ts, *te, *gc, *go, *gd;
     float *gw, *grgb;
     float ww[4], mid[4], res[4], c[12], gr[12];
     bool full;
-    __device__ __forceinline__ void load(int64_t p0, const bool valid[4])
+    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
     {
-        float a[4], b[4];
-        load4<VEC>(w, p0, valid, 0.0f, ww);
-        load4<VEC>(ts, p0, valid, 0.0f, a);
-        load4<VEC>(te, p0, valid, 0.0f, b);
+        ld4<VEC>(w, p0, ps, valid, r.w);
+        ld4<VEC>(ts, p0, ps, valid, r.a);
+        ld4<VEC>(te, p0, ps, valid, r.b);
+        load_rgb12(rgb, VEC, p0, ps, valid, r.c);
+        r.p0 = p0;
+    }
+    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    {
         full = VEC && valid[0] && valid[1] && valid[2] && valid[3];
-        if (full) {
-            const float4 *q = reinterpret_cast<const float4 *>(rgb + 3 * p0);
-            const float4 q0 = q[0], q1 = q[1], q2 = q[2];
-            c[0] = q0.x; c[1] = q0.y; c[2] = q0.z; c[3] = q0.w; c[4] = q1.x; c[5] = q1.y;
-            c[6] = q1.z; c[7] = q1.w; c[8] = q2.x; c[9] = q2.y; c[10] = q2.z; c[11] = q2.w;
-        } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) c[3 * j + k] = valid[j] ? rgb[3 * (p0 + j) + k] : 0.0f;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) mid[j] = (a[j] + b[j]) / 2.0f;
+        for (int j = 0; j < 4; ++j) { ww[j] = r.w.v[j]; mid[j] = (r.a.v[j] + r.b.v[j]) / 2.0f; }
+        fix_rgb12(rgb, VEC, r.p0, valid, r.c, c);
     }
     __device__ __forceinline__ float x(int, int) const { return 0.0f; }
     __device__ __forceinline__ void emit(int j, int64_t, bool valid, bool, int rid, int, const float *, const float *)
@@ -751,10 +910,11 @@ struct RenderAccumBwdOp : OpBase1 {
                 q[1] = make_float4(gr[4], gr[5], gr[6], gr[7]);
                 q[2] = make_float4(gr[8], gr[9], gr[10], gr[11]);
             } else {
+                volatile float *pv = grgb;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (valid[j]) {
-                        grgb[3 * (p0 + j)] = gr[3 * j]; grgb[3 * (p0 + j) + 1] = gr[3 * j + 1]; grgb[3 * (p0 + j) + 2] = gr[3 * j + 2];
+                        pv[3 * (p0 + j)] = gr[3 * j]; pv[3 * (p0 + j) + 1] = gr[3 * j + 1]; pv[3 * (p0 + j) + 2] = gr[3 * j + 2];
                     }
             }
         }
@@ -835,28 +995,39 @@ using namespace nfa;
     NFA_REQUIRE(n_rays >= 0 && n_elems >= 0, name ": negative size");                                   \
     NFA_REQUIRE(n_rays < ((int64_t)1 << 31) - 64, name ": too many rays");                              \
     if (n_elems == 0 && n_rays == 0) return NFA_OK;                                                      \
-    NFA_REQUIRE(packed_info && tiles, name ": packed_info/tiles is null")
+    NFA_REQUIRE(packed_info && tiles && n_tiles >= 1, name ": packed_info/tiles is null")
 
 extern "C" {
 
-int64_t nfa_seg_num_tiles(int64_t n_elems) { return n_elems / NFA_SEG_TILE + 1; }
+void nfa_seg_plan(int64_t n_elems, int64_t *tile_elems, int64_t *n_tiles)
+{
+    // One wave per tile.  Measured on MI355X (scripts/sweep_seg.sh, 32 M samples): 1024-element tiles
+    // (4 steps per wave, ~120 waves per CU) are fastest; longer tiles lose to the tail of the last
+    // wave round, shorter ones to the per-tile prologue.
+    (void)n_elems;
+    int64_t t = 1024;
+    if (const char *e = getenv("NFA_SEG_TILE")) t = atoll(e);  // tuning knob (multiple of 256)
+    *tile_elems = t;
+    *n_tiles = n_elems / t + 1;
+}
 
-int nfa_seg_build_tiles(const int64_t *packed_info, int64_t n_rays, int64_t n_elems, int32_t *tiles, int32_t *flags,
-                        nfa_stream_t stream)
+int nfa_seg_build_tiles(const int64_t *packed_info, int64_t n_rays, int64_t n_elems, int64_t tile_elems, int64_t n_tiles,
+                        int64_t *tiles, int32_t *flags, nfa_stream_t stream)
 {
     NFA_REQUIRE(n_rays >= 0 && n_elems >= 0 && tiles && flags, "seg_build_tiles: bad arguments");
     NFA_REQUIRE(n_rays == 0 || packed_info, "seg_build_tiles: packed_info is null");
     NFA_REQUIRE(n_rays < ((int64_t)1 << 31) - 64, "seg_build_tiles: too many rays");
+    NFA_REQUIRE(tile_elems >= 256 && tile_elems % 256 == 0 && n_tiles == n_elems / tile_elems + 1,
+                "seg_build_tiles: tile_elems must be a multiple of 256 and n_tiles == n_elems / tile_elems + 1");
     hipStream_t s = as_stream(stream);
     if (hipMemsetAsync(flags, 0, sizeof(int32_t), s) != hipSuccess) { set_error("seg_build_tiles: memset failed"); return NFA_EHIP; }
-    const int64_t n_tiles = nfa_seg_num_tiles(n_elems);
     hipLaunchKernelGGL(seg_build_tiles_kernel, dim3(grid_1d(n_rays + 1, 256)), dim3(256), 0, s, packed_info, n_rays,
-                       n_elems, n_tiles, tiles, flags);
+                       n_elems, tile_elems, n_tiles, reinterpret_cast<longlong2 *>(tiles), flags);
     NFA_CHECK_LAUNCH("seg_build_tiles");
     return NFA_OK;
 }
 
-int nfa_packed_scan(int kind, int reverse, const int64_t *packed_info, const int32_t *tiles, int64_t n_rays,
+int nfa_packed_scan(int kind, int reverse, const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles, int64_t n_rays,
                     int64_t n_elems, const float *inputs, float *outputs, nfa_stream_t stream)
 {
     SEG_COMMON_CHECKS("packed_scan");
@@ -868,11 +1039,11 @@ int nfa_packed_scan(int kind, int reverse, const int64_t *packed_info, const int
 #define NFA_SCAN_CASE(EX, PR)                                                                             \
     do {                                                                                                  \
         if (vec) { ScanOp<EX, PR, true> op; op.in = inputs; op.out = outputs;                            \
-            if (reverse) launch_seg<-1>(op, packed_info, tiles, n_rays, n_elems, s);                      \
-            else launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); }                             \
+            if (reverse) launch_seg<-1>(op, packed_info, tiles, n_rays, n_tiles, s);                      \
+            else launch_seg<1>(op, packed_info, tiles, n_rays, n_tiles, s); }                             \
         else { ScanOp<EX, PR, false> op; op.in = inputs; op.out = outputs;                               \
-            if (reverse) launch_seg<-1>(op, packed_info, tiles, n_rays, n_elems, s);                      \
-            else launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); }                             \
+            if (reverse) launch_seg<-1>(op, packed_info, tiles, n_rays, n_tiles, s);                      \
+            else launch_seg<1>(op, packed_info, tiles, n_rays, n_tiles, s); }                             \
     } while (0)
     switch (kind) {
         case 0: NFA_SCAN_CASE(false, false); break;
@@ -903,7 +1074,7 @@ int nfa_packed_scan_generic(int kind, int reverse, int normalize, const int64_t 
     return NFA_OK;
 }
 
-int nfa_packed_prod_backward(int kind, const int64_t *packed_info, const int32_t *tiles, int64_t n_rays,
+int nfa_packed_prod_backward(int kind, const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles, int64_t n_rays,
                              int64_t n_elems, const float *inputs, const float *outputs, const float *grad_outputs,
                              float *grad_inputs, nfa_stream_t stream)
 {
@@ -915,7 +1086,7 @@ int nfa_packed_prod_backward(int kind, const int64_t *packed_info, const int32_t
     const bool vec = all_aligned16(inputs, outputs, grad_outputs, grad_inputs);
 #define NFA_PB(EX, V)                                                                                      \
     do { ProdBwdOp<EX, V> op; op.in = inputs; op.outv = outputs; op.g = grad_outputs; op.gin = grad_inputs; \
-         launch_seg<-1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+         launch_seg<-1>(op, packed_info, tiles, n_rays, n_tiles, s); } while (0)
     if (kind == 2) { if (vec) NFA_PB(false, true); else NFA_PB(false, false); }
     else           { if (vec) NFA_PB(true, true); else NFA_PB(true, false); }
 #undef NFA_PB
@@ -924,7 +1095,7 @@ int nfa_packed_prod_backward(int kind, const int64_t *packed_info, const int32_t
 }
 
 int nfa_render_from_density_fwd(const float *t_starts, const float *t_ends, const float *sigmas,
-                                const float *prefix_trans, const int64_t *packed_info, const int32_t *tiles,
+                                const float *prefix_trans, const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles,
                                 int64_t n_rays, int64_t n_elems, float *weights, float *trans, float *alphas,
                                 nfa_stream_t stream)
 {
@@ -935,7 +1106,7 @@ int nfa_render_from_density_fwd(const float *t_starts, const float *t_ends, cons
     const bool vec = all_aligned16(t_starts, t_ends, sigmas, prefix_trans, weights, trans, alphas);
 #define NFA_DF(V)                                                                                          \
     do { DensityFwdOp<V> op; op.ts = t_starts; op.te = t_ends; op.sig = sigmas; op.prefix = prefix_trans;   \
-         op.w = weights; op.tr = trans; op.al = alphas; launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+         op.w = weights; op.tr = trans; op.al = alphas; launch_seg<1>(op, packed_info, tiles, n_rays, n_tiles, s); } while (0)
     if (vec) NFA_DF(true); else NFA_DF(false);
 #undef NFA_DF
     NFA_CHECK_LAUNCH("render_from_density_fwd");
@@ -943,7 +1114,7 @@ int nfa_render_from_density_fwd(const float *t_starts, const float *t_ends, cons
 }
 
 int nfa_render_from_alpha_fwd(const float *alphas, const float *prefix_trans, const int64_t *packed_info,
-                              const int32_t *tiles, int64_t n_rays, int64_t n_elems, float *weights, float *trans,
+                              const int64_t *tiles, int64_t n_tiles, int64_t n_rays, int64_t n_elems, float *weights, float *trans,
                               nfa_stream_t stream)
 {
     SEG_COMMON_CHECKS("render_from_alpha_fwd");
@@ -953,7 +1124,7 @@ int nfa_render_from_alpha_fwd(const float *alphas, const float *prefix_trans, co
     const bool vec = all_aligned16(alphas, prefix_trans, weights, trans);
 #define NFA_AF(V)                                                                                          \
     do { AlphaFwdOp<V> op; op.al = alphas; op.prefix = prefix_trans; op.w = weights; op.tr = trans;          \
-         launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+         launch_seg<1>(op, packed_info, tiles, n_rays, n_tiles, s); } while (0)
     if (vec) NFA_AF(true); else NFA_AF(false);
 #undef NFA_AF
     NFA_CHECK_LAUNCH("render_from_alpha_fwd");
@@ -962,7 +1133,7 @@ int nfa_render_from_alpha_fwd(const float *alphas, const float *prefix_trans, co
 
 int nfa_render_from_density_bwd(const float *t_starts, const float *t_ends, const float *trans, const float *alphas,
                                 const float *g_weights, const float *g_trans, const float *g_alphas,
-                                const int64_t *packed_info, const int32_t *tiles, int64_t n_rays, int64_t n_elems,
+                                const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles, int64_t n_rays, int64_t n_elems,
                                 float *grad_sigmas, float *grad_x, nfa_stream_t stream)
 {
     SEG_COMMON_CHECKS("render_from_density_bwd");
@@ -973,7 +1144,7 @@ int nfa_render_from_density_bwd(const float *t_starts, const float *t_ends, cons
 #define NFA_DB(V)                                                                                          \
     do { DensityBwdOp<V> op; op.ts = t_starts; op.te = t_ends; op.tr = trans; op.al = alphas; op.gw = g_weights; \
          op.gt = g_trans; op.ga = g_alphas; op.gsig = grad_sigmas; op.gx = grad_x;                            \
-         launch_seg<-1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+         launch_seg<-1>(op, packed_info, tiles, n_rays, n_tiles, s); } while (0)
     if (vec) NFA_DB(true); else NFA_DB(false);
 #undef NFA_DB
     NFA_CHECK_LAUNCH("render_from_density_bwd");
@@ -981,7 +1152,7 @@ int nfa_render_from_density_bwd(const float *t_starts, const float *t_ends, cons
 }
 
 int nfa_render_from_alpha_bwd(const float *alphas, const float *trans, const float *g_weights, const float *g_trans,
-                              const int64_t *packed_info, const int32_t *tiles, int64_t n_rays, int64_t n_elems,
+                              const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles, int64_t n_rays, int64_t n_elems,
                               float *grad_alphas, nfa_stream_t stream)
 {
     SEG_COMMON_CHECKS("render_from_alpha_bwd");
@@ -991,7 +1162,7 @@ int nfa_render_from_alpha_bwd(const float *alphas, const float *trans, const flo
     const bool vec = all_aligned16(alphas, trans, g_weights, g_trans, grad_alphas);
 #define NFA_AB(V)                                                                                          \
     do { AlphaBwdOp<V> op; op.al = alphas; op.tr = trans; op.gw = g_weights; op.gt = g_trans; op.galpha = grad_alphas; \
-         launch_seg<-1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+         launch_seg<-1>(op, packed_info, tiles, n_rays, n_tiles, s); } while (0)
     if (vec) NFA_AB(true); else NFA_AB(false);
 #undef NFA_AB
     NFA_CHECK_LAUNCH("render_from_alpha_bwd");
@@ -1000,7 +1171,7 @@ int nfa_render_from_alpha_bwd(const float *alphas, const float *trans, const flo
 
 int nfa_render_visibility(const float *t_starts, const float *t_ends, const float *sigmas_or_alphas,
                           const float *prefix_trans, float early_stop_eps, float alpha_thre,
-                          const int64_t *packed_info, const int32_t *tiles, int64_t n_rays, int64_t n_elems,
+                          const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles, int64_t n_rays, int64_t n_elems,
                           uint8_t *vis, int64_t *vis_cnts, nfa_stream_t stream)
 {
     SEG_COMMON_CHECKS("render_visibility");
@@ -1015,22 +1186,22 @@ int nfa_render_visibility(const float *t_starts, const float *t_ends, const floa
 #define NFA_VIS(DN, V)                                                                                     \
     do { VisibilityOp<DN, V> op; op.ts = t_starts; op.te = t_ends; op.val = sigmas_or_alphas; op.prefix = prefix_trans; \
          op.eps = early_stop_eps; op.thre = alpha_thre; op.vis = vis;                 \
-         launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+         launch_seg<1>(op, packed_info, tiles, n_rays, n_tiles, s); } while (0)
         if (density) { if (vec) NFA_VIS(true, true); else NFA_VIS(true, false); }
         else         { if (vec) NFA_VIS(false, true); else NFA_VIS(false, false); }
 #undef NFA_VIS
     }
     if (vis_cnts) {
         const bool vec = n_elems > 0 && (reinterpret_cast<uintptr_t>(vis) & 3) == 0;
-        if (vec) { MaskCountOp<true> op; op.vis = vis; op.cnts = vis_cnts; launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); }
-        else { MaskCountOp<false> op; op.vis = vis; op.cnts = vis_cnts; launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); }
+        if (vec) { MaskCountOp<true> op; op.vis = vis; op.cnts = vis_cnts; launch_seg<1>(op, packed_info, tiles, n_rays, n_tiles, s); }
+        else { MaskCountOp<false> op; op.vis = vis; op.cnts = vis_cnts; launch_seg<1>(op, packed_info, tiles, n_rays, n_tiles, s); }
     }
     NFA_CHECK_LAUNCH("render_visibility");
     return NFA_OK;
 }
 
 int nfa_compact_samples(const uint8_t *vis, const float *t_starts, const float *t_ends, const int64_t *packed_info,
-                        const int32_t *tiles, const int64_t *out_starts, int64_t n_rays, int64_t n_elems,
+                        const int64_t *tiles, int64_t n_tiles, const int64_t *out_starts, int64_t n_rays, int64_t n_elems,
                         int64_t *out_ray_indices, float *out_t_starts, float *out_t_ends, nfa_stream_t stream)
 {
     SEG_COMMON_CHECKS("compact_samples");
@@ -1039,9 +1210,9 @@ int nfa_compact_samples(const uint8_t *vis, const float *t_starts, const float *
     hipStream_t s = as_stream(stream);
     const bool vec = all_aligned16(t_starts, t_ends);
 #define NFA_CP(V)                                                                                          \
-    do { CompactOp<V> op; op.vis = vis; op.ts = t_starts; op.te = t_ends; op.out_starts = out_starts;       \
+    do { CompactOp<V> op; op.vis = vis; op.vis_vec = (reinterpret_cast<uintptr_t>(vis) & 3) == 0; op.ts = t_starts; op.te = t_ends; op.out_starts = out_starts;       \
          op.o_ri = out_ray_indices; op.o_ts = out_t_starts; op.o_te = out_t_ends;                           \
-         launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+         launch_seg<1>(op, packed_info, tiles, n_rays, n_tiles, s); } while (0)
     if (vec) NFA_CP(true); else NFA_CP(false);
 #undef NFA_CP
     NFA_CHECK_LAUNCH("compact_samples");
@@ -1049,7 +1220,7 @@ int nfa_compact_samples(const uint8_t *vis, const float *t_starts, const float *
 }
 
 int nfa_accumulate_along_rays(const float *weights, const float *values, int32_t D, const int64_t *packed_info,
-                              const int32_t *tiles, int64_t n_rays, int64_t n_elems, int accumulate, float *out,
+                              const int64_t *tiles, int64_t n_tiles, int64_t n_rays, int64_t n_elems, int accumulate, float *out,
                               nfa_stream_t stream)
 {
     SEG_COMMON_CHECKS("accumulate_along_rays");
@@ -1062,7 +1233,7 @@ int nfa_accumulate_along_rays(const float *weights, const float *values, int32_t
         const int32_t c = (D - d0 >= 4) ? 4 : (D - d0);
 #define NFA_ACC(C, V)                                                                                      \
     do { AccumOp<C, V> op; op.w = weights; op.vals = values; op.D = D; op.d0 = d0; op.out = out;             \
-         op.accumulate = accumulate; launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+         op.accumulate = accumulate; launch_seg<1>(op, packed_info, tiles, n_rays, n_tiles, s); } while (0)
         if (vec) { if (c == 4) NFA_ACC(4, true); else if (c == 3) NFA_ACC(3, true); else if (c == 2) NFA_ACC(2, true); else NFA_ACC(1, true); }
         else     { if (c == 4) NFA_ACC(4, false); else if (c == 3) NFA_ACC(3, false); else if (c == 2) NFA_ACC(2, false); else NFA_ACC(1, false); }
 #undef NFA_ACC
@@ -1085,7 +1256,7 @@ int nfa_accumulate_along_rays_atomic(const float *weights, const float *values, 
 }
 
 int nfa_accumulate_along_rays_bwd(const float *weights, const float *values, int32_t D, const float *g_out,
-                                  const int64_t *packed_info, const int32_t *tiles, int64_t n_rays, int64_t n_elems,
+                                  const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles, int64_t n_rays, int64_t n_elems,
                                   float *g_weights, float *g_values, nfa_stream_t stream)
 {
     SEG_COMMON_CHECKS("accumulate_along_rays_bwd");
@@ -1099,7 +1270,7 @@ int nfa_accumulate_along_rays_bwd(const float *weights, const float *values, int
 #define NFA_ACB(C, V)                                                                                      \
     do { AccumBwdOp<C, V> op; op.w = weights; op.vals = values; op.gout = g_out; op.D = D; op.d0 = d0;       \
          op.first = (d0 == 0); op.gw = g_weights; op.gv = g_values;                                          \
-         launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+         launch_seg<1>(op, packed_info, tiles, n_rays, n_tiles, s); } while (0)
         if (vec) { if (c == 4) NFA_ACB(4, true); else if (c == 3) NFA_ACB(3, true); else if (c == 2) NFA_ACB(2, true); else NFA_ACB(1, true); }
         else     { if (c == 4) NFA_ACB(4, false); else if (c == 3) NFA_ACB(3, false); else if (c == 2) NFA_ACB(2, false); else NFA_ACB(1, false); }
 #undef NFA_ACB
@@ -1110,7 +1281,7 @@ int nfa_accumulate_along_rays_bwd(const float *weights, const float *values, int
 }
 
 int nfa_render_accumulate_fwd(const float *weights, const float *rgbs, const float *t_starts, const float *t_ends,
-                              const int64_t *packed_info, const int32_t *tiles, int64_t n_rays, int64_t n_elems,
+                              const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles, int64_t n_rays, int64_t n_elems,
                               float *colors, float *opacities, float *depths, nfa_stream_t stream)
 {
     SEG_COMMON_CHECKS("render_accumulate_fwd");
@@ -1122,7 +1293,7 @@ int nfa_render_accumulate_fwd(const float *weights, const float *rgbs, const flo
 #define NFA_RA(V)                                                                                          \
     do { RenderAccumOp<V> op; op.w = weights; op.rgb = rgbs; op.ts = t_starts; op.te = t_ends;               \
          op.colors = colors; op.opac = opacities; op.depth = depths;                                         \
-         launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+         launch_seg<1>(op, packed_info, tiles, n_rays, n_tiles, s); } while (0)
     if (vec) NFA_RA(true); else NFA_RA(false);
 #undef NFA_RA
     NFA_CHECK_LAUNCH("render_accumulate_fwd");
@@ -1131,7 +1302,7 @@ int nfa_render_accumulate_fwd(const float *weights, const float *rgbs, const flo
 
 int nfa_render_accumulate_bwd(const float *weights, const float *rgbs, const float *t_starts, const float *t_ends,
                               const float *g_colors, const float *g_opacities, const float *g_depths,
-                              const int64_t *packed_info, const int32_t *tiles, int64_t n_rays, int64_t n_elems,
+                              const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles, int64_t n_rays, int64_t n_elems,
                               float *g_weights, float *g_rgbs, nfa_stream_t stream)
 {
     SEG_COMMON_CHECKS("render_accumulate_bwd");
@@ -1142,7 +1313,7 @@ int nfa_render_accumulate_bwd(const float *weights, const float *rgbs, const flo
 #define NFA_RB(V)                                                                                          \
     do { RenderAccumBwdOp<V> op; op.w = weights; op.rgb = rgbs; op.ts = t_starts; op.te = t_ends;            \
          op.gc = g_colors; op.go = g_opacities; op.gd = g_depths; op.gw = g_weights; op.grgb = g_rgbs;       \
-         launch_seg<1>(op, packed_info, tiles, n_rays, n_elems, s); } while (0)
+         launch_seg<1>(op, packed_info, tiles, n_rays, n_tiles, s); } while (0)
     if (vec) NFA_RB(true); else NFA_RB(false);
 #undef NFA_RB
     NFA_CHECK_LAUNCH("render_accumulate_bwd");

@@ -101,12 +101,16 @@ struct RunState {
     float open_thr;
 };
 
+// Run record: {t_first : f32 | k_start : 31, continues_previous : 1}, k_start = number of samples of
+// this ray before the run (the run's length is the next record's k_start, or the ray's count).
 __device__ __forceinline__ void close_run(RunState &st, const RunsParams &p, int64_t tid)
 {
     if (!st.open) return;
-    if (st.n_runs < p.max_runs)
+    if (st.n_runs < p.max_runs) {
+        const uint32_t k_start = (uint32_t)(st.n_samples - st.run_n);
         p.runs[tid * p.max_runs + st.n_runs] =
-            (unsigned long long)f32_bits(st.run_t0) | ((unsigned long long)((uint32_t)st.run_n | (st.run_cont ? 0x80000000u : 0u)) << 32);
+            (unsigned long long)f32_bits(st.run_t0) | ((unsigned long long)(k_start | (st.run_cont ? 0x80000000u : 0u)) << 32);
+    }
     st.n_runs++;
     st.open = false;
 }
@@ -341,6 +345,8 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
         close_run(st, p, tid);
         if (a.terminate_planes) a.terminate_planes[tid] = st.t_last;
         a.sm_cnts[tid] = st.n_samples;
+        // rays with > 2^21 samples go to the serial fill too (the expansion packs a 27-bit batch offset)
+        if (st.n_samples > (1 << 21) && st.n_runs <= p.max_runs) st.n_runs = p.max_runs + 1;
         p.run_cnts[tid] = st.n_runs;
         if (st.n_runs > p.max_runs) atomicAdd(p.overflow, 1);
     }
@@ -348,6 +354,10 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
 
 // ------------------------------------------------------------------------------------------
 // Expansion: runs -> (t_starts, t_ends, ray_indices).  One wave per batch of EXP_RPW rays.
+// Staging is a flat parallel copy: entry q of the batch belongs to the ray found by a 5-step search
+// over the per-ray run offsets, and its output position is ray start + k_start, so all loads are
+// independent.  LDS entry = {pos : 27 | local ray : 5, t_first}; a ray whose runs overflowed gets
+// one sentinel entry (t_first = NaN) so that its output range is skipped (the serial kernel fills it).
 __global__ __launch_bounds__(256) void expand_runs_kernel(int64_t n_rays, float dt, const int32_t *__restrict__ run_cnts,
                                                           const unsigned long long *__restrict__ runs, int32_t max_runs,
                                                           const int64_t *__restrict__ sm_starts,
@@ -357,29 +367,29 @@ __global__ __launch_bounds__(256) void expand_runs_kernel(int64_t n_rays, float 
 {
     __shared__ uint32_t s_pos[4][EXP_QMAX];
     __shared__ float s_t0[4][EXP_QMAX];
-    __shared__ uint32_t s_meta[4][EXP_QMAX];  // n (24 bits) | local ray (8 bits)
+    __shared__ int32_t s_base[4][EXP_RPW + 1];   // exclusive run offsets of the batch's rays
+    __shared__ uint32_t s_rel[4][EXP_RPW];       // output offset of each ray inside the batch
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     uint32_t *pos = s_pos[wave];
     float *t0s = s_t0[wave];
-    uint32_t *meta = s_meta[wave];
+    int32_t *base = s_base[wave];
+    uint32_t *rels = s_rel[wave];
     const int64_t n_batches = ceil_div64(n_rays, EXP_RPW);
     for (int64_t batch = (int64_t)blockIdx.x * 4 + wave; batch < n_batches; batch += (int64_t)gridDim.x * 4) {
         const int64_t r0 = batch * EXP_RPW;
         const int64_t ray = r0 + lane;
         const bool own = lane < EXP_RPW && ray < n_rays;
-        int32_t c = 0;
+        int32_t c = 0, c_real = 0;
         int64_t s = 0, n = 0;
         if (own) {
-            c = run_cnts[ray];
-            if (c > max_runs) c = 0;  // overflowed ray: filled by the serial kernel instead
+            c_real = run_cnts[ray];
             s = sm_starts[ray];
             n = sm_cnts[ray];
+            c = (c_real > max_runs) ? 1 : c_real;  // overflowed ray: one sentinel entry
         }
         const int64_t W0 = __shfl(s, 0, 64);
-        // end of the batch's output range = max over owned rays of (s + n): lane of the last ray
         const int last_lane = (int)min((int64_t)EXP_RPW, n_rays - r0) - 1;
         const int64_t W1 = __shfl(s + n, last_lane, 64);
-        // exclusive scan of the run counts over the 32 owning lanes
         int32_t incl = c;
 #pragma unroll
         for (int off = 1; off < EXP_RPW; off <<= 1) {
@@ -387,16 +397,28 @@ __global__ __launch_bounds__(256) void expand_runs_kernel(int64_t n_rays, float 
             if (lane >= off) incl += u;
         }
         const int32_t Q = __shfl(incl, EXP_RPW - 1, 64);
-        int32_t q = incl - c;
-        uint32_t rel = (uint32_t)(s - W0);
-        for (int32_t j = 0; j < c; ++j) {
-            const unsigned long long rec = runs[ray * max_runs + j];
-            const uint32_t nn = (uint32_t)(rec >> 32) & 0x7FFFFFFFu;
-            pos[q] = rel;
-            t0s[q] = bits_f32((uint32_t)rec);
-            meta[q] = (nn & 0xFFFFFFu) | ((uint32_t)lane << 24);
-            rel += nn;
-            ++q;
+        if (lane < EXP_RPW) { base[lane] = incl - c; rels[lane] = (uint32_t)(s - W0); }
+        if (lane == 0) base[EXP_RPW] = Q;
+        // overflow flag per local ray as a wave-uniform mask
+        const unsigned long long ovf_mask = __ballot(own && c_real > max_runs);
+        __builtin_amdgcn_wave_barrier();
+        for (int32_t q = lane; q < Q; q += 64) {
+            int lo = 0, hi = EXP_RPW;  // last local ray with base <= q
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (base[mid] <= q) lo = mid; else hi = mid;
+            }
+            const int rl = lo;
+            const bool ovf = (ovf_mask >> rl) & 1ull;
+            uint32_t k_start = 0;
+            float t0 = __builtin_nanf("");
+            if (!ovf) {
+                const unsigned long long rec = runs[(r0 + rl) * max_runs + (q - base[rl])];
+                k_start = (uint32_t)(rec >> 32) & 0x7FFFFFFFu;
+                t0 = bits_f32((uint32_t)rec);
+            }
+            pos[q] = ((rels[rl] + k_start) & 0x7FFFFFFu) | ((uint32_t)rl << 27);
+            t0s[q] = t0;
         }
         __builtin_amdgcn_wave_barrier();
         if (Q > 0 && W1 > W0) {
@@ -406,7 +428,6 @@ __global__ __launch_bounds__(256) void expand_runs_kernel(int64_t n_rays, float 
                 bool valid[4];
                 float ts4[4], te4[4];
                 int64_t ri4[4];
-                // run containing the first in-range position of this lane
                 int32_t j = -1;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -415,25 +436,25 @@ __global__ __launch_bounds__(256) void expand_runs_kernel(int64_t n_rays, float 
                     ts4[k] = te4[k] = 0.f; ri4[k] = 0;
                     if (pa < W0 || pa >= W1) continue;
                     const uint32_t pr = (uint32_t)(pa - W0);
-                    if (j < 0) {  // upper_bound(pos, pr) - 1
+                    if (j < 0) {  // last entry with position <= pr
                         int32_t lo = 0, hi = Q;
                         while (lo < hi) {
                             const int32_t mid = (lo + hi) >> 1;
-                            if (pos[mid] <= pr) lo = mid + 1; else hi = mid;
+                            if ((pos[mid] & 0x7FFFFFFu) <= pr) lo = mid + 1; else hi = mid;
                         }
                         j = lo - 1;
                     } else {
-                        while (j + 1 < Q && pos[j + 1] <= pr) ++j;
+                        while (j + 1 < Q && (pos[j + 1] & 0x7FFFFFFu) <= pr) ++j;
                     }
-                    if (j < 0) continue;  // before the first run (an overflowed ray's range)
-                    const uint32_t m = meta[j];
-                    const uint32_t kk = pr - pos[j];
-                    if (kk >= (m & 0xFFFFFFu)) continue;  // not covered by a run (overflowed ray)
+                    if (j < 0) continue;
                     const float t0 = t0s[j];
+                    if (t0 != t0) continue;  // sentinel: overflowed ray, filled by the serial kernel
+                    const uint32_t e = pos[j];
+                    const uint32_t kk = pr - (e & 0x7FFFFFFu);
                     const float inc = (t0 + dt) - t0;  // the run's exact per-step increment
                     ts4[k] = (float)((double)t0 + (double)kk * (double)inc);
                     te4[k] = (float)((double)t0 + (double)(kk + 1) * (double)inc);
-                    ri4[k] = r0 + (m >> 24);
+                    ri4[k] = r0 + (e >> 27);
                     valid[k] = true;
                 }
                 if (vec && valid[0] && valid[1] && valid[2] && valid[3]) {

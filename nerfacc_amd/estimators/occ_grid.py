@@ -125,7 +125,9 @@ class OccGridEstimator(AbstractEstimator):
                     alphas = torch.empty((0,), device=t_starts.device)
                 assert alphas.shape == t_starts.shape, "alphas must have shape of (N,)! Got {}".format(alphas.shape)
                 vis, cnts = _visibility_native(seg, None, None, alphas, None, early_stop_eps, alpha_thre, True)
-            ray_indices, t_starts, t_ends = _compact(seg, vis, cnts, t_starts, t_ends)
+            compacted = _compact(seg, vis, cnts, t_starts, t_ends)
+            if compacted is not None:
+                ray_indices, t_starts, t_ends = compacted
         return ray_indices, t_starts, t_ends
 
     # ------------------------------------------------------------------ grid maintenance (torch)
@@ -209,19 +211,22 @@ class OccGridEstimator(AbstractEstimator):
 
 def _compact(seg: SegInfo, vis: Tensor, cnts: Tensor, t_starts: Tensor, t_ends: Tensor):
     """``x[masks]`` for the sampler's three arrays in one pass (ref :216-220), given the mask and
-    the per-ray visible counts.  One device->host read (the output size)."""
+    the per-ray visible counts.  One device->host read (the output size).  Returns None when no
+    sample is dropped (the caller keeps its arrays: same values as the boolean-index copy)."""
     dev = t_starts.device
     n = t_starts.numel()
     with torch.cuda.device(dev):
         total = torch.empty(1, dtype=torch.int64, device=dev)
         out_starts = _exclusive_cumsum(cnts, total)
         m = int(total.item())
+        if m == n:  # every sample is visible: x[masks] would be a copy of x
+            return None
         ri = torch.empty(m, dtype=torch.int64, device=dev)
         ts = torch.empty(m, dtype=torch.float32, device=dev)
         te = torch.empty(m, dtype=torch.float32, device=dev)
         if m > 0:
             B.call("nfa_compact_samples", B.ptr(vis), B.ptr(t_starts), B.ptr(t_ends), B.ptr(seg.packed_info),
-                   B.ptr(seg.tiles), B.ptr(out_starts), seg.n_rays, n, B.ptr(ri), B.ptr(ts), B.ptr(te), B.stream())
+                   B.ptr(seg.tiles), seg.n_tiles, B.ptr(out_starts), seg.n_rays, n, B.ptr(ri), B.ptr(ts), B.ptr(te), B.stream())
         packed = torch.stack([out_starts, cnts], dim=-1)
     info = tag_trusted(packed, m)
     tag_ray_indices(ri, seg.n_rays, info)

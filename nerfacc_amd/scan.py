@@ -30,7 +30,7 @@ def _packed_scan_raw(kind: int, reverse: bool, seg: SegInfo, inputs: Tensor, nor
         return out
     with torch.cuda.device(dev):
         if seg.contiguous and not normalize:
-            B.call("nfa_packed_scan", kind, int(reverse), B.ptr(seg.packed_info), B.ptr(seg.tiles), seg.n_rays,
+            B.call("nfa_packed_scan", kind, int(reverse), B.ptr(seg.packed_info), B.ptr(seg.tiles), seg.n_tiles, seg.n_rays,
                    inputs.numel(), B.ptr(inputs), B.ptr(out), B.stream())
         else:
             B.call("nfa_packed_scan_generic", kind, int(reverse), int(normalize), B.ptr(seg.packed_info),
@@ -75,7 +75,7 @@ class _PackedProd(torch.autograd.Function):
         if seg.contiguous:
             grad_inputs = torch.empty_like(grad_outputs)
             with torch.cuda.device(grad_outputs.device):
-                B.call("nfa_packed_prod_backward", kind, B.ptr(seg.packed_info), B.ptr(seg.tiles), seg.n_rays,
+                B.call("nfa_packed_prod_backward", kind, B.ptr(seg.packed_info), B.ptr(seg.tiles), seg.n_tiles, seg.n_rays,
                        inputs.numel(), B.ptr(inputs), B.ptr(outputs), B.ptr(grad_outputs), B.ptr(grad_inputs),
                        B.stream())
         else:  # the reference's composition, on the generic kernel

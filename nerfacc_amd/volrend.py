@@ -42,7 +42,7 @@ class _RenderFromDensity(torch.autograd.Function):
         if n:
             with torch.cuda.device(dev):
                 B.call("nfa_render_from_density_fwd", B.ptr(ts), B.ptr(te), B.ptr(sg), B.ptr(pf),
-                       B.ptr(seg.packed_info), B.ptr(seg.tiles), seg.n_rays, n, B.ptr(weights), B.ptr(trans),
+                       B.ptr(seg.packed_info), B.ptr(seg.tiles), seg.n_tiles, seg.n_rays, n, B.ptr(weights), B.ptr(trans),
                        B.ptr(alphas), B.stream())
         ctx.seg = seg
         ctx.want_weights = want_weights
@@ -70,7 +70,7 @@ class _RenderFromDensity(torch.autograd.Function):
         if n and (need_sg or need_x):
             with torch.cuda.device(sg.device):
                 B.call("nfa_render_from_density_bwd", B.ptr(ts), B.ptr(te), B.ptr(trans), B.ptr(alphas), B.ptr(g_w),
-                       B.ptr(g_t), B.ptr(g_a), B.ptr(seg.packed_info), B.ptr(seg.tiles), seg.n_rays, n,
+                       B.ptr(g_t), B.ptr(g_a), B.ptr(seg.packed_info), B.ptr(seg.tiles), seg.n_tiles, seg.n_rays, n,
                        B.ptr(g_sig), B.ptr(g_x), B.stream())
         g_ts = (-(g_x * sg)) if need_ts else None
         g_te = (g_x * sg) if need_te else None
@@ -89,7 +89,7 @@ class _RenderFromAlpha(torch.autograd.Function):
         trans = torch.empty_like(al)
         if n:
             with torch.cuda.device(dev):
-                B.call("nfa_render_from_alpha_fwd", B.ptr(al), B.ptr(pf), B.ptr(seg.packed_info), B.ptr(seg.tiles),
+                B.call("nfa_render_from_alpha_fwd", B.ptr(al), B.ptr(pf), B.ptr(seg.packed_info), B.ptr(seg.tiles), seg.n_tiles,
                        seg.n_rays, n, B.ptr(weights), B.ptr(trans), B.stream())
         ctx.seg, ctx.want_weights = seg, want_weights
         ctx.save_for_backward(al, trans)
@@ -113,7 +113,7 @@ class _RenderFromAlpha(torch.autograd.Function):
         if al.numel():
             with torch.cuda.device(al.device):
                 B.call("nfa_render_from_alpha_bwd", B.ptr(al), B.ptr(trans), B.ptr(g_w), B.ptr(g_t),
-                       B.ptr(seg.packed_info), B.ptr(seg.tiles), seg.n_rays, al.numel(), B.ptr(g_al), B.stream())
+                       B.ptr(seg.packed_info), B.ptr(seg.tiles), seg.n_tiles, seg.n_rays, al.numel(), B.ptr(g_al), B.stream())
         return g_al, None, None, None
 
 
@@ -128,7 +128,7 @@ class _Accumulate(torch.autograd.Function):
         out = torch.empty((seg.n_rays, D), dtype=torch.float32, device=dev)
         if seg.n_rays and D:
             with torch.cuda.device(dev):
-                B.call("nfa_accumulate_along_rays", B.ptr(w), B.ptr(v), D, B.ptr(seg.packed_info), B.ptr(seg.tiles),
+                B.call("nfa_accumulate_along_rays", B.ptr(w), B.ptr(v), D, B.ptr(seg.packed_info), B.ptr(seg.tiles), seg.n_tiles,
                        seg.n_rays, w.numel(), 0, B.ptr(out), B.stream())
         ctx.seg, ctx.D, ctx.has_values = seg, D, v is not None
         ctx.save_for_backward(w, v if v is not None else w.new_empty(0))
@@ -147,7 +147,7 @@ class _Accumulate(torch.autograd.Function):
         if w.numel() and (need_w or need_v):
             with torch.cuda.device(w.device):
                 B.call("nfa_accumulate_along_rays_bwd", B.ptr(w), B.ptr(v), ctx.D, B.ptr(g_out),
-                       B.ptr(seg.packed_info), B.ptr(seg.tiles), seg.n_rays, w.numel(), B.ptr(g_w), B.ptr(g_v),
+                       B.ptr(seg.packed_info), B.ptr(seg.tiles), seg.n_tiles, seg.n_rays, w.numel(), B.ptr(g_w), B.ptr(g_v),
                        B.stream())
         return g_w, g_v, None
 
@@ -166,7 +166,7 @@ class _RenderAccumulate(torch.autograd.Function):
         if R:
             with torch.cuda.device(dev):
                 B.call("nfa_render_accumulate_fwd", B.ptr(w), B.ptr(c), B.ptr(ts), B.ptr(te), B.ptr(seg.packed_info),
-                       B.ptr(seg.tiles), R, w.numel(), B.ptr(colors), B.ptr(opac), B.ptr(depth), B.stream())
+                       B.ptr(seg.tiles), seg.n_tiles, R, w.numel(), B.ptr(colors), B.ptr(opac), B.ptr(depth), B.stream())
         ctx.seg = seg
         ctx.save_for_backward(w, c, ts, te)
         return colors, opac, depth
@@ -182,7 +182,7 @@ class _RenderAccumulate(torch.autograd.Function):
         if w.numel() and (need_w or need_c):
             with torch.cuda.device(w.device):
                 B.call("nfa_render_accumulate_bwd", B.ptr(w), B.ptr(c), B.ptr(ts), B.ptr(te), B.ptr(_f32c(g_c)),
-                       B.ptr(_f32c(g_o)), B.ptr(_f32c(g_d)), B.ptr(seg.packed_info), B.ptr(seg.tiles), seg.n_rays,
+                       B.ptr(_f32c(g_o)), B.ptr(_f32c(g_d)), B.ptr(seg.packed_info), B.ptr(seg.tiles), seg.n_tiles, seg.n_rays,
                        w.numel(), B.ptr(g_w), B.ptr(g_rgb), B.stream())
         return g_w, g_rgb, None, None, None
 
@@ -347,7 +347,7 @@ def _visibility_native(seg: SegInfo, t_starts, t_ends, vals, prefix_trans, early
     cnts = torch.empty(seg.n_rays, dtype=torch.int64, device=dev) if want_counts else None
     with torch.cuda.device(dev):
         B.call("nfa_render_visibility", B.ptr(ts), B.ptr(te), B.ptr(v), B.ptr(pf), float(early_stop_eps),
-               float(alpha_thre), B.ptr(seg.packed_info), B.ptr(seg.tiles), seg.n_rays, n, B.ptr(vis), B.ptr(cnts),
+               float(alpha_thre), B.ptr(seg.packed_info), B.ptr(seg.tiles), seg.n_tiles, seg.n_rays, n, B.ptr(vis), B.ptr(cnts),
                B.stream())
     return (vis, cnts) if want_counts else vis
 
@@ -454,7 +454,7 @@ def accumulate_along_rays_(
             with torch.cuda.device(w.device):
                 if seg.sorted_indices:
                     B.call("nfa_accumulate_along_rays", B.ptr(w), B.ptr(v), D, B.ptr(seg.packed_info),
-                           B.ptr(seg.tiles), n_rays, w.numel(), 1, B.ptr(outputs), B.stream())
+                           B.ptr(seg.tiles), seg.n_tiles, n_rays, w.numel(), 1, B.ptr(outputs), B.stream())
                 else:
                     ri = ray_indices.to(torch.int64).contiguous()
                     B.call("nfa_accumulate_along_rays_atomic", B.ptr(w), B.ptr(v), D, B.ptr(ri), n_rays, w.numel(),

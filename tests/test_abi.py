@@ -16,7 +16,8 @@ def test_header_and_library_agree():
         assert hasattr(lib, name), f"{name} declared in nerfacc_hip.h but not exported"
     assert declared == set(B.EXPORTED_SYMBOLS), declared ^ set(B.EXPORTED_SYMBOLS)
     assert lib.nfa_version() >= 100
-    assert lib.nfa_seg_num_tiles(0) == 1 and lib.nfa_seg_num_tiles(4096) == 3
+    from nerfacc_amd._backend import seg_plan
+    assert seg_plan(0) == (1024, 1) and seg_plan(32 * 1024 * 1024)[0] % 256 == 0
 
 
 def test_argument_errors_are_reported():
