@@ -107,9 +107,38 @@ def run_step(w, world_size: int = 1):
     loss = colors.sum()
     w["params"].grad = None
     loss.backward()
-    if world_size > 1:
-        torch.distributed.all_reduce(w["params"].grad)      # RCCL over xGMI: 8 bytes
+    allreduce_grads([w["params"]], world_size)              # RCCL over xGMI: 8 bytes
     return ri.numel(), loss
+
+
+# ----------------------------------------------------------------------------- distributed glue
+def init_distributed(backend: str, device=None):
+    """(world, rank, local_rank) from the torchrun environment; initialises the process group when
+    WORLD_SIZE > 1.  backend "nccl" is RCCL on ROCm; the CPU tests use "gloo"."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not torch.distributed.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        torch.distributed.init_process_group(backend=backend, **kw)
+    return world, rank, local_rank
+
+
+def allreduce_grads(params, world: int):
+    """Rays are independent, so ranks own disjoint ray batches and the only exchange is the SUM of
+    the (tiny) parameter gradient: d/dp sum_over_all_rays = sum over ranks of the local gradient."""
+    if world > 1:
+        for p in params:
+            torch.distributed.all_reduce(p.grad, op=torch.distributed.ReduceOp.SUM)
+
+
+def max_over_ranks(seconds: float, world: int, device="cpu") -> float:
+    if world == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return float(t.item())
 
 
 # ----------------------------------------------------------------------------- per-kernel timing (HIP events)
@@ -172,38 +201,40 @@ def algorithmic_bytes(R, M, Mv, res, G=1):
 
 
 # ----------------------------------------------------------------------------- CPU baseline (oracle, bounded sample)
-def cpu_baseline(w, sample_rays: int = 65536):
-    """The CPU restatement (oracle/) on every (R/sample)-th ray of the same batch: sampling +
-    rendering forward + analytic backward, timed on the host cores."""
+def cpu_baseline(w, min_seconds: float = 12.0, max_reps: int = 40):
+    """The CPU restatement (oracle/) on the SAME batch: sampling + rendering forward + analytic
+    backward of the step, repeated until about `min_seconds` of CPU work have been timed, on all host
+    cores (C/OpenMP traversal and scans, numpy elementwise)."""
     from oracle import oracle as O
     O.build()
     o, d = w["rays_np"]
-    stride = max(1, o.shape[0] // sample_rays)
-    o, d = np.ascontiguousarray(o[::stride]), np.ascontiguousarray(d[::stride])
     b = w["binaries_np"]
     aabb = np.array([[-1, -1, -1, 1, 1, 1]], np.float32)
 
     def sig(ts, te, ri):
         return (4.0 * (0.5 + 0.5 * np.sin(20.0 * (ts + te)))).astype(np.float32)
 
-    t0 = time.perf_counter()
-    ri, ts, te = O.occgrid_sampling(o, d, b, aabb, sigma_fn=sig, render_step_size=w["step"], early_stop_eps=1e-4,
-                                    alpha_thre=0.0, occs_mean=float(b.mean()))
     n = o.shape[0]
-    pi = O.pack_info(ri, n)
-    s = sig(ts, te, ri)
-    wts, tr, al = O.render_weight_from_density(ts, te, s, pi)
-    rgb = np.repeat(ts[:, None], 3, 1)
-    colors = O.accumulate_along_rays(wts, rgb, ri, n)
-    # backward of colors.sum(): g_w = sum_c rgb, then the reverse scan (vectorised restatement)
-    gw = rgb.sum(-1)
-    q = gw * wts
-    suffix = O.packed_scan("exclusive_sum", q, pi, backward=True)
-    gsig = (te - ts) * (gw * tr * (1 - al) - suffix)
-    dt = time.perf_counter() - t0
-    del colors, gsig
-    return dict(value=n / dt, unit="rays/s", cores=O.max_threads(), kind="port",
-                sample=f"{n} rays (every {stride}th ray of the batch), {ri.size} samples, {dt:.2f} s, "
+    total, reps, samples = 0.0, 0, 0
+    while total < min_seconds and reps < max_reps:
+        t0 = time.perf_counter()
+        ri, ts, te = O.occgrid_sampling(o, d, b, aabb, sigma_fn=sig, render_step_size=w["step"], early_stop_eps=1e-4,
+                                        alpha_thre=0.0, occs_mean=float(b.mean()))
+        pi = O.pack_info(ri, n)
+        s = sig(ts, te, ri)
+        wts, tr, al = O.render_weight_from_density(ts, te, s, pi)
+        rgb = np.repeat(ts[:, None], 3, 1)
+        colors = O.accumulate_along_rays(wts, rgb, ri, n)
+        # backward of colors.sum(): g_w = sum_c rgb, then the reverse scan (vectorised restatement)
+        gw = rgb.sum(-1)
+        suffix = O.packed_scan("exclusive_sum", gw * wts, pi, backward=True)
+        gsig = (te - ts) * (gw * tr * (1 - al) - suffix)
+        total += time.perf_counter() - t0
+        reps += 1
+        samples = int(ri.size)
+        del colors, gsig
+    return dict(value=n * reps / total, unit="rays/s", cores=O.max_threads(), kind="port",
+                sample=f"{reps} passes over the full {n}-ray batch ({samples} samples each), {total:.1f} s of CPU work, "
                        f"C/OpenMP traversal + scans, numpy elementwise")
 
 
@@ -221,16 +252,12 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group(backend="nccl", device_id=dev)
+    world, rank, local_rank = init_distributed("nccl", dev)
     assert world == max(1, args.gpus) or world == 1, "launch with torchrun --nproc-per-node == --gpus"
 
     w = make_workload(dev, args.rays, args.res, args.grid, args.ray_variant, rank)
@@ -255,10 +282,7 @@ def main():
     dt = time.perf_counter() - t0
     if timer is not None:
         ksum = timer.summary(args.steps); timer.uninstall()
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt, world, dev)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -289,12 +313,64 @@ def main():
                     entry["algorithmic_bytes_per_launch"] = per_launch
                     entry["achieved_GBps"] = per_launch / (v["ms_per_launch"] * 1e-3) / 1e9
                 kernels[k] = entry
-            dom = max((k for k in kernels if k in ab), key=lambda k: kernels[k]["ms_per_step"])
-            a = kernels[dom]["achieved_GBps"]
+            # Op-level view: one logical op of the reference API may be several launches here.
+            groups = {
+                "traverse_grids (nfa_traverse_runs + nfa_expand_runs [+ nfa_traverse_grids fill of overflow rays])":
+                    ["nfa_traverse_runs", "nfa_expand_runs", "nfa_traverse_grids[mode=0]", "nfa_traverse_grids[mode=1]"],
+                "render_weight_from_density fwd": ["nfa_render_from_density_fwd"],
+                "render_weight_from_density bwd": ["nfa_render_from_density_bwd"],
+                "accumulate_along_rays x3 fwd": ["nfa_render_accumulate_fwd"],
+                "accumulate_along_rays x3 bwd": ["nfa_render_accumulate_bwd"],
+                "render_visibility (+count)": ["nfa_render_visibility"],
+                "sample compaction": ["nfa_compact_samples"],
+            }
+            trav_bytes = args.rays * (24 + 8) + args.res ** 3 + M * 16 + args.rays * 16   # B_trav, SURVEY 8(d)
+            ops = {}
+            for name, ks in groups.items():
+                ks = [k for k in ks if k in kernels]
+                if not ks:
+                    continue
+                ms = sum(kernels[k]["ms_per_step"] for k in ks)
+                nbytes = trav_bytes if name.startswith("traverse_grids") else sum(ab[k] for k in ks)
+                ops[name] = {"ms_per_step": ms, "launches": [k for k in ks], "algorithmic_bytes": nbytes,
+                             "achieved_GBps": nbytes / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+            # HBM traffic from the PMC passes committed under profiles/ (collected with
+            # scripts/collect_profiles.sh in separate rocprofv3 --pmc runs; 2 x FETCH_SIZE + WRITE_SIZE)
+            traffic = {}
+            try:
+                prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_hbm_traffic.json"))[-1]
+                pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
+                sym = {"nfa_traverse_runs": "runs_kernel", "nfa_expand_runs": "expand_runs_kernel",
+                       "nfa_render_from_density_fwd": "DensityFwdOp", "nfa_render_from_density_bwd": "DensityBwdOp",
+                       "nfa_render_accumulate_fwd": "RenderAccumOp", "nfa_render_accumulate_bwd": "RenderAccumBwdOp",
+                       "nfa_render_visibility": ("VisibilityOp", "MaskCountOp"), "nfa_compact_samples": "CompactOp"}
+                for name, o in ops.items():
+                    tot, ok = 0.0, True
+                    for k in o["launches"]:
+                        pats = sym.get(k)
+                        if pats is None:
+                            continue
+                        for pat in ((pats,) if isinstance(pats, str) else pats):
+                            hit = [v for kk, v in pmc.items() if pat + "<" in kk or kk.endswith(pat)]
+                            ok = ok and bool(hit)
+                            tot += sum(h["hbm_bytes_per_launch"] for h in hit[:1])
+                    traffic[name] = tot if ok and tot > 0 else None
+                    o["hbm_traffic_bytes"] = traffic[name]
+                    o["hbm_traffic_source"] = "profiles/" + prof
+            except Exception:
+                pass
+            dom = max(ops, key=lambda k: ops[k]["ms_per_step"])
+            a = ops[dom]["achieved_GBps"]
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": a / HBM_PEAK_GBPS, "traffic": None,
-                               "ms_per_launch": kernels[dom]["ms_per_launch"],
-                               "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"]}
+                               "frac": a / HBM_PEAK_GBPS, "traffic": traffic.get(dom),
+                               "ms_per_launch": ops[dom]["ms_per_step"],
+                               "algorithmic_bytes_per_launch": ops[dom]["algorithmic_bytes"]}
+            out["ops"] = ops
+            # SURVEY 8(d) headline: (B_trav + B_rw_f + B_rw_b) / (t_trav + t_rw_f + t_rw_b)
+            hk = [k for k in ops if k.startswith(("traverse_grids", "render_weight_from_density"))]
+            hb = sum(ops[k]["algorithmic_bytes"] for k in hk); ht = sum(ops[k]["ms_per_step"] for k in hk)
+            out["headline_roofline"] = {"ops": hk, "achieved": hb / (ht * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                        "frac": hb / (ht * 1e-3) / 1e9 / HBM_PEAK_GBPS, "target_frac": 0.60}
             out["kernels"] = kernels
             out["config"]["samples_before_compaction"] = M
             native_ms = sum(v["ms_per_step"] for v in ksum.values())

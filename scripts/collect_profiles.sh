@@ -1,0 +1,16 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): kernel-trace stats + HBM byte counters for the bench command.
+# Counters go in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one TCC pass; no --pmc together
+# with trace domains other than kernel-trace).  Outputs land in gpurun_out/<tag>_*; summarise with
+# scripts/summarize_profiles.py, which writes the files committed under profiles/.
+set -e
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- $CMD > $OUT/${TAG}_trace.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -- $CMD > $OUT/${TAG}_fetch.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -- $CMD > $OUT/${TAG}_write.log 2>&1
+echo "profiles collected for $TAG"

@@ -1,0 +1,68 @@
+"""CPU, world_size 2, gloo: the multi-GPU path of bench.py.  Rays are independent, ranks own
+disjoint batches and the only exchange is the SUM all-reduce of the parameter gradient, plus the
+MAX-over-ranks of the timed region.  The per-rank "step" here is the CPU oracle (test
+infrastructure) on a small ray batch; the check is that the all-reduced gradient equals the
+gradient of the union batch computed in one process."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+R_PER_RANK = 256
+
+
+def _local_grad(rank):
+    """d/d(sigma scale) of sum of opacities over this rank's rays (analytic, via the oracle)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import oracle as O
+    o, d = bench.make_rays(R_PER_RANK, "random", rank=rank)
+    b = bench.make_grid(32, "iid10")
+    aabb = np.array([[-1, -1, -1, 1, 1, 1]], np.float32)
+    ri, ts, te = O.occgrid_sampling(o, d, b, aabb, render_step_size=0.02)
+    pi = O.pack_info(ri, R_PER_RANK)
+    sig = (4.0 * (0.5 + 0.5 * np.sin(20.0 * (ts + te)))).astype(np.float32)
+    # loss = sum_k w_k ; dL/ds at s = 1 for sigma = s * sig
+    g_sigma = O.render_weight_from_density_backward(ts, te, sig, pi, np.ones_like(sig))
+    return float((g_sigma * sig).sum()), int(ri.size)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import bench
+    w, r, lr = bench.init_distributed("gloo")
+    assert (w, r) == (world, rank)
+    g, n = _local_grad(rank)
+    p = torch.nn.Parameter(torch.zeros(2, dtype=torch.float64))
+    p.grad = torch.tensor([g, float(n)], dtype=torch.float64)
+    bench.allreduce_grads([p], w)
+    torch.distributed.barrier()
+    dt = bench.max_over_ranks(0.1 * (rank + 1), w)
+    q.put((rank, p.grad.tolist(), dt))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_matches_union_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g0, n0 = _local_grad(0)
+    g1, n1 = _local_grad(1)
+    for rank, grad, dt in res:
+        assert abs(grad[0] - (g0 + g1)) < 1e-9 * max(1.0, abs(g0 + g1))
+        assert grad[1] == n0 + n1
+        assert abs(dt - 0.2) < 1e-12          # MAX over ranks of the per-rank times
+    assert n0 > 0 and n1 > 0 and abs(g0 - g1) > 0  # the two shards really differ

@@ -603,3 +603,44 @@ def test_full_size_properties(dev):
     ref = torch.zeros((n, 3), device=dev).index_add_(0, ri, wts[:, None] * v)
     assert torch.allclose(a1, ref, atol=2e-5)
     del last
+
+
+# ----------------------------------------------------------------------------- the reference's `_C` surface
+def test_cuda_compat_module_matches_pybind_surface(dev, oracle):
+    """nerfacc_amd.cuda_compat exposes the names/signatures of nerfacc/cuda/csrc/nerfacc.cpp:100-129; the calls
+    below are written the way the reference's Python layer makes them (scan.py:197, grid.py:165, pdf.py:59,125)."""
+    import nerfacc_amd.cuda_compat as _C
+    g = load_golden("ragged_packed")
+    starts, cnts = T(g["packed_info"][:, 0].copy(), dev), T(g["packed_info"][:, 1].copy(), dev)
+    x, xp, gg = T(g["x"], dev), T(g["xp"], dev), T(g["g"], dev)
+    assert_close(_C.inclusive_sum(starts, cnts, x, False, False), g["inclusive_sum"], atol=1e-5)
+    assert_close(_C.exclusive_sum(starts, cnts, gg, False, True), g["exclusive_sum_grad"], atol=2e-5, rtol=1e-4)
+    out = _C.exclusive_prod_forward(starts, cnts, xp)
+    assert_close(out, g["exclusive_prod"], atol=1e-6)
+    assert_close(_C.exclusive_prod_backward(starts, cnts, xp, out, gg), g["exclusive_prod_grad"], atol=2e-5, rtol=1e-4)
+    out = _C.inclusive_prod_forward(starts, cnts, xp)
+    assert_close(_C.inclusive_prod_backward(starts, cnts, xp, out, gg), g["inclusive_prod_grad"], atol=2e-5, rtol=1e-4)
+    with pytest.raises(RuntimeError):
+        _C.inclusive_sum(starts.cpu(), cnts, x, False, False)
+    # grid: the 17-argument traverse_grids of grid.py:165-185
+    gt = load_golden("traversal")
+    binaries = np.unpackbits(gt["a_binaries"]).astype(bool).reshape(4, 32, 32, 32)
+    o, d, ab = gt["a_rays_o"][:8], gt["a_rays_d"][:8], gt["a_aabbs"]
+    to, td, tab, tb = T(o, dev), T(d, dev), T(ab, dev), T(binaries, dev)
+    t_mins, t_maxs, hits = _C.ray_aabb_intersect(to, td, tab, -float("inf"), float("inf"), float("inf"))
+    t_sorted, t_indices = torch.sort(torch.cat([t_mins, t_maxs], -1), -1)
+    iv, sm, term = _C.traverse_grids(to, td, torch.ones(8, dtype=torch.bool, device=dev), tb, tab, t_sorted, t_indices, hits,
+                                     torch.zeros(8, device=dev), torch.full((8,), float("inf"), device=dev), 1e-3, 0.0,
+                                     True, True, True, -1, False)
+    assert (iv.vals.cpu().numpy() == gt["a8_iv_vals"]).all() and (iv.is_left.cpu().numpy() == gt["a8_iv_left"]).all()
+    assert (torch.stack([sm.chunk_starts, sm.chunk_cnts], -1).cpu().numpy() == gt["a8_sm_packed"]).all()
+    assert (term.cpu().numpy() == gt["a8_term"]).all() and sm.is_left is None and iv.is_valid is None
+    # pdf
+    gp = load_golden("pdf")
+    spec = _C.RaySegmentsSpec(); spec.vals = T(gp["b_vals"], dev)
+    ivs, sms = _C.importance_sampling(spec, T(gp["b_cdfs"], dev), int(gp["b_S"]), False)
+    assert_close(ivs.vals, gp["b_oracle_edges"], atol=1e-6); assert_close(sms.vals, gp["b_oracle_centres"], atol=1e-6)
+    q, k = _C.RaySegmentsSpec(), _C.RaySegmentsSpec()
+    q.vals, k.vals = T(gp["loss_q_vals"], dev), T(gp["loss_k_vals"], dev)
+    il, ir = _C.searchsorted(q, k)
+    assert (il.cpu().numpy() == gp["loss_ids_left"]).all() and (ir.cpu().numpy() == gp["loss_ids_right"]).all()
