@@ -6,6 +6,8 @@ cross-compiles without a GPU, and travels to the GPU box as a file.
 """
 from __future__ import annotations
 
+import fcntl
+import hashlib
 import os
 import shutil
 import subprocess
@@ -37,15 +39,30 @@ def _deps() -> list[str]:
     return deps
 
 
+HASH_PATH = LIB_PATH + ".hash"
+
+
+def _source_hash() -> str:
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
+    for d in sorted(_deps()):
+        if os.path.exists(d):
+            h.update(os.path.basename(d).encode())
+            h.update(open(d, "rb").read())
+    return h.hexdigest()
+
+
 def is_stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+    """The library is current iff it was built from exactly these sources and flags (content hash,
+    not mtimes: the tree is copied to the GPU box and mtimes do not survive reliably)."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(HASH_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in _deps())
+    return open(HASH_PATH).read().strip() != _source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile (if stale) and return the path of libnerfacc_hip.so."""
+    """Compile (if stale) and return the path of libnerfacc_hip.so.  Safe to call from several
+    processes at once (one rank per GPU): an exclusive lock serialises the build."""
     if not force and not is_stale():
         return LIB_PATH
     cc = hipcc()
@@ -53,20 +70,33 @@ def build(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError("nerfacc_amd: hipcc not found; cannot build libnerfacc_hip.so")
     obj_dir = os.path.join(CSRC, "_obj")
     os.makedirs(obj_dir, exist_ok=True)
+    with open(os.path.join(obj_dir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():  # another process built it while we waited
+                return LIB_PATH
+            tag = str(os.getpid())
 
-    def compile_one(src: str) -> str:
-        obj = os.path.join(obj_dir, src + ".o")
-        cmd = [cc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
-        return obj
+            def compile_one(src: str) -> str:
+                obj = os.path.join(obj_dir, f"{src}.{tag}.o")
+                cmd = [cc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.run(cmd, check=True)
+                return obj
 
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
-    tmp = LIB_PATH + ".tmp"
-    subprocess.run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", tmp], check=True)
-    os.replace(tmp, LIB_PATH)
+            with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+                objs = list(ex.map(compile_one, SOURCES))
+            tmp = f"{LIB_PATH}.{tag}.tmp"
+            subprocess.run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", tmp], check=True)
+            os.replace(tmp, LIB_PATH)
+            with open(HASH_PATH + "." + tag, "w") as f:
+                f.write(_source_hash())
+            os.replace(HASH_PATH + "." + tag, HASH_PATH)
+            for o in objs:
+                os.remove(o)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
