@@ -226,25 +226,44 @@ def _get_bricks(binaries: Tensor):
 
 
 @torch.no_grad()
-def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size, cone_angle):
+def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size, cone_angle,
+                      rays_mask=None, traverse_steps_limit=None, t_sorted=None, t_indices=None, hits=None,
+                      return_terminate=False):
     """Sampler fast path: (ray_indices, t_starts, t_ends, packed_info) straight from the traversal.
 
     Same values as ``intervals.vals[is_left]``, ``intervals.vals[is_right]``,
     ``samples.ray_indices``, ``samples.packed_info`` of :func:`traverse_grids`
     (ref: estimators/occ_grid.py:164-177) without materialising edges and masks and without
     the two boolean-index syncs.  Constant-step marching (``cone_angle == 0``) takes the
-    run-length path: one DDA walk per ray + a fully parallel, coalesced expansion."""
-    (dev, rays_o, rays_d, binaries, aabbs, near_planes, far_planes, _, t_sorted, t_indices,
-     hits) = _prepare(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, None, None, None, None,
+    run-length path: one DDA walk per ray + a fully parallel, coalesced expansion.
+
+    With ``rays_mask`` / ``traverse_steps_limit`` this is the compacted equivalent of the reference's
+    ``traverse_grids(over_allocate=True, rays_mask=..., traverse_steps_limit=...)`` followed by the
+    ``is_left`` / ``is_right`` / ``is_valid`` boolean indexing of examples/utils.py:342-365: masked
+    rays get no samples, every other ray at most ``traverse_steps_limit``.
+    """
+    limit = -1 if traverse_steps_limit is None else int(traverse_steps_limit)
+    use_runs = float(step_size) > 0.0 and float(cone_angle) == 0.0
+    if not use_runs and (rays_mask is not None or limit > 0):
+        # marching with a cone angle / per-cell mode: the reference's route (over-allocate + compaction)
+        iv, sm, term = traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size, cone_angle,
+                                      limit if limit > 0 else None, limit > 0, rays_mask, t_sorted, t_indices, hits)
+        valid = sm.is_valid if sm.is_valid is not None else torch.ones_like(sm.ray_indices, dtype=torch.bool)
+        out = (sm.ray_indices[valid], iv.vals[iv.is_left], iv.vals[iv.is_right], sm.packed_info)
+        return (*out, term) if return_terminate else out
+    (dev, rays_o, rays_d, binaries, aabbs, near_planes, far_planes, rays_mask, t_sorted, t_indices,
+     hits) = _prepare(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, rays_mask, t_sorted, t_indices, hits,
                       allow_fused=True)
     n_rays = rays_o.shape[0]
-    use_runs = float(step_size) > 0.0 and float(cone_angle) == 0.0
     with torch.cuda.device(dev):
         sm_cnts = torch.empty(n_rays, dtype=torch.int64, device=dev)
         meta = torch.zeros(2, dtype=torch.int64, device=dev)  # [total samples, rays with too many runs]
-        a = _traverse_args(rays_o, rays_d, None, binaries, aabbs, t_sorted, t_indices, hits, near_planes, far_planes,
-                           step_size, cone_angle, -1, 0)
+        terminate = torch.empty(n_rays, dtype=torch.float32, device=dev) if return_terminate else None
+        masked = rays_mask is not None or limit > 0
+        a = _traverse_args(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indices, hits, near_planes, far_planes,
+                           step_size, cone_angle, limit, 2 if (use_runs and masked) else 0)
         a.sm_cnts = B.ptr(sm_cnts)
+        a.terminate_planes = B.ptr(terminate)
         if use_runs:
             bricks, coarse = _get_bricks(binaries)
             run_cnts = torch.empty(n_rays, dtype=torch.int32, device=dev)
@@ -264,15 +283,17 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
                        B.ptr(sm_starts), B.ptr(sm_cnts), B.ptr(t_starts), B.ptr(t_ends), B.ptr(ray_indices), B.stream())
             if not use_runs or n_overflow > 0:
                 a.mode = 1
+                a.terminate_planes = None
                 a.sm_starts = B.ptr(sm_starts)
                 a.sm_t_starts, a.sm_t_ends, a.sm_ray_indices = B.ptr(t_starts), B.ptr(t_ends), B.ptr(ray_indices)
-                if use_runs:  # only the rays whose runs did not fit
+                if use_runs:  # only the rays whose runs did not fit (their counts already honour mask and limit)
                     a.ray_filter, a.ray_filter_min = B.ptr(run_cnts), MAX_RUNS
                 _launch(a)
         packed_info = torch.stack([sm_starts, sm_cnts], dim=-1)
     info = tag_trusted(packed_info, n_sm)
     tag_ray_indices(ray_indices, n_rays, info)
-    return ray_indices, t_starts, t_ends, packed_info
+    out = (ray_indices, t_starts, t_ends, packed_info)
+    return (*out, terminate) if return_terminate else out
 
 
 def _enlarge_aabb(aabb: Tensor, factor: float) -> Tensor:

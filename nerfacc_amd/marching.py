@@ -1,0 +1,104 @@
+"""Test-mode (inference) marching with ray-level early termination.
+
+Counterpart of the reference's caller harness ``render_image_with_occgrid_test``
+(ref: examples/utils.py:252-425).  Same iteration schedule, same per-iteration
+semantics and the same final blend:
+
+    n_samples = max(min(num_rays // n_alive, 64), min_samples)          (:338)
+    traverse the alive rays for at most n_samples steps, resuming at the previous
+        termination planes                                                   (:342-360, :407)
+    weights with prefix_trans = 1 - opacity[ray_indices]                    (:370-377)
+    in-place accumulation of rgb / opacity / depth                          (:388-405)
+    alive = (opacity <= 1 - early_stop_eps) & (samples taken == n_samples)   (:409-414)
+
+The reference implements one iteration as an over-allocated ``traverse_grids`` (dead rays still
+occupy a thread and n_alive * n_samples * 3 zero-filled slots), three boolean-index compactions
+(three device syncs) and a ``pack_info``.  Here the ray mask and the step limit are honoured inside
+the run-length traversal, which emits the compact ``(ray_indices, t_starts, t_ends, packed_info)``
+directly: two host reads per iteration (number of alive rays, number of samples).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from .estimators.occ_grid import OccGridEstimator
+from .grid import _traverse_samples, ray_aabb_intersect
+from .volrend import accumulate_along_rays_, render_weight_from_density
+
+
+@torch.no_grad()
+def render_rays_test_mode(
+    max_samples: int,
+    rgb_sigma_fn: Callable,
+    estimator: OccGridEstimator,
+    rays_o: Tensor,  # [n_rays, 3]
+    rays_d: Tensor,  # [n_rays, 3]
+    near_plane: float = 0.0,
+    far_plane: float = 1e10,
+    render_step_size: float = 1e-3,
+    render_bkgd: Optional[Tensor] = None,
+    cone_angle: float = 0.0,
+    alpha_thre: float = 0.0,
+    early_stop_eps: float = 1e-4,
+) -> Tuple[Tensor, Tensor, Tensor, int]:
+    """Render rays by iterative marching; returns ``(rgb (n,3), opacity (n,1), depth (n,1), total_samples)``.
+
+    ``rgb_sigma_fn(t_starts, t_ends, ray_indices) -> (rgbs (N,3), sigmas (N,))`` as in
+    :func:`nerfacc_amd.rendering`.
+    """
+    num_rays = rays_o.shape[0]
+    device = rays_o.device
+    opacity = torch.zeros(num_rays, 1, device=device)
+    depth = torch.zeros(num_rays, 1, device=device)
+    rgb = torch.zeros(num_rays, 3, device=device)
+    ray_mask = torch.ones(num_rays, device=device, dtype=torch.bool)
+    min_samples = 1 if cone_angle == 0 else 4  # 1 for synthetic scenes, 4 for real scenes (:312)
+    iter_samples = total_samples = 0
+    near_planes = torch.full_like(rays_o[..., 0], fill_value=near_plane)
+    far_planes = torch.full_like(rays_o[..., 0], fill_value=far_plane)
+
+    n_grids = estimator.binaries.size(0)
+    t_sorted = t_indices = hits = None
+    if n_grids > 1:  # intersections are computed once (:317-327); one grid is intersected in-kernel
+        t_mins, t_maxs, hits = ray_aabb_intersect(rays_o, rays_d, estimator.aabbs)
+        t_sorted, t_indices = torch.sort(torch.cat([t_mins, t_maxs], -1), -1)
+    opc_thre = 1 - early_stop_eps
+    rgbs = None
+
+    while iter_samples < max_samples:
+        n_alive = int(ray_mask.sum().item())
+        if n_alive == 0:
+            break
+        n_samples = max(min(num_rays // n_alive, 64), min_samples)
+        iter_samples += n_samples
+
+        ray_indices, t_starts, t_ends, packed_info, termination_planes = _traverse_samples(
+            rays_o, rays_d, estimator.binaries, estimator.aabbs, near_planes, far_planes, render_step_size,
+            cone_angle, rays_mask=ray_mask, traverse_steps_limit=n_samples, t_sorted=t_sorted, t_indices=t_indices,
+            hits=hits, return_terminate=True)
+
+        if ray_indices.numel() > 0:
+            rgbs, sigmas = rgb_sigma_fn(t_starts, t_ends, ray_indices)
+            weights, _, alphas = render_weight_from_density(
+                t_starts, t_ends, sigmas, packed_info=packed_info, n_rays=num_rays,
+                prefix_trans=1 - opacity[ray_indices].squeeze(-1))
+            if alpha_thre > 0:
+                vis_mask = alphas >= alpha_thre
+                ray_indices, rgbs, weights, t_starts, t_ends = (
+                    ray_indices[vis_mask], rgbs[vis_mask], weights[vis_mask], t_starts[vis_mask], t_ends[vis_mask])
+            accumulate_along_rays_(weights, values=rgbs, ray_indices=ray_indices, outputs=rgb)
+            accumulate_along_rays_(weights, values=None, ray_indices=ray_indices, outputs=opacity)
+            accumulate_along_rays_(weights, values=(t_starts + t_ends)[..., None] / 2.0, ray_indices=ray_indices,
+                                   outputs=depth)
+        near_planes = termination_planes
+        ray_mask = torch.logical_and(opacity.view(-1) <= opc_thre, packed_info[:, 1] == n_samples)
+        total_samples += ray_indices.shape[0]
+
+    if render_bkgd is not None:
+        rgb = rgb + render_bkgd * (1.0 - opacity)
+    eps = torch.finfo(rgb.dtype).eps
+    depth = depth / opacity.clamp_min(eps)
+    return rgb, opacity, depth, total_samples

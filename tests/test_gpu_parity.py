@@ -644,3 +644,84 @@ def test_cuda_compat_module_matches_pybind_surface(dev, oracle):
     q.vals, k.vals = T(gp["loss_q_vals"], dev), T(gp["loss_k_vals"], dev)
     il, ir = _C.searchsorted(q, k)
     assert (il.cpu().numpy() == gp["loss_ids_left"]).all() and (ir.cpu().numpy() == gp["loss_ids_right"]).all()
+
+
+# ----------------------------------------------------------------------------- test-mode marching loop
+def _oracle_test_mode_loop(O, max_samples, rgb_sigma, rays_o, rays_d, binaries, aabbs, near_plane, far_plane, step,
+                           bkgd, cone_angle, alpha_thre, early_stop_eps):
+    """numpy restatement of examples/utils.py:252-425 on the oracle's traverse_grids(over_allocate=True)."""
+    n = rays_o.shape[0]
+    opacity = np.zeros((n, 1), np.float32); depth = np.zeros((n, 1), np.float32); rgb = np.zeros((n, 3), np.float32)
+    mask = np.ones(n, bool)
+    min_samples = 1 if cone_angle == 0 else 4
+    near = np.full(n, near_plane, np.float32); far = np.full(n, far_plane, np.float32)
+    t_mins, t_maxs, hits = O.ray_aabb_intersect(rays_o, rays_d, aabbs)
+    t_sorted, t_indices = O.sort_intersections(t_mins, t_maxs)
+    it = total = 0
+    min_margin = np.inf
+    while it < max_samples:
+        n_alive = int(mask.sum())
+        if n_alive == 0:
+            break
+        ns = max(min(n // n_alive, 64), min_samples)
+        it += ns
+        iv, sm, term = O.traverse_grids(rays_o, rays_d, binaries, aabbs, near, far, step, cone_angle, ns, True, mask,
+                                        t_sorted, t_indices, hits)
+        ts, te = iv["vals"][iv["is_left"]], iv["vals"][iv["is_right"]]
+        ri = sm["ray_indices"][sm["is_valid"]]
+        pi = sm["packed_info"]
+        if len(ri):
+            rgbs, sig = rgb_sigma(ts, te, ri)
+            w, _, al = O.render_weight_from_density(ts, te, sig, O.pack_info(ri, n), prefix_trans=1 - opacity[ri, 0])
+            if alpha_thre > 0:
+                v = al >= alpha_thre
+                ri, rgbs, w, ts, te = ri[v], rgbs[v], w[v], ts[v], te[v]
+            np.add.at(rgb, ri, (w[:, None] * rgbs).astype(np.float32))
+            np.add.at(opacity, ri, w[:, None].astype(np.float32))
+            np.add.at(depth, ri, (w[:, None] * ((ts + te)[:, None] / np.float32(2.0))).astype(np.float32))
+        near = term
+        alive_op = opacity[:, 0] <= 1 - early_stop_eps
+        min_margin = min(min_margin, float(np.abs(opacity[mask, 0] - (1 - early_stop_eps)).min()))
+        mask = alive_op & (pi[:, 1] == ns)
+        total += len(ri)
+    rgb = rgb + bkgd * (1.0 - opacity)
+    depth = depth / np.maximum(opacity, np.finfo(np.float32).eps)
+    return rgb, opacity, depth, total, min_margin
+
+
+@pytest.mark.parametrize("levels,cone,alpha_thre", [(1, 0.0, 0.0), (2, 0.0, 0.02), (2, 0.004, 0.0)])
+def test_test_mode_marching_loop(dev, oracle, levels, cone, alpha_thre):
+    from nerfacc_amd.marching import render_rays_test_mode
+    rng = np.random.default_rng(17)
+    n, res, step = 1500, 48, 6e-3
+    o = (rng.random((n, 3)).astype(np.float32) - 0.5) * 3.0
+    d = rng.standard_normal((n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    b = rng.random((levels, res, res, res)) < 0.25
+    est = na.OccGridEstimator([-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=res, levels=levels).to(dev)
+    est.binaries = T(b, dev)
+    bk = np.array([0.2, 0.4, 0.6], np.float32)
+
+    def field_np(ts, te, ri):
+        tm = (ts + te) * np.float32(0.5)
+        sig = (np.float32(25.0) * (np.float32(0.5) + np.float32(0.5) * np.sin(np.float32(9.0) * tm))).astype(np.float32)
+        rgbs = np.stack([np.float32(0.5) + np.float32(0.5) * np.cos(tm), (ri % 7).astype(np.float32) / np.float32(7.0),
+                         np.full_like(tm, 0.3)], -1).astype(np.float32)
+        return rgbs, sig
+
+    def field_t(ts, te, ri):
+        tm = (ts + te) * 0.5
+        return (torch.stack([0.5 + 0.5 * torch.cos(tm), (ri % 7).float() / 7.0, torch.full_like(tm, 0.3)], -1),
+                25.0 * (0.5 + 0.5 * torch.sin(9.0 * tm)))
+
+    rgb, opa, dep, total = render_rays_test_mode(600, field_t, est, T(o, dev), T(d, dev), near_plane=0.05, far_plane=1e10,
+                                                 render_step_size=step, render_bkgd=T(bk, dev), cone_angle=cone,
+                                                 alpha_thre=alpha_thre, early_stop_eps=1e-3)
+    orgb, oopa, odep, ototal, margin = _oracle_test_mode_loop(oracle, 600, field_np, o, d, b, est.aabbs.cpu().numpy(), 0.05, 1e10,
+                                                              step, bk, cone, alpha_thre, 1e-3)
+    assert ototal > 10000
+    if margin > 1e-5:  # no ray sits on the early-termination threshold: the schedules are identical
+        assert total == ototal
+    assert abs(total - ototal) <= 64 * 4
+    assert_close(opa, oopa, atol=2e-5, rtol=1e-5); assert_close(rgb, orgb, atol=2e-5, rtol=1e-5)
+    assert_close(dep, odep, atol=1e-4, rtol=1e-4)
+    assert (opa.max() <= 1.0 + 1e-5) and (opa.min() >= 0)
