@@ -197,6 +197,10 @@ def algorithmic_bytes(R, M, Mv, res, G=1):
         "nfa_render_from_density_bwd": Mv * (4 + 12 + 4) + R * 16,
         "nfa_render_accumulate_fwd": Mv * (4 + 12 + 8) + R * (16 + 20),
         "nfa_render_accumulate_bwd": Mv * (4 + 12 + 8 + 4 + 12) + R * 36,
+        # rendering() as one pass each way: (ts, te, sigma, rgb) -> (w, T, alpha) + per-ray (colour, opacity, depth);
+        # backward (ts, te, rgb, T, alpha) + per-ray gradients -> (g_sigma, g_rgb)
+        "nfa_render_fused_fwd": Mv * (12 + 12 + 12) + R * (16 + 20),
+        "nfa_render_fused_bwd": Mv * (8 + 12 + 8 + 4 + 12) + R * (16 + 20),
     }
 
 
@@ -317,6 +321,8 @@ def main():
             groups = {
                 "traverse_grids (nfa_traverse_runs + nfa_expand_runs [+ nfa_traverse_grids fill of overflow rays])":
                     ["nfa_traverse_runs", "nfa_expand_runs", "nfa_traverse_grids[mode=0]", "nfa_traverse_grids[mode=1]"],
+                "rendering fwd (render_weight_from_density + 3 accumulations, one pass)": ["nfa_render_fused_fwd"],
+                "rendering bwd (3 accumulations + render_weight_from_density, one pass)": ["nfa_render_fused_bwd"],
                 "render_weight_from_density fwd": ["nfa_render_from_density_fwd"],
                 "render_weight_from_density bwd": ["nfa_render_from_density_bwd"],
                 "accumulate_along_rays x3 fwd": ["nfa_render_accumulate_fwd"],
@@ -343,7 +349,8 @@ def main():
                 sym = {"nfa_traverse_runs": "runs_kernel", "nfa_expand_runs": "expand_runs_kernel",
                        "nfa_render_from_density_fwd": "DensityFwdOp", "nfa_render_from_density_bwd": "DensityBwdOp",
                        "nfa_render_accumulate_fwd": "RenderAccumOp", "nfa_render_accumulate_bwd": "RenderAccumBwdOp",
-                       "nfa_render_visibility": ("VisibilityOp", "MaskCountOp"), "nfa_compact_samples": "CompactOp"}
+                       "nfa_render_fused_fwd": "RenderFusedFwdOp", "nfa_render_fused_bwd": "RenderFusedBwdOp",
+                       "nfa_render_visibility": "VisibilityOp", "nfa_compact_samples": "CompactOp"}
                 for name, o in ops.items():
                     tot, ok = 0.0, True
                     for k in o["launches"]:
@@ -367,7 +374,7 @@ def main():
                                "algorithmic_bytes_per_launch": ops[dom]["algorithmic_bytes"]}
             out["ops"] = ops
             # SURVEY 8(d) headline: (B_trav + B_rw_f + B_rw_b) / (t_trav + t_rw_f + t_rw_b)
-            hk = [k for k in ops if k.startswith(("traverse_grids", "render_weight_from_density"))]
+            hk = [k for k in ops if k.startswith(("traverse_grids", "render_weight_from_density", "rendering "))]
             hb = sum(ops[k]["algorithmic_bytes"] for k in hk); ht = sum(ops[k]["ms_per_step"] for k in hk)
             out["headline_roofline"] = {"ops": hk, "achieved": hb / (ht * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                         "frac": hb / (ht * 1e-3) / 1e9 / HBM_PEAK_GBPS, "target_frac": 0.60}

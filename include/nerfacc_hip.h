@@ -228,6 +228,24 @@ int nfa_render_accumulate_bwd(const float *weights, const float *rgbs, const flo
                               int64_t n_rays, int64_t n_elems, float *g_weights, float *g_rgbs,
                               nfa_stream_t stream);
 
+/* `rendering` with a density callback in one pass (ref: volrend.py:109-156 = render_weight_from_density
+ * + three accumulate_along_rays): per-sample weights / trans / alphas (each may be NULL) and the per-ray
+ * colors[r,3], opacities[r], un-normalised depths[r].  Results are bit-identical to
+ * nfa_render_from_density_fwd followed by nfa_render_accumulate_fwd. */
+int nfa_render_fused_fwd(const float *t_starts, const float *t_ends, const float *sigmas, const float *rgbs,
+                         const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles, int64_t n_rays,
+                         int64_t n_elems, float *weights, float *trans, float *alphas, float *colors,
+                         float *opacities, float *depths, nfa_stream_t stream);
+/* Its backward in one reverse pass.  g_colors[r,3] / g_opacities[r] / g_depths[r]: gradients of the per-ray
+ * outputs (NULL = zero); g_weights / g_trans / g_alphas: gradients arriving at the per-sample outputs
+ * (NULL = zero).  Writes grad_sigmas[n] and/or grad_rgbs[n,3]. */
+int nfa_render_fused_bwd(const float *t_starts, const float *t_ends, const float *rgbs, const float *trans,
+                         const float *alphas, const float *g_colors, const float *g_opacities,
+                         const float *g_depths, const float *g_weights, const float *g_trans,
+                         const float *g_alphas, const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles,
+                         int64_t n_rays, int64_t n_elems, float *grad_sigmas, float *grad_rgbs,
+                         nfa_stream_t stream);
+
 /* ------------------------------------------------------------------ pdf */
 
 /* ref: cuda/csrc/pdf.cu:359-421 (int overload): S samples + S+1 edges per ray, batched outputs.

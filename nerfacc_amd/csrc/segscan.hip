@@ -107,6 +107,97 @@ __device__ __forceinline__ void store4(float *__restrict__ p, int64_t p0, const 
 }
 
 // ------------------------------------------------------------------------------------------
+// Wave-level segmented scan primitives (256 elements per step: 4 per lane in scan order k).
+struct StepHeads {
+    int32_t lh[4];        // most recent head ray id over the lane's elements 0..k (-1: none)
+    uint32_t acc;         // bit s: at Hillis-Steele step s (offset 2^s) this lane still accumulates
+    bool open_prefix;     // no head in any earlier lane of this step: the carry of previous steps applies
+    int32_t ph;           // ray id in front of the lane's first element (carry folded in)
+    int32_t rid[4], prev_rid[4];
+    bool is_head[4];
+};
+
+template <int DIR>
+__device__ __forceinline__ void resolve_heads(const int32_t hj[4], const bool valid[4], int32_t carry_rid, StepHeads &hd)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = DIR > 0 ? k : 3 - k;
+        const int32_t h = valid[j] ? hj[j] : -1;
+        hd.is_head[k] = h >= 0;
+        hd.lh[k] = (k == 0 || h >= 0) ? h : hd.lh[k - 1 < 0 ? 0 : k - 1];  // most recent head (ids fall in reverse scans)
+    }
+    int32_t ah = hd.lh[3];
+    uint32_t acc = 0;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int off = 1 << s;
+        const int32_t uh = __shfl_up(ah, off, NFA_WAVE);
+        if (lane >= off) {
+            if (ah < 0) { acc |= 1u << s; ah = uh; }
+        }
+    }
+    hd.acc = acc;
+    int32_t ph = __shfl_up(ah, 1, NFA_WAVE);
+    if (lane == 0) ph = -1;
+    hd.open_prefix = ph < 0;
+    if (ph < 0) ph = carry_rid;
+    hd.ph = ph;
+    int32_t pr = ph;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        hd.prev_rid[k] = pr;
+        hd.rid[k] = hd.lh[k] >= 0 ? hd.lh[k] : ph;
+        pr = hd.rid[k];
+    }
+}
+
+// Inclusive segmented scan of x (scan order) given the resolved heads; `prev[k]` is the inclusive
+// value of the element before k (in that element's own ray).  `carry` is updated to the state after
+// the step's last element.
+template <int N, class FI, class FC>
+__device__ __forceinline__ void scan_values(const StepHeads &hd, const float x[4][N], float carry[N], float incl[4][N],
+                                            float prev[4][N], FI identity, FC comb)
+{
+    const int lane = lane_id();
+    float li[4][N];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int ch = 0; ch < N; ++ch)
+            li[k][ch] = (k == 0 || hd.is_head[k]) ? x[k][ch] : comb(ch, li[k - 1 < 0 ? 0 : k - 1][ch], x[k][ch]);
+    float av[N];
+#pragma unroll
+    for (int ch = 0; ch < N; ++ch) av[ch] = li[3][ch];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int off = 1 << s;
+#pragma unroll
+        for (int ch = 0; ch < N; ++ch) {
+            const float uv = __shfl_up(av[ch], off, NFA_WAVE);
+            if ((hd.acc >> s) & 1u) av[ch] = comb(ch, uv, av[ch]);
+        }
+    }
+    float pv[N];
+#pragma unroll
+    for (int ch = 0; ch < N; ++ch) {
+        pv[ch] = __shfl_up(av[ch], 1, NFA_WAVE);
+        if (lane == 0) pv[ch] = identity(ch);
+        if (hd.open_prefix) pv[ch] = comb(ch, carry[ch], pv[ch]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int ch = 0; ch < N; ++ch) {
+            prev[k][ch] = (k == 0) ? pv[ch] : incl[k - 1 < 0 ? 0 : k - 1][ch];
+            incl[k][ch] = hd.lh[k] >= 0 ? li[k][ch] : comb(ch, pv[ch], li[k][ch]);
+        }
+#pragma unroll
+    for (int ch = 0; ch < N; ++ch) carry[ch] = __shfl(incl[3][ch], 63, NFA_WAVE);
+}
+
+// ------------------------------------------------------------------------------------------
 // The engine.  Op interface (all indices j are in ADDRESS order, 0..3, element p0 + j):
 //   static constexpr int NCH;                       scan channels
 //   __device__ float identity(int ch);
@@ -153,6 +244,10 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
     float carry[NCH];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) carry[ch] = op.identity(ch);
+    constexpr int NCB = Op::NCHB > 0 ? Op::NCHB : 1;
+    float carry_b[NCB];
+#pragma unroll
+    for (int ch = 0; ch < NCB; ++ch) carry_b[ch] = 0.0f;
     int32_t carry_rid = -1;
 
     const int64_t c_first = DIR > 0 ? (e_lo / SEG_CHUNK) * SEG_CHUNK : ((e_hi - 1) / SEG_CHUNK) * SEG_CHUNK;
@@ -213,80 +308,52 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
         if (!PIPE && ci > 0) op.fetch(p0, ld_safe(c), valid, raw_cur);
         op.load(raw_cur, valid);
 
-        // ---- lane-local inclusive segmented scan, scan order k (address j = DIR>0 ? k : 3-k)
-        float li[4][NCH];
-        int32_t lh[4];
+        // ---- segment structure of this step: ray id of every element (scan order k, address j = DIR>0 ? k : 3-k)
+        StepHeads hd;
+        resolve_heads<DIR>(hj, valid, carry_rid, hd);
+        if constexpr (Op::NEEDS_RID) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int j = DIR > 0 ? k : 3 - k;
-            const int32_t h = valid[j] ? hj[j] : -1;
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                const float xv = valid[j] ? op.x(j, ch) : op.identity(ch);
-                li[k][ch] = (k == 0 || h >= 0) ? xv : op.comb(ch, li[k - 1 < 0 ? 0 : k - 1][ch], xv);
+            for (int k = 0; k < 4; ++k) {
+                const int j = DIR > 0 ? k : 3 - k;
+                op.pre(j, p0 + j, valid[j], hd.rid[k]);
             }
-            lh[k] = (k == 0) ? h : max(lh[k - 1 < 0 ? 0 : k - 1], h);
         }
-        // ---- wave inclusive scan of the lane aggregates
-        float av[NCH];
+        // ---- stage A: scan of op.x, results to op.emit
+        {
+            float xa[4][NCH], incl[4][NCH], prev[4][NCH];
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) av[ch] = li[3][ch];
-        int32_t ah = lh[3];
+            for (int k = 0; k < 4; ++k) {
+                const int j = DIR > 0 ? k : 3 - k;
 #pragma unroll
-        for (int off = 1; off < NFA_WAVE; off <<= 1) {
-            const int32_t uh = __shfl_up(ah, off, NFA_WAVE);
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                const float uv = __shfl_up(av[ch], off, NFA_WAVE);
-                if (lane >= off && ah < 0) av[ch] = op.comb(ch, uv, av[ch]);
+                for (int ch = 0; ch < NCH; ++ch) xa[k][ch] = valid[j] ? op.x(j, ch) : op.identity(ch);
             }
-            if (lane >= off) ah = max(ah, uh);
-        }
-        // ---- exclusive lane prefix, with the carry of the previous steps folded in
-        float pv[NCH];
-        int32_t ph = __shfl_up(ah, 1, NFA_WAVE);
+            scan_values<NCH>(hd, xa, carry, incl, prev, [&](int ch) { return op.identity(ch); },
+                             [&](int ch, float u, float v) { return op.comb(ch, u, v); });
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) pv[ch] = __shfl_up(av[ch], 1, NFA_WAVE);
-        if (lane == 0) {
-            ph = -1;
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) pv[ch] = op.identity(ch);
-        }
-        if (ph < 0) {
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) pv[ch] = op.comb(ch, carry[ch], pv[ch]);
-            ph = carry_rid;
-        }
-        // ---- per element results
-        float prev[NCH];
-        int32_t prev_rid = ph;
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) prev[ch] = pv[ch];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int j = DIR > 0 ? k : 3 - k;
-            float incl[NCH];
-            int32_t rid;
-            if (lh[k] >= 0) {
-                rid = lh[k];
-#pragma unroll
-                for (int ch = 0; ch < NCH; ++ch) incl[ch] = li[k][ch];
-            } else {
-                rid = ph;
-#pragma unroll
-                for (int ch = 0; ch < NCH; ++ch) incl[ch] = op.comb(ch, pv[ch], li[k][ch]);
+            for (int k = 0; k < 4; ++k) {
+                const int j = DIR > 0 ? k : 3 - k;
+                op.emit(j, p0 + j, valid[j], hd.is_head[k], hd.rid[k], hd.prev_rid[k], incl[k], prev[k]);
             }
-            const bool is_head = valid[j] && hj[j] >= 0;
-            op.emit(j, p0 + j, valid[j], is_head, rid, prev_rid, incl, prev);
-            prev_rid = rid;
+        }
+        // ---- stage B (optional): additive scan of values derived from stage A's results
+        if constexpr (Op::NCHB > 0) {
+            constexpr int NB = Op::NCHB > 0 ? Op::NCHB : 1;
+            float xb[4][NB], incl[4][NB], prev[4][NB];
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) prev[ch] = incl[ch];
+            for (int k = 0; k < 4; ++k) {
+                const int j = DIR > 0 ? k : 3 - k;
+#pragma unroll
+                for (int ch = 0; ch < NB; ++ch) xb[k][ch] = valid[j] ? op.xb(j, ch) : 0.0f;
+            }
+            scan_values<NB>(hd, xb, carry_b, incl, prev, [](int) { return 0.0f; }, [](int, float u, float v) { return u + v; });
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = DIR > 0 ? k : 3 - k;
+                op.emit_b(j, p0 + j, valid[j], hd.is_head[k], hd.rid[k], hd.prev_rid[k], incl[k], prev[k]);
+            }
         }
         op.store(p0, valid);
-        // ---- carry = state after the last element of this step (lane 63, k = 3)
-        carry_rid = __shfl(prev_rid, 63, NFA_WAVE);
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) carry[ch] = __shfl(prev[ch], 63, NFA_WAVE);
+        carry_rid = __shfl(hd.rid[3], 63, NFA_WAVE);
         if (PIPE) raw_cur = raw_next;
     }
     // remaining owned rays are all empty (their start equals e_hi / e_lo)
@@ -298,7 +365,10 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
         if (v_next < n_own) { win_base = v_next; load_window(); continue; }
         break;
     }
-    if (carry_rid >= 0 && lane == 0) op.ray_done(carry_rid, carry);
+    if (carry_rid >= 0 && lane == 0) {
+        op.ray_done(carry_rid, carry);
+        if constexpr (Op::NCHB > 0) op.ray_done_b(carry_rid, carry_b);
+    }
 }
 
 template <int DIR, bool PIPE, class Op>
@@ -334,6 +404,8 @@ static void launch_seg(const Op &op, const int64_t *packed_info, const int64_t *
 
 struct OpBase1 {  // one additive channel
     static constexpr int NCH = 1;
+    static constexpr int NCHB = 0;
+    static constexpr bool NEEDS_RID = false;
     __device__ __forceinline__ float identity(int) const { return 0.0f; }
     __device__ __forceinline__ float comb(int, float a, float b) const { return a + b; }
     __device__ __forceinline__ void ray_done(int, const float *) const {}
@@ -344,6 +416,8 @@ struct OpBase1 {  // one additive channel
 template <bool EXCL, bool PROD, bool VEC>
 struct ScanOp {
     static constexpr int NCH = 1;
+    static constexpr int NCHB = 0;
+    static constexpr bool NEEDS_RID = false;
     struct Raw { F4 x; };
     const float *in;
     float *out;
@@ -437,6 +511,8 @@ struct DensityFwdOp : OpBase1 {
 template <bool VEC>
 struct AlphaFwdOp {
     static constexpr int NCH = 1;
+    static constexpr int NCHB = 0;
+    static constexpr bool NEEDS_RID = false;
     struct Raw { F4 a, pf; };
     const float *al, *prefix;
     float *w, *tr;
@@ -546,15 +622,18 @@ struct AlphaBwdOp : OpBase1 {
     __device__ __forceinline__ void store(int64_t p0, const bool valid[4]) { store4<VEC>(galpha, p0, valid, res); }
 };
 
-// ---- visibility mask, volrend.py:412-418 / :474-480 (the per-ray visible count that the
-//      sampler's compaction needs is a second, 1 B/sample pass: MaskCountOp)
-template <bool DENSITY, bool VEC>
+// ---- visibility mask, volrend.py:412-418 / :474-480.  COUNT adds the per-ray number of visible
+//      samples (what the sampler's compaction needs) as a stage-B scan of the mask just computed.
+template <bool DENSITY, bool VEC, bool COUNT>
 struct VisibilityOp {
     static constexpr int NCH = 1;
+    static constexpr int NCHB = COUNT ? 1 : 0;
+    static constexpr bool NEEDS_RID = false;
     struct Raw { F4 s, pf, a, b; };
     const float *ts, *te, *val, *prefix;
     float eps, thre;
     uint8_t *vis;
+    int64_t *cnts;
     float x0[4], a4[4], pf[4];
     uint8_t m[4];
     __device__ __forceinline__ float identity(int) const { return DENSITY ? 0.0f : 1.0f; }
@@ -587,6 +666,12 @@ struct VisibilityOp {
         if (thre > 0.0f) v = v && (a4[j] >= thre);
         m[j] = (valid && v) ? 1 : 0;
     }
+    __device__ __forceinline__ float xb(int j, int) const { return (float)m[j]; }
+    __device__ __forceinline__ void emit_b(int, int64_t, bool, bool is_head, int, int prev_rid, const float *, const float prev[1]) const
+    {
+        if (is_head && prev_rid >= 0) cnts[prev_rid] = (int64_t)prev[0];
+    }
+    __device__ __forceinline__ void ray_done_b(int rid, const float tot[1]) const { cnts[rid] = (int64_t)tot[0]; }
     __device__ __forceinline__ void store(int64_t p0, const bool valid[4])
     {
         if (VEC && valid[0] && valid[1] && valid[2] && valid[3]) {
@@ -599,7 +684,10 @@ struct VisibilityOp {
         }
     }
     __device__ __forceinline__ void ray_done(int, const float *) const {}
-    __device__ __forceinline__ void empty_ray(int) const {}
+    __device__ __forceinline__ void empty_ray(int rid) const
+    {
+        if (COUNT) cnts[rid] = 0;
+    }
 };
 
 struct U4 { uint32_t w; };  // 4 mask bytes, raw
@@ -620,29 +708,7 @@ __device__ __forceinline__ float mask_sel(const U4 &m, int j, const bool valid[4
     return (valid[j] && ((m.w >> (8 * j)) & 0xFFu)) ? 1.0f : 0.0f;
 }
 
-// ---- per-ray count of set mask bytes (second pass input of the compaction) and the compaction
-template <bool VEC>
-struct MaskCountOp : OpBase1 {
-    struct Raw { U4 m; };
-    const uint8_t *vis;
-    int64_t *cnts;
-    float m[4];
-    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const { load_mask4(vis, VEC, p0, ps, valid, r.m); }
-    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
-    {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) m[j] = mask_sel(r.m, j, valid);
-    }
-    __device__ __forceinline__ float x(int j, int) const { return m[j]; }
-    __device__ __forceinline__ void emit(int, int64_t, bool, bool is_head, int, int prev_rid, const float *, const float prev[1])
-    {
-        if (is_head && prev_rid >= 0) cnts[prev_rid] = (int64_t)prev[0];
-    }
-    __device__ __forceinline__ void store(int64_t, const bool *) const {}
-    __device__ __forceinline__ void ray_done(int rid, const float tot[1]) const { cnts[rid] = (int64_t)tot[0]; }
-    __device__ __forceinline__ void empty_ray(int rid) const { cnts[rid] = 0; }
-};
-
+// ---- compaction of the visible samples (per-ray output offsets = cumsum of VisibilityOp's counts)
 template <bool VEC>
 struct CompactOp : OpBase1 {
     struct Raw { U4 m; F4 a, b; };
@@ -679,6 +745,8 @@ struct CompactOp : OpBase1 {
 template <int C, bool VEC>
 struct AccumOp {
     static constexpr int NCH = C;
+    static constexpr int NCHB = 0;
+    static constexpr bool NEEDS_RID = false;
     struct Raw { F4 w; float v[4][C]; };
     const float *w, *vals;  // vals may be null (C == 1): accumulate w
     int32_t D, d0;
@@ -817,6 +885,8 @@ __device__ __forceinline__ void fix_rgb12(const float *rgb, bool vec, int64_t p0
 template <bool VEC>
 struct RenderAccumOp {
     static constexpr int NCH = 5;
+    static constexpr int NCHB = 0;
+    static constexpr bool NEEDS_RID = false;
     struct Raw { F4 w, a, b; float c[12]; int64_t p0; };
     const float *w, *rgb, *ts, *te;
     float *colors, *opac, *depth;
@@ -909,6 +979,153 @@ struct RenderAccumBwdOp : OpBase1 {
                 q[0] = make_float4(gr[0], gr[1], gr[2], gr[3]);
                 q[1] = make_float4(gr[4], gr[5], gr[6], gr[7]);
                 q[2] = make_float4(gr[8], gr[9], gr[10], gr[11]);
+            } else {
+                volatile float *pv = grgb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (valid[j]) {
+                        pv[3 * (p0 + j)] = gr[3 * j]; pv[3 * (p0 + j) + 1] = gr[3 * j + 1]; pv[3 * (p0 + j) + 2] = gr[3 * j + 2];
+                    }
+            }
+        }
+    }
+};
+
+// ---- `rendering` with a density callback in ONE pass (volrend.py:109-151): stage A scans
+//      sigma*delta into transmittance -> (w, T, alpha); stage B scans w*rgb, w, w*mid into the per-ray
+//      colour / opacity / un-normalised depth.  Bit-identical to DensityFwdOp followed by
+//      RenderAccumOp (same expressions, same scan tree), 12 B/sample less traffic.
+template <bool VEC>
+struct RenderFusedFwdOp : OpBase1 {
+    static constexpr int NCHB = 5;
+    struct Raw { F4 a, b, s; float c[12]; int64_t p0; };
+    const float *ts, *te, *sig, *rgb;
+    float *w, *tr, *al, *colors, *opac, *depth;
+    float xs[4], mid[4], rw[4], rt[4], ra[4], c[12];
+    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
+    {
+        ld4<VEC>(ts, p0, ps, valid, r.a);
+        ld4<VEC>(te, p0, ps, valid, r.b);
+        ld4<VEC>(sig, p0, ps, valid, r.s);
+        load_rgb12(rgb, VEC, p0, ps, valid, r.c);
+        r.p0 = p0;
+    }
+    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    {
+        fix_rgb12(rgb, VEC, r.p0, valid, r.c, c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xs[j] = valid[j] ? r.s.v[j] * (r.b.v[j] - r.a.v[j]) : 0.0f;
+            mid[j] = (r.a.v[j] + r.b.v[j]) / 2.0f;
+        }
+    }
+    __device__ __forceinline__ float x(int j, int) const { return xs[j]; }
+    __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int, int, const float *, const float prev[1])
+    {
+        const float S = is_head ? 0.0f : prev[0];
+        const float T = expf(-S);
+        const float a = 1.0f - expf(-xs[j]);
+        rt[j] = T; ra[j] = a; rw[j] = T * a;
+    }
+    __device__ __forceinline__ float xb(int j, int ch) const
+    {
+        return ch < 3 ? rw[j] * c[3 * j + ch] : (ch == 3 ? rw[j] : rw[j] * mid[j]);
+    }
+    __device__ __forceinline__ void put(int rid, const float *t) const
+    {
+        colors[3 * (int64_t)rid] = t[0]; colors[3 * (int64_t)rid + 1] = t[1]; colors[3 * (int64_t)rid + 2] = t[2];
+        opac[rid] = t[3]; depth[rid] = t[4];
+    }
+    __device__ __forceinline__ void emit_b(int, int64_t, bool, bool is_head, int, int prev_rid, const float *, const float prev[5]) const
+    {
+        if (is_head && prev_rid >= 0) put(prev_rid, prev);
+    }
+    __device__ __forceinline__ void ray_done_b(int rid, const float t[5]) const { put(rid, t); }
+    __device__ __forceinline__ void empty_ray(int rid) const
+    {
+        const float z[5] = {0, 0, 0, 0, 0};
+        put(rid, z);
+    }
+    __device__ __forceinline__ void store(int64_t p0, const bool valid[4])
+    {
+        if (w) store4<VEC>(w, p0, valid, rw);
+        if (tr) store4<VEC>(tr, p0, valid, rt);
+        if (al) store4<VEC>(al, p0, valid, ra);
+    }
+};
+
+// ---- its backward in one reverse pass: the gradient of the three accumulations w.r.t. w is formed
+//      from the per-ray output gradients (needs the ray id before the scan: NEEDS_RID), added to the
+//      gradients arriving at extras' weights / trans / alphas, and pushed through the transmittance
+//      chain.  Same expressions as RenderAccumBwdOp followed by DensityBwdOp.
+template <bool VEC>
+struct RenderFusedBwdOp : OpBase1 {
+    static constexpr bool NEEDS_RID = true;
+    struct Raw { F4 a, b, T, A, gw, gt, ga; float c[12]; int64_t p0; };
+    const float *ts, *te, *rgb, *tr, *al, *gc, *go, *gd, *gw, *gt, *ga;
+    float *gsig, *grgb;
+    float T[4], A[4], GW[4], GT[4], GA[4], dlt[4], mid[4], q[4], rs[4], c[12], gr[12];
+    bool full;
+    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
+    {
+        ld4<VEC>(ts, p0, ps, valid, r.a);
+        ld4<VEC>(te, p0, ps, valid, r.b);
+        ld4<VEC>(tr, p0, ps, valid, r.T);
+        ld4<VEC>(al, p0, ps, valid, r.A);
+        if (gw) ld4<VEC>(gw, p0, ps, valid, r.gw);
+        if (gt) ld4<VEC>(gt, p0, ps, valid, r.gt);
+        if (ga) ld4<VEC>(ga, p0, ps, valid, r.ga);
+        load_rgb12(rgb, VEC, p0, ps, valid, r.c);
+        r.p0 = p0;
+    }
+    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    {
+        full = VEC && valid[0] && valid[1] && valid[2] && valid[3];
+        fix_rgb12(rgb, VEC, r.p0, valid, r.c, c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            T[j] = sel(r.T, j, valid, 0.0f); A[j] = sel(r.A, j, valid, 0.0f);
+            GW[j] = (gw && valid[j]) ? r.gw.v[j] : 0.0f;
+            GT[j] = (gt && valid[j]) ? r.gt.v[j] : 0.0f;
+            GA[j] = (ga && valid[j]) ? r.ga.v[j] : 0.0f;
+            dlt[j] = r.b.v[j] - r.a.v[j];
+            mid[j] = (r.a.v[j] + r.b.v[j]) / 2.0f;
+        }
+    }
+    __device__ __forceinline__ void pre(int j, int64_t, bool valid, int rid)
+    {
+        float g = 0.0f;
+        gr[3 * j] = gr[3 * j + 1] = gr[3 * j + 2] = 0.0f;
+        const float wj = T[j] * A[j];
+        if (valid) {
+            if (gc) {
+                const float g0 = gc[3 * (int64_t)rid], g1 = gc[3 * (int64_t)rid + 1], g2 = gc[3 * (int64_t)rid + 2];
+                g += g0 * c[3 * j] + g1 * c[3 * j + 1] + g2 * c[3 * j + 2];
+                gr[3 * j] = g0 * wj; gr[3 * j + 1] = g1 * wj; gr[3 * j + 2] = g2 * wj;
+            }
+            if (go) g += go[rid];
+            if (gd) g += gd[rid] * mid[j];
+        }
+        GW[j] = g + GW[j];
+        q[j] = GW[j] * wj + GT[j] * T[j];
+    }
+    __device__ __forceinline__ float x(int j, int) const { return q[j]; }
+    __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int, int, const float *, const float prev[1])
+    {
+        const float E = is_head ? 0.0f : prev[0];
+        const float om = 1.0f - A[j];
+        const float Bv = GW[j] * T[j] * om + GA[j] * om - E;
+        rs[j] = dlt[j] * Bv;
+    }
+    __device__ __forceinline__ void store(int64_t p0, const bool valid[4])
+    {
+        if (gsig) store4<VEC>(gsig, p0, valid, rs);
+        if (grgb) {
+            if (full) {
+                float4 *qq = reinterpret_cast<float4 *>(grgb + 3 * p0);
+                qq[0] = make_float4(gr[0], gr[1], gr[2], gr[3]);
+                qq[1] = make_float4(gr[4], gr[5], gr[6], gr[7]);
+                qq[2] = make_float4(gr[8], gr[9], gr[10], gr[11]);
             } else {
                 volatile float *pv = grgb;
 #pragma unroll
@@ -1183,18 +1400,17 @@ int nfa_render_visibility(const float *t_starts, const float *t_ends, const floa
         // the uchar4 mask store needs 4-byte alignment of vis, the float loads 16
         const bool vec = all_aligned16(t_starts, t_ends, sigmas_or_alphas, prefix_trans) &&
                          (reinterpret_cast<uintptr_t>(vis) & 3) == 0;
-#define NFA_VIS(DN, V)                                                                                     \
-    do { VisibilityOp<DN, V> op; op.ts = t_starts; op.te = t_ends; op.val = sigmas_or_alphas; op.prefix = prefix_trans; \
-         op.eps = early_stop_eps; op.thre = alpha_thre; op.vis = vis;                 \
+#define NFA_VIS(DN, V, CN)                                                                                 \
+    do { VisibilityOp<DN, V, CN> op; op.ts = t_starts; op.te = t_ends; op.val = sigmas_or_alphas; op.prefix = prefix_trans; \
+         op.eps = early_stop_eps; op.thre = alpha_thre; op.vis = vis; op.cnts = vis_cnts;                    \
          launch_seg<1>(op, packed_info, tiles, n_rays, n_tiles, s); } while (0)
-        if (density) { if (vec) NFA_VIS(true, true); else NFA_VIS(true, false); }
-        else         { if (vec) NFA_VIS(false, true); else NFA_VIS(false, false); }
+#define NFA_VIS2(DN, V) do { if (vis_cnts) NFA_VIS(DN, V, true); else NFA_VIS(DN, V, false); } while (0)
+        if (density) { if (vec) NFA_VIS2(true, true); else NFA_VIS2(true, false); }
+        else         { if (vec) NFA_VIS2(false, true); else NFA_VIS2(false, false); }
+#undef NFA_VIS2
 #undef NFA_VIS
-    }
-    if (vis_cnts) {
-        const bool vec = n_elems > 0 && (reinterpret_cast<uintptr_t>(vis) & 3) == 0;
-        if (vec) { MaskCountOp<true> op; op.vis = vis; op.cnts = vis_cnts; launch_seg<1>(op, packed_info, tiles, n_rays, n_tiles, s); }
-        else { MaskCountOp<false> op; op.vis = vis; op.cnts = vis_cnts; launch_seg<1>(op, packed_info, tiles, n_rays, n_tiles, s); }
+    } else if (vis_cnts && n_rays > 0) {
+        if (hipMemsetAsync(vis_cnts, 0, sizeof(int64_t) * n_rays, s) != hipSuccess) { set_error("render_visibility: memset failed"); return NFA_EHIP; }
     }
     NFA_CHECK_LAUNCH("render_visibility");
     return NFA_OK;
@@ -1317,6 +1533,49 @@ int nfa_render_accumulate_bwd(const float *weights, const float *rgbs, const flo
     if (vec) NFA_RB(true); else NFA_RB(false);
 #undef NFA_RB
     NFA_CHECK_LAUNCH("render_accumulate_bwd");
+    return NFA_OK;
+}
+
+int nfa_render_fused_fwd(const float *t_starts, const float *t_ends, const float *sigmas, const float *rgbs,
+                         const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles, int64_t n_rays, int64_t n_elems,
+                         float *weights, float *trans, float *alphas, float *colors, float *opacities, float *depths,
+                         nfa_stream_t stream)
+{
+    SEG_COMMON_CHECKS("render_fused_fwd");
+    if (n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(colors && opacities && depths && (n_elems == 0 || (t_starts && t_ends && sigmas && rgbs)),
+                "render_fused_fwd: null pointer");
+    hipStream_t s = as_stream(stream);
+    const bool vec = all_aligned16(t_starts, t_ends, sigmas, rgbs, weights, trans, alphas);
+#define NFA_FF(V)                                                                                          \
+    do { RenderFusedFwdOp<V> op; op.ts = t_starts; op.te = t_ends; op.sig = sigmas; op.rgb = rgbs; op.w = weights; \
+         op.tr = trans; op.al = alphas; op.colors = colors; op.opac = opacities; op.depth = depths;          \
+         launch_seg<1>(op, packed_info, tiles, n_rays, n_tiles, s); } while (0)
+    if (vec) NFA_FF(true); else NFA_FF(false);
+#undef NFA_FF
+    NFA_CHECK_LAUNCH("render_fused_fwd");
+    return NFA_OK;
+}
+
+int nfa_render_fused_bwd(const float *t_starts, const float *t_ends, const float *rgbs, const float *trans, const float *alphas,
+                         const float *g_colors, const float *g_opacities, const float *g_depths, const float *g_weights,
+                         const float *g_trans, const float *g_alphas, const int64_t *packed_info, const int64_t *tiles,
+                         int64_t n_tiles, int64_t n_rays, int64_t n_elems, float *grad_sigmas, float *grad_rgbs,
+                         nfa_stream_t stream)
+{
+    SEG_COMMON_CHECKS("render_fused_bwd");
+    if (n_elems == 0) return NFA_OK;
+    NFA_REQUIRE(t_starts && t_ends && rgbs && trans && alphas && (grad_sigmas || grad_rgbs), "render_fused_bwd: null pointer");
+    hipStream_t s = as_stream(stream);
+    const bool vec = all_aligned16(t_starts, t_ends, rgbs, trans, alphas, g_weights, g_trans, g_alphas, grad_sigmas, grad_rgbs);
+#define NFA_FB(V)                                                                                          \
+    do { RenderFusedBwdOp<V> op; op.ts = t_starts; op.te = t_ends; op.rgb = rgbs; op.tr = trans; op.al = alphas; \
+         op.gc = g_colors; op.go = g_opacities; op.gd = g_depths; op.gw = g_weights; op.gt = g_trans; op.ga = g_alphas; \
+         op.gsig = grad_sigmas; op.grgb = grad_rgbs;                                                         \
+         launch_seg<-1>(op, packed_info, tiles, n_rays, n_tiles, s); } while (0)
+    if (vec) NFA_FB(true); else NFA_FB(false);
+#undef NFA_FB
+    NFA_CHECK_LAUNCH("render_fused_bwd");
     return NFA_OK;
 }
 

@@ -80,7 +80,8 @@ struct RunsParams {
 //   EV_OCC(thr)    emit steps while mid < thr              (grid.cu:207-262)
 //   EV_SPAN(thr)   start of a grid span: skip to thr only if the previous step was not emitted
 //                  (grid.cu:153-163, `if (!continuous)`)
-constexpr int EV_MAX = 16;  // 32 entries measured no faster (fewer mid-walk flushes but 4 instead of 7 waves/SIMD)
+constexpr int EV_MAX = 32;  // measured on cfg2: 16 entries 630 us, 32 entries 566 us (fewer mid-walk flushes win over occupancy)
+using evt_t = uint64_t;      // 2 bits per entry
 enum { EV_EMPTY = 0, EV_OCC = 1, EV_SPAN = 2, EV_NONE = 3 };
 
 struct RunState {
@@ -96,7 +97,7 @@ struct RunState {
     unsigned long long brick_word;
     // event list: open (unmerged) entry in registers, closed entries in LDS
     int32_t ev_cnt;
-    uint32_t ev_types;  // 2 bits per closed entry
+    evt_t ev_types;  // 2 bits per closed entry
     int32_t open_type;
     float open_thr;
 };
@@ -180,13 +181,13 @@ __device__ __forceinline__ void process_events(RunState &st, const float *ev_thr
         if (type == EV_EMPTY) st.continuous = false;
     }
     st.ev_cnt = 0;
-    st.ev_types = 0u;
+    st.ev_types = 0;
 }
 
 __device__ __forceinline__ void push_closed(RunState &st, float *ev_thr, int type, float thr)
 {
     ev_thr[st.ev_cnt * 256 + threadIdx.x] = thr;
-    st.ev_types |= (uint32_t)type << (2 * st.ev_cnt);
+    st.ev_types |= (evt_t)type << (2 * st.ev_cnt);
     st.ev_cnt++;
 }
 
@@ -249,7 +250,7 @@ __device__ __forceinline__ void runs_span(const nfa_traverse_args &a, const Runs
             const int type = (int)((st.brick_word >> bit) & 1ull);  // EV_EMPTY / EV_OCC
             const bool changed = type != st.open_type;
             ev_thr[(changed ? st.ev_cnt : EV_MAX) * 256 + threadIdx.x] = st.open_thr;
-            st.ev_types |= changed ? ((uint32_t)st.open_type << (2 * st.ev_cnt)) : 0u;
+            st.ev_types |= changed ? ((evt_t)st.open_type << (2 * st.ev_cnt)) : (evt_t)0;
             st.ev_cnt += changed ? 1 : 0;
             st.open_type = type;
             st.open_thr = fminf(fminf(tdist[0], fminf(tdist[1], tdist[2])), this_tmax);  // t_traverse, non-decreasing
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
         st.t_last = near_plane; st.continuous = false;
         st.n_samples = 0; st.n_runs = 0; st.open = false; st.run_cont = false; st.run_t0 = 0.f; st.run_inc = 0.f;
         st.run_n = 0; st.brick_id = -1; st.brick_word = 0ull;
-        st.ev_cnt = 0; st.ev_types = 0u; st.open_type = EV_NONE; st.open_thr = 0.f;
+        st.ev_cnt = 0; st.ev_types = 0; st.open_type = EV_NONE; st.open_thr = 0.f;
         if (FUSED) {
             float tmin, tmax, lo, hi;
             bool hit = true;

@@ -20,6 +20,10 @@ from ._segments import SegInfo, resolve, seginfo_from_ray_indices
 from .scan import exclusive_prod, exclusive_sum
 
 
+# rendering(): one fused pass each way (True) or weights + accumulation as two passes (False, for A/B tests)
+FUSE_RENDERING = True
+
+
 def _f32c(t: Optional[Tensor]) -> Optional[Tensor]:
     if t is None:
         return None
@@ -187,6 +191,52 @@ class _RenderAccumulate(torch.autograd.Function):
         return g_w, g_rgb, None, None, None
 
 
+class _RenderFused(torch.autograd.Function):
+    """``rendering`` with a density callback as one forward and one backward pass over the samples.
+
+    Replaces render_weight_from_density + the three accumulations (volrend.py:109-151): the reference
+    runs ~20 ATen kernels there; the unfused native path two each way.  Outputs are bit-identical to
+    ``_RenderFromDensity`` followed by ``_RenderAccumulate``.
+    """
+
+    @staticmethod
+    def forward(ctx, t_starts, t_ends, sigmas, rgbs, seg: SegInfo):
+        ts, te, sg, c = _f32c(t_starts), _f32c(t_ends), _f32c(sigmas), _f32c(rgbs)
+        dev = B.require_device(ts, te, sg, c)
+        R, n = seg.n_rays, sg.numel()
+        weights, trans, alphas = torch.empty_like(sg), torch.empty_like(sg), torch.empty_like(sg)
+        colors = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        opac = torch.empty((R, 1), dtype=torch.float32, device=dev)
+        depth = torch.empty((R, 1), dtype=torch.float32, device=dev)
+        if R:
+            with torch.cuda.device(dev):
+                B.call("nfa_render_fused_fwd", B.ptr(ts), B.ptr(te), B.ptr(sg), B.ptr(c), B.ptr(seg.packed_info),
+                       B.ptr(seg.tiles), seg.n_tiles, R, n, B.ptr(weights), B.ptr(trans), B.ptr(alphas), B.ptr(colors),
+                       B.ptr(opac), B.ptr(depth), B.stream())
+        ctx.seg = seg
+        ctx.save_for_backward(ts, te, c, trans, alphas)
+        return colors, opac, depth, weights, trans, alphas
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_c, g_o, g_d, g_w, g_t, g_a):
+        ts, te, c, trans, alphas = ctx.saved_tensors
+        seg = ctx.seg
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            raise NotImplementedError("nerfacc_amd: rendering is not differentiable w.r.t. t_starts / t_ends "
+                                      "(same contract as the reference, volrend.py:33-35)")
+        need_sg, need_c = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        g_sig = torch.empty_like(trans) if need_sg else None
+        g_rgb = torch.empty_like(c) if need_c else None
+        if trans.numel() and (need_sg or need_c):
+            with torch.cuda.device(trans.device):
+                B.call("nfa_render_fused_bwd", B.ptr(ts), B.ptr(te), B.ptr(c), B.ptr(trans), B.ptr(alphas),
+                       B.ptr(_f32c(g_c)), B.ptr(_f32c(g_o)), B.ptr(_f32c(g_d)), B.ptr(_f32c(g_w)), B.ptr(_f32c(g_t)),
+                       B.ptr(_f32c(g_a)), B.ptr(seg.packed_info), B.ptr(seg.tiles), seg.n_tiles, seg.n_rays,
+                       trans.numel(), B.ptr(g_sig), B.ptr(g_rgb), B.stream())
+        return None, None, g_sig, g_rgb, None
+
+
 def _use_fused(seg: Optional[SegInfo], *tensors: Optional[Tensor]) -> bool:
     if seg is None or not seg.contiguous:
         return False
@@ -220,6 +270,11 @@ def rendering(
     if rgb_sigma_fn is None and rgb_alpha_fn is None:
         raise ValueError("At least one of `rgb_sigma_fn` and `rgb_alpha_fn` should be specified.")
 
+    seg = None
+    if ray_indices is not None and ray_indices.is_cuda:
+        assert n_rays is not None, "n_rays must be provided"
+        seg = seginfo_from_ray_indices(ray_indices, n_rays)
+
     if rgb_sigma_fn is not None:
         if t_starts.shape[0] != 0:
             rgbs, sigmas = rgb_sigma_fn(t_starts, t_ends, ray_indices)
@@ -228,6 +283,13 @@ def rendering(
             sigmas = torch.empty((0,), device=t_starts.device)
         assert rgbs.shape[-1] == 3, "rgbs must have 3 channels, got {}".format(rgbs.shape)
         assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
+        if FUSE_RENDERING and seg is not None and seg.sorted_indices and _use_fused(seg, sigmas, t_starts, t_ends) \
+                and rgbs.dtype == torch.float32 and rgbs.dim() == 2 \
+                and not (t_starts.requires_grad or t_ends.requires_grad):
+            # the whole of volrend.py:109-151 as one pass each way
+            colors, opacities, depths, weights, trans, alphas = _RenderFused.apply(t_starts, t_ends, sigmas, rgbs, seg)
+            extras = {"weights": weights, "alphas": alphas, "trans": trans, "sigmas": sigmas, "rgbs": rgbs}
+            return _finish_rendering(colors, opacities, depths, extras, rgbs, render_bkgd)
         weights, trans, alphas = render_weight_from_density(
             t_starts, t_ends, sigmas, ray_indices=ray_indices, n_rays=n_rays
         )
@@ -243,10 +305,6 @@ def rendering(
         weights, trans = render_weight_from_alpha(alphas, ray_indices=ray_indices, n_rays=n_rays)
         extras = {"weights": weights, "trans": trans, "rgbs": rgbs, "alphas": alphas}
 
-    seg = None
-    if ray_indices is not None and ray_indices.is_cuda:
-        assert n_rays is not None, "n_rays must be provided"
-        seg = seginfo_from_ray_indices(ray_indices, n_rays)
     if seg is not None and seg.sorted_indices and _use_fused(seg, weights, t_starts, t_ends) \
             and rgbs.dtype == torch.float32:
         # one pass for colours, opacity and depth (the reference runs 3 x (mul + index_add_))
@@ -257,6 +315,11 @@ def rendering(
         depths = accumulate_along_rays(
             weights, values=(t_starts + t_ends)[..., None] / 2.0, ray_indices=ray_indices, n_rays=n_rays
         )
+    return _finish_rendering(colors, opacities, depths, extras, rgbs, render_bkgd)
+
+
+def _finish_rendering(colors, opacities, depths, extras, rgbs, render_bkgd):
+    # ref: volrend.py:152-158
     depths = depths / opacities.clamp_min(torch.finfo(rgbs.dtype).eps)
     if render_bkgd is not None:
         colors = colors + render_bkgd * (1.0 - opacities)

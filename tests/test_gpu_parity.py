@@ -301,6 +301,56 @@ def test_rendering_composite(dev):
 
 
 # ----------------------------------------------------------------------------- grid
+def test_rendering_fused_pass_is_bit_identical_to_two_passes(dev, oracle):
+    """The one-pass rendering (stage-A transmittance scan + stage-B accumulation scan, and the reverse pass
+    that needs the ray id before its scan) against the two-pass composition, many tiles, ragged + empty rays,
+    with gradients arriving at colours / opacity / depth AND at extras' weights / trans / alphas."""
+    rng = np.random.default_rng(11)
+    cnts = rng.integers(0, 90, size=5000)
+    cnts[rng.integers(0, 5000, size=40)] = 0
+    cnts[17], cnts[4000] = 3001, 1500
+    n_rays, n = cnts.size, int(cnts.sum())
+    ri = torch.repeat_interleave(torch.arange(n_rays, device=dev), T(cnts, dev))
+    ts_np = rng.uniform(0.0, 4.0, n).astype(np.float32)
+    ts = T(ts_np, dev); te = T(ts_np + rng.uniform(1e-3, 0.05, n).astype(np.float32), dev)
+    sig0, rgb0 = T(rng.uniform(0, 6, n).astype(np.float32), dev), T(rng.uniform(0, 1, (n, 3)).astype(np.float32), dev)
+    gw = T(rng.normal(size=n).astype(np.float32), dev)
+    res = []
+    for fuse in (True, False):
+        na.volrend.FUSE_RENDERING = fuse
+        try:
+            sig, rgb = sig0.clone().requires_grad_(True), rgb0.clone().requires_grad_(True)
+            c, o, d, ex = na.rendering(ts, te, ri, n_rays, rgb_sigma_fn=lambda a, b, r: (rgb, sig),
+                                       render_bkgd=torch.tensor([0.1, 0.5, 0.9], device=dev))
+            loss = (c * c).sum() + 0.3 * d.sum() + (o * 0.7).sum() + (ex["weights"] * gw).sum() \
+                + 0.2 * (ex["trans"] * gw.flip(0)).sum() + 0.1 * (ex["alphas"] ** 2).sum()
+            loss.backward()
+            res.append([c, o, d, ex["weights"], ex["trans"], ex["alphas"], sig.grad, rgb.grad])
+        finally:
+            na.volrend.FUSE_RENDERING = True
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    # and against the oracle's composition (numpy fp32), forward
+    w, tr, al = oracle.render_weight_from_density(ts_np, te.cpu().numpy(), sig0.cpu().numpy(),
+                                                  packed_info=oracle.pack_info(ri.cpu().numpy(), n_rays))
+    assert_close(res[0][3], w, atol=1e-5); assert_close(res[0][4], tr, atol=1e-5)
+    acc = oracle.accumulate_along_rays(w, rgb0.cpu().numpy(), ri.cpu().numpy(), n_rays)
+    opa = oracle.accumulate_along_rays(w, None, ri.cpu().numpy(), n_rays)
+    assert_close(res[0][0], acc + np.array([0.1, 0.5, 0.9], np.float32) * (1 - opa), atol=2e-5)
+    # only colours used (the common training loss): NULL gradients for everything else
+    sig, rgb = sig0.clone().requires_grad_(True), rgb0.clone().requires_grad_(True)
+    c, _, _, _ = na.rendering(ts, te, ri, n_rays, rgb_sigma_fn=lambda a, b, r: (rgb, sig))
+    c.sum().backward()
+    na.volrend.FUSE_RENDERING = False
+    try:
+        sig2, rgb2 = sig0.clone().requires_grad_(True), rgb0.clone().requires_grad_(True)
+        c2, _, _, _ = na.rendering(ts, te, ri, n_rays, rgb_sigma_fn=lambda a, b, r: (rgb2, sig2))
+        c2.sum().backward()
+    finally:
+        na.volrend.FUSE_RENDERING = True
+    assert torch.equal(sig.grad, sig2.grad) and torch.equal(rgb.grad, rgb2.grad) and torch.equal(c, c2)
+
+
 def test_ray_aabb_intersect(dev, oracle):
     g = load_golden("ray_aabb")
     tm, tM, hit = na.ray_aabb_intersect(T(g["rays_o"], dev), T(g["rays_d"], dev), T(g["aabbs"], dev))
