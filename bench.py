@@ -33,6 +33,101 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+# ----------------------------------------------------------------------------- synthetic radiance field (harness)
+FIELD_SRC = os.path.join(ROOT, "bench_csrc", "field.hip")
+FIELD_LIB = os.path.join(ROOT, "bench_csrc", "libbench_field.so")
+
+
+def build_field(force: bool = False) -> str:
+    """Compile bench_csrc/field.hip (the synthetic field's three streaming kernels; harness code, see its
+    header) in-tree.  Rebuilt when the source is newer than the library or its hash changed."""
+    import hashlib
+    import subprocess
+    from nerfacc_amd import _build
+    want = hashlib.sha256(open(FIELD_SRC, "rb").read()).hexdigest()
+    hp = FIELD_LIB + ".hash"
+    if not force and os.path.exists(FIELD_LIB) and os.path.exists(hp) and open(hp).read().strip() == want:
+        return FIELD_LIB
+    cc = _build.hipcc()
+    if cc is None:
+        raise RuntimeError("hipcc not found: cannot build the bench's synthetic field")
+    tmp = FIELD_LIB + f".{os.getpid()}.tmp"
+    subprocess.run([cc, "-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={_build.ARCH}", "-o", tmp, FIELD_SRC],
+                   check=True)
+    os.replace(tmp, FIELD_LIB)
+    with open(hp, "w") as f:
+        f.write(want)
+    return FIELD_LIB
+
+
+class NativeField:
+    """sigma_base(t) = 4 (1/2 + 1/2 sin(20 (ts + te))); sigma = p0 sigma_base; rgb = p1 ts (grey ramp).
+    Same function as `torch_field`, evaluated by bench_csrc/field.hip: one kernel per callback and one
+    for the backward to the two parameters, so the step is dominated by the hot path it measures."""
+
+    def __init__(self, params: torch.Tensor):
+        import ctypes
+        self.params = params
+        self.lib = ctypes.CDLL(build_field())
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        self.lib.bf_field_sigma.argtypes = [vp, vp, i64, vp, vp]
+        self.lib.bf_field_fwd.argtypes = [vp, vp, i64, vp, vp, vp, vp]
+        self.lib.bf_field_bwd.argtypes = [vp, vp, vp, vp, i64, vp, vp]
+        self.blocks = int(self.lib.bf_grid_blocks())
+        lib, blocks = self.lib, self.blocks
+        st = lambda: torch.cuda.current_stream().cuda_stream
+        ptr = lambda t: None if t is None else t.data_ptr()
+
+        class Fn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, params, ts, te):
+                ts, te = ts.contiguous(), te.contiguous()
+                n = ts.numel()
+                sigma, rgb = torch.empty_like(ts), torch.empty((n, 3), dtype=ts.dtype, device=ts.device)
+                assert lib.bf_field_fwd(ptr(ts), ptr(te), n, ptr(params), ptr(sigma), ptr(rgb), st()) == 0
+                ctx.save_for_backward(ts, te)
+                return rgb, sigma
+
+            @staticmethod
+            def backward(ctx, g_rgb, g_sigma):
+                ts, te = ctx.saved_tensors
+                g_rgb = None if g_rgb is None else g_rgb.contiguous()
+                g_sigma = None if g_sigma is None else g_sigma.contiguous()
+                partial = torch.empty((blocks, 2), dtype=torch.float32, device=ts.device)
+                assert lib.bf_field_bwd(ptr(ts), ptr(te), ptr(g_sigma), ptr(g_rgb), ts.numel(), ptr(partial), st()) == 0
+                return partial.sum(0), None, None
+
+        self.Fn = Fn
+
+    def sigma_fn(self, ts, te, ri):                          # used inside sampling (no grad)
+        ts, te = ts.contiguous(), te.contiguous()
+        out = torch.empty_like(ts)
+        assert self.lib.bf_field_sigma(ts.data_ptr(), te.data_ptr(), ts.numel(), out.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream) == 0
+        return out
+
+    def rgb_sigma_fn(self, ts, te, ri):                      # used inside rendering (with grad)
+        return self.Fn.apply(self.params, ts, te)
+
+
+class TorchField:
+    """The same field with torch elementwise ops (~25 launches, 1.3 ms per step on 32 M samples)."""
+
+    def __init__(self, params: torch.Tensor):
+        self.params = params
+
+    @staticmethod
+    def base_sigma(ts, te):
+        return 4.0 * (0.5 + 0.5 * torch.sin(20.0 * (ts + te)))
+
+    def sigma_fn(self, ts, te, ri):
+        return self.base_sigma(ts, te)
+
+    def rgb_sigma_fn(self, ts, te, ri):
+        rgbs = (ts * self.params[1])[:, None].expand(-1, 3)  # grey ramp; made contiguous by rendering()
+        return rgbs, self.base_sigma(ts, te) * self.params[0]
+
+
 # ----------------------------------------------------------------------------- synthetic workload
 def make_grid(res: int, variant: str, seed: int = 42) -> np.ndarray:
     rng = np.random.default_rng(seed)
@@ -70,7 +165,7 @@ def make_rays(n_rays: int, variant: str, rank: int = 0, seed: int = 42):
 
 
 def make_workload(dev, n_rays: int = 1024 * 1024, res: int = 128, grid: str = "shell10", rays: str = "image",
-                  rank: int = 0):
+                  rank: int = 0, field: str = "native"):
     import nerfacc_amd as na
     b = make_grid(res, grid)
     o, d = make_rays(n_rays, rays, rank)
@@ -78,20 +173,10 @@ def make_workload(dev, n_rays: int = 1024 * 1024, res: int = 128, grid: str = "s
     est.binaries = torch.from_numpy(b).to(dev)
     est.occs = torch.from_numpy(b.reshape(-1).astype(np.float32)).to(dev)
     step = 2 * math.sqrt(3) / 1024                          # <= 1024 samples per ray
-    # two scalar parameters (density scale, colour scale): the "network" of this synthetic step.
-    # (scalar leaves keep the user-side backward to flat reductions; a [M,3]->[3] column
-    # reduction in torch costs more than the whole native pipeline.)
+    # two scalar parameters (density scale, colour scale): the "network" of this synthetic step
     params = torch.nn.Parameter(torch.tensor([1.0, 1.0], device=dev))
-
-    def base_sigma(ts, te):
-        return 4.0 * (0.5 + 0.5 * torch.sin(20.0 * (ts + te)))
-
-    def sigma_fn(ts, te, ri):                                # used inside sampling (no grad)
-        return base_sigma(ts, te)
-
-    def rgb_sigma_fn(ts, te, ri):                            # used inside rendering (with grad)
-        rgbs = (ts * params[1])[:, None].expand(-1, 3)       # grey ramp; made contiguous by rendering()
-        return rgbs, base_sigma(ts, te) * params[0]
+    fld = NativeField(params) if field == "native" else TorchField(params)
+    sigma_fn, rgb_sigma_fn = fld.sigma_fn, fld.rgb_sigma_fn
 
     return dict(estimator=est, rays_o=torch.from_numpy(o).to(dev), rays_d=torch.from_numpy(d).to(dev),
                 binaries_np=b, rays_np=(o, d), step=step, params=params, sigma_fn=sigma_fn, rgb_sigma_fn=rgb_sigma_fn,
@@ -252,6 +337,8 @@ def main():
     ap.add_argument("--res", type=int, default=128)
     ap.add_argument("--grid", default="shell10", choices=["shell10", "iid10"])
     ap.add_argument("--ray-variant", default="image", choices=["image", "random"])
+    ap.add_argument("--field", default="native", choices=["native", "torch"],
+                    help="synthetic radiance field: three streaming HIP kernels (bench_csrc/field.hip) or torch elementwise ops")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -264,7 +351,7 @@ def main():
     world, rank, local_rank = init_distributed("nccl", dev)
     assert world == max(1, args.gpus) or world == 1, "launch with torchrun --nproc-per-node == --gpus"
 
-    w = make_workload(dev, args.rays, args.res, args.grid, args.ray_variant, rank)
+    w = make_workload(dev, args.rays, args.res, args.grid, args.ray_variant, rank, args.field)
 
     def sync():
         torch.cuda.synchronize()
@@ -299,7 +386,8 @@ def main():
             "config": {"workload": f"cfg2: {args.rays} {args.ray_variant} rays/GPU, {args.res}^3 {args.grid} occ grid "
                                    f"(G=1), step 2*sqrt(3)/1024, sampling+rendering fwd+bwd",
                        "rays_per_gpu": args.rays, "resolution": args.res, "grid": args.grid,
-                       "samples_after_compaction": int(m_last), "parallelism": f"ray-sharded x{world}"},
+                       "samples_after_compaction": int(m_last), "parallelism": f"ray-sharded x{world}",
+                       "field": f"synthetic analytic field, {args.field} callbacks (see bench.py NativeField/TorchField)"},
         }
         if timer is not None:
             # total samples before compaction: size of the traversal output, from the estimator

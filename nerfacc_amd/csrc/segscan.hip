@@ -76,16 +76,28 @@ __global__ __launch_bounds__(256) void seg_build_tiles_kernel(const int64_t *__r
 // defeats the one-step-ahead prefetch.
 struct F4 { float v[4]; };
 
+// Where a lane stands in the current step.  `c` (step base, multiple of 256) and `safe` are wave-uniform
+// and live in scalar registers; only `off` is per lane, so element addresses are scalar base + 32-bit
+// lane offset and the range checks are 32-bit compares against scalars.
+struct Pos {
+    int64_t c;      // first element offset of the step
+    int32_t off;    // 4 * (lane in address order)
+    int32_t safe;   // offset from c of an in-range, 16 B aligned element every lane may read
+    bool valid[4];  // element c + off + j belongs to the tile's element range
+    bool any, all;
+    __device__ __forceinline__ int64_t p0() const { return c + off; }
+};
+
 template <bool VEC>
-__device__ __forceinline__ void ld4(const float *__restrict__ p, int64_t p0, int64_t ps, const bool valid[4], F4 &out)
+__device__ __forceinline__ void ld4(const float *__restrict__ p, const Pos &q, F4 &out)
 {
+    const float *b = p + q.c;
     if (VEC) {
-        const bool any = valid[0] | valid[1] | valid[2] | valid[3];
-        const float4 v = *reinterpret_cast<const float4 *>(p + (any ? p0 : ps));
+        const float4 v = *reinterpret_cast<const float4 *>(b + (q.any ? q.off : q.safe));
         out.v[0] = v.x; out.v[1] = v.y; out.v[2] = v.z; out.v[3] = v.w;
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) out.v[j] = p[valid[j] ? p0 + j : ps];
+        for (int j = 0; j < 4; ++j) out.v[j] = b[q.valid[j] ? q.off + j : q.safe];
     }
 }
 __device__ __forceinline__ float sel(const F4 &r, int j, const bool valid[4], float fill) { return valid[j] ? r.v[j] : fill; }
@@ -94,15 +106,16 @@ __device__ __forceinline__ float sel(const F4 &r, int j, const bool valid[4], fl
 // through a volatile pointer: otherwise the compiler if-converts both paths into dwordx3 + dword
 // stores for EVERY lane, which halves the store rate.
 template <bool VEC>
-__device__ __forceinline__ void store4(float *__restrict__ p, int64_t p0, const bool valid[4], const float v[4])
+__device__ __forceinline__ void store4(float *__restrict__ p, const Pos &q, const float v[4])
 {
-    if (VEC && valid[0] && valid[1] && valid[2] && valid[3]) {
-        *reinterpret_cast<float4 *>(p + p0) = make_float4(v[0], v[1], v[2], v[3]);
+    float *b = p + q.c;
+    if (VEC && q.all) {
+        *reinterpret_cast<float4 *>(b + q.off) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
-        volatile float *pv = p;
+        volatile float *pv = b;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (valid[j]) pv[p0 + j] = v[j];
+            if (q.valid[j]) pv[q.off + j] = v[j];
     }
 }
 
@@ -117,10 +130,48 @@ struct StepHeads {
     bool is_head[4];
 };
 
+// Cross-lane moves as DPP modifiers (one VALU instruction each, no LDS crossbar round trip):
+// step s < 4 shifts by 2^s inside each row of 16 lanes, step 4 broadcasts lane 15 of rows 0 / 2 to rows 1 / 3,
+// step 5 broadcasts lane 31 to rows 2 and 3.  Lanes without a source keep `old`.
+template <int S>
+__device__ __forceinline__ int32_t dpp_step(int32_t old, int32_t src)
+{
+    static_assert(S >= 0 && S < 6, "dpp_step");
+    if constexpr (S == 0) return __builtin_amdgcn_update_dpp(old, src, 0x111, 0xf, 0xf, false);       // row_shr:1
+    else if constexpr (S == 1) return __builtin_amdgcn_update_dpp(old, src, 0x112, 0xf, 0xf, false);  // row_shr:2
+    else if constexpr (S == 2) return __builtin_amdgcn_update_dpp(old, src, 0x114, 0xf, 0xf, false);  // row_shr:4
+    else if constexpr (S == 3) return __builtin_amdgcn_update_dpp(old, src, 0x118, 0xf, 0xf, false);  // row_shr:8
+    else if constexpr (S == 4) return __builtin_amdgcn_update_dpp(old, src, 0x142, 0xa, 0xf, false);  // row_bcast:15
+    else return __builtin_amdgcn_update_dpp(old, src, 0x143, 0xc, 0xf, false);                        // row_bcast:31
+}
+template <int S>
+__device__ __forceinline__ float dpp_step(float old, float src)
+{
+    return __int_as_float(dpp_step<S>(__float_as_int(old), __float_as_int(src)));
+}
+// value of the previous lane (lane 0 keeps `old`)
+__device__ __forceinline__ int32_t dpp_prev_lane(int32_t old, int32_t src)
+{
+    return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xf, 0xf, false);  // wave_shr:1
+}
+__device__ __forceinline__ float dpp_prev_lane(float old, float src)
+{
+    return __int_as_float(dpp_prev_lane(__float_as_int(old), __float_as_int(src)));
+}
+__device__ __forceinline__ int32_t last_lane(int32_t v) { return __builtin_amdgcn_readlane(v, 63); }
+__device__ __forceinline__ float last_lane(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+
+template <int S>
+__device__ __forceinline__ void heads_step(int32_t &ah, uint32_t &acc)
+{
+    const int32_t uh = dpp_step<S>(-1, ah);
+    // (a lane without a source reads -1: it keeps ah < 0 and its acc bit combines with the identity)
+    if (ah < 0) { acc |= 1u << S; ah = uh; }
+}
+
 template <int DIR>
 __device__ __forceinline__ void resolve_heads(const int32_t hj[4], const bool valid[4], int32_t carry_rid, StepHeads &hd)
 {
-    const int lane = lane_id();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int j = DIR > 0 ? k : 3 - k;
@@ -130,17 +181,15 @@ __device__ __forceinline__ void resolve_heads(const int32_t hj[4], const bool va
     }
     int32_t ah = hd.lh[3];
     uint32_t acc = 0;
-#pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        const int off = 1 << s;
-        const int32_t uh = __shfl_up(ah, off, NFA_WAVE);
-        if (lane >= off) {
-            if (ah < 0) { acc |= 1u << s; ah = uh; }
-        }
-    }
-    hd.acc = acc;
-    int32_t ph = __shfl_up(ah, 1, NFA_WAVE);
-    if (lane == 0) ph = -1;
+    heads_step<0>(ah, acc); heads_step<1>(ah, acc); heads_step<2>(ah, acc);
+    heads_step<3>(ah, acc); heads_step<4>(ah, acc); heads_step<5>(ah, acc);
+    // keep only the steps at which this lane has a source lane (so that x + identity is never formed:
+    // -0.0 would come back as +0.0)
+    const int lane = lane_id(), r = lane & 15;
+    const uint32_t has_src = (r >= 1 ? 1u : 0u) | (r >= 2 ? 2u : 0u) | (r >= 4 ? 4u : 0u) | (r >= 8 ? 8u : 0u) |
+                             ((lane & 16) ? 16u : 0u) | (lane >= 32 ? 32u : 0u);
+    hd.acc = acc & has_src;
+    int32_t ph = dpp_prev_lane(-1, ah);
     hd.open_prefix = ph < 0;
     if (ph < 0) ph = carry_rid;
     hd.ph = ph;
@@ -153,6 +202,17 @@ __device__ __forceinline__ void resolve_heads(const int32_t hj[4], const bool va
     }
 }
 
+template <int S, int N, class FI, class FC>
+__device__ __forceinline__ void values_step(const StepHeads &hd, float av[N], FI identity, FC comb)
+{
+    const bool take = (hd.acc >> S) & 1u;
+#pragma unroll
+    for (int ch = 0; ch < N; ++ch) {
+        const float uv = dpp_step<S>(identity(ch), av[ch]);
+        if (take) av[ch] = comb(ch, uv, av[ch]);
+    }
+}
+
 // Inclusive segmented scan of x (scan order) given the resolved heads; `prev[k]` is the inclusive
 // value of the element before k (in that element's own ray).  `carry` is updated to the state after
 // the step's last element.
@@ -160,7 +220,6 @@ template <int N, class FI, class FC>
 __device__ __forceinline__ void scan_values(const StepHeads &hd, const float x[4][N], float carry[N], float incl[4][N],
                                             float prev[4][N], FI identity, FC comb)
 {
-    const int lane = lane_id();
     float li[4][N];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -170,20 +229,13 @@ __device__ __forceinline__ void scan_values(const StepHeads &hd, const float x[4
     float av[N];
 #pragma unroll
     for (int ch = 0; ch < N; ++ch) av[ch] = li[3][ch];
-#pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        const int off = 1 << s;
-#pragma unroll
-        for (int ch = 0; ch < N; ++ch) {
-            const float uv = __shfl_up(av[ch], off, NFA_WAVE);
-            if ((hd.acc >> s) & 1u) av[ch] = comb(ch, uv, av[ch]);
-        }
-    }
+    values_step<0, N>(hd, av, identity, comb); values_step<1, N>(hd, av, identity, comb);
+    values_step<2, N>(hd, av, identity, comb); values_step<3, N>(hd, av, identity, comb);
+    values_step<4, N>(hd, av, identity, comb); values_step<5, N>(hd, av, identity, comb);
     float pv[N];
 #pragma unroll
     for (int ch = 0; ch < N; ++ch) {
-        pv[ch] = __shfl_up(av[ch], 1, NFA_WAVE);
-        if (lane == 0) pv[ch] = identity(ch);
+        pv[ch] = dpp_prev_lane(identity(ch), av[ch]);
         if (hd.open_prefix) pv[ch] = comb(ch, carry[ch], pv[ch]);
     }
 #pragma unroll
@@ -194,26 +246,65 @@ __device__ __forceinline__ void scan_values(const StepHeads &hd, const float x[4
             incl[k][ch] = hd.lh[k] >= 0 ? li[k][ch] : comb(ch, pv[ch], li[k][ch]);
         }
 #pragma unroll
-    for (int ch = 0; ch < N; ++ch) carry[ch] = __shfl(incl[3][ch], 63, NFA_WAVE);
+    for (int ch = 0; ch < N; ++ch) carry[ch] = last_lane(incl[3][ch]);
+}
+
+// Per-ray totals: a ray is finished where the next head appears; (prev_rid, prev) there is its id and
+// its inclusive total.  A lane has at most 4 such heads and almost always at most one, so the first is
+// handled in one predicated block and further ones behind a wave-uniform (rarely taken) branch.
+template <int N, class F>
+__device__ __forceinline__ void flush_totals(const StepHeads &hd, const float prev[4][N], F &&done)
+{
+    bool f[4];
+    int nf = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { f[k] = hd.is_head[k] && hd.prev_rid[k] >= 0; nf += f[k] ? 1 : 0; }
+    if (nf > 0) {
+        const int32_t rid = f[0] ? hd.prev_rid[0] : (f[1] ? hd.prev_rid[1] : (f[2] ? hd.prev_rid[2] : hd.prev_rid[3]));
+        float t[N];
+#pragma unroll
+        for (int ch = 0; ch < N; ++ch) t[ch] = f[0] ? prev[0][ch] : (f[1] ? prev[1][ch] : (f[2] ? prev[2][ch] : prev[3][ch]));
+        done(rid, t);
+    }
+    if (__ballot(nf > 1) != 0ull) {
+        bool seen = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (f[k] && seen) done(hd.prev_rid[k], prev[k]);
+            seen = seen || f[k];
+        }
+    }
+}
+
+__device__ __forceinline__ int64_t uniform64(int64_t v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
 // ------------------------------------------------------------------------------------------
-// The engine.  Op interface (all indices j are in ADDRESS order, 0..3, element p0 + j):
-//   static constexpr int NCH;                       scan channels
-//   __device__ float identity(int ch);
-//   __device__ float comb(int ch, float a, float b);   a = earlier in scan order
+// The engine.  Op interface (all __device__):
+//   static constexpr int NCH;                       scan channels of stage A
+//   static constexpr int NCHB;                      channels of the optional stage B (additive; 0 = none):
+//                                                   per-ray totals of values derived from stage A's results
+//   static constexpr bool NEEDS_RID;                op.pre(j, pos, valid, rid) is called before stage A's
+//                                                   inputs are read (the ray id is known before any value scan)
+//   static constexpr bool TOTALS;                   op.ray_done(rid, total[NCH]) for EVERY finished ray
+//   float identity(int ch); float comb(int ch, float a, float b);   a = earlier in scan order
 //   struct Raw;                                      registers filled straight from memory
-//   __device__ void  fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const;   loads only
-//   __device__ void  load(const Raw &r, const bool valid[4]);              derive scan inputs
-//   __device__ float x(int j, int ch);                scan input of element j
-//   __device__ void  emit(int j, int64_t pos, bool valid, bool is_head, int rid, int prev_rid,
-//                         const float incl[NCH], const float prev[NCH]);
+//   void  fetch(const Pos &q, Raw &r) const;         loads only (unconditional, raw)
+//   void  load(const Raw &r, const Pos &q);          derive scan inputs
+//   float x(int j, int ch);                          stage-A input of element j (address order)
+//   void  emit(int j, int64_t pos, bool valid, bool is_head, int rid, int prev_rid,
+//              const float incl[NCH], const float prev[NCH]);
 //        incl = inclusive scan value at this element; prev = inclusive value of the previous
-//        element in scan order (in that element's own ray; exclusive value = is_head ?
-//        identity : prev).  At a head, (prev_rid, prev) is the finished previous ray.
-//   __device__ void  store(int64_t p0, const bool valid[4]);
-//   __device__ void  ray_done(int rid, const float total[NCH]);   last ray of the tile
-//   __device__ void  empty_ray(int rid);
+//        element in scan order (in that element's own ray; exclusive value = is_head ? identity : prev)
+//   float xb(int j, int ch);  void ray_done_b(int rid, const float total[NCHB]);     (stage B)
+//   void  store(const Pos &q);
+//   void  empty_ray(int rid);
+// Everything that is the same for the whole wave (tile bounds, step base, loop control) is kept in
+// scalar registers (the tile index is made uniform with readfirstlane).
 template <int DIR, bool PIPE, class Op>
 __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__ packed_info,
                                              const longlong2 *__restrict__ tiles, int64_t n_rays, int64_t tile,
@@ -222,11 +313,11 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
     constexpr int NCH = Op::NCH;
     const int lane = lane_id();
     const int alane = DIR > 0 ? lane : 63 - lane;  // lane in address order
-    const longlong2 t_lo = tiles[tile], t_hi = tiles[tile + 1];  // one 32-byte read: no dependent chain
-    const int32_t r_lo = (int32_t)t_lo.x, r_hi = (int32_t)t_hi.x;
+    const longlong2 t_lo = tiles[tile], t_hi = tiles[tile + 1];
+    const int32_t r_lo = __builtin_amdgcn_readfirstlane((int32_t)t_lo.x), r_hi = __builtin_amdgcn_readfirstlane((int32_t)t_hi.x);
     if (r_lo >= r_hi) return;
     const int32_t n_own = r_hi - r_lo;
-    const int64_t e_lo = t_lo.y, e_hi = t_hi.y;  // chunks are contiguous: the last owned ray ends where the next tile begins
+    const int64_t e_lo = uniform64(t_lo.y), e_hi = uniform64(t_hi.y);  // chunks are contiguous: the last owned ray ends where the next tile begins
 
     // window of packed_info rows, in walk order v = 0..n_own-1: ray(v) = r_lo + v (fwd) / r_hi-1-v (rev)
     int32_t v_next = 0, win_base = 0;
@@ -253,30 +344,34 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
     const int64_t c_first = DIR > 0 ? (e_lo / SEG_CHUNK) * SEG_CHUNK : ((e_hi - 1) / SEG_CHUNK) * SEG_CHUNK;
     const int64_t n_chunks = e_hi > e_lo ? ((e_hi - 1) / SEG_CHUNK - e_lo / SEG_CHUNK + 1) : 0;
 
-    // Software pipeline: the loads of step i+1 are issued before step i is computed and stored, so a
-    // wave always has a step's worth of loads in flight and never waits for its own stores
-    // (vmcnt retires in order: loads issued BEFORE the stores can be waited for without them).
     auto chunk_base = [&](int64_t ci) { return c_first + (DIR > 0 ? ci : -ci) * SEG_CHUNK; };
-    // an address every lane may read: the first in-range multiple of 4 of the step
-    auto ld_safe = [&](int64_t c) { return c > e_lo ? c : (e_lo / 4) * 4; };
-    auto chunk_valid = [&](int64_t p0, bool valid[4]) {
+    auto make_pos = [&](int64_t c, Pos &q) {
+        // range of the step in element offsets from c, clamped to [0, 256]: scalar
+        const int64_t lo64 = e_lo - c, hi64 = e_hi - c;
+        const int32_t d_lo = lo64 < 0 ? 0 : (lo64 > SEG_CHUNK ? SEG_CHUNK : (int32_t)lo64);
+        const int32_t d_hi = hi64 < 0 ? 0 : (hi64 > SEG_CHUNK ? SEG_CHUNK : (int32_t)hi64);
+        q.c = c;
+        q.off = 4 * alane;
+        q.safe = (d_lo / 4) * 4;  // first in-range multiple of 4 (every step holds at least one element)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) valid[j] = (p0 + j >= e_lo) && (p0 + j < e_hi);
+        for (int j = 0; j < 4; ++j) q.valid[j] = (q.off + j >= d_lo) && (q.off + j < d_hi);
+        q.any = (q.off + 3 >= d_lo) && (q.off < d_hi);
+        q.all = (q.off >= d_lo) && (q.off + 3 < d_hi);
     };
+    // Software pipeline (PIPE): the loads of step i+1 are issued before step i is computed and stored
+    // (vmcnt retires in order: loads issued BEFORE the stores can be waited for without them).
     typename Op::Raw raw_cur, raw_next;
     if (n_chunks > 0) {
-        bool v0[4];
-        const int64_t p0 = chunk_base(0) + 4 * alane;
-        chunk_valid(p0, v0);
-        op.fetch(p0, ld_safe(chunk_base(0)), v0, raw_cur);
+        Pos q0;
+        make_pos(chunk_base(0), q0);
+        op.fetch(q0, raw_cur);
     }
     for (int64_t ci = 0; ci < n_chunks; ++ci) {
         const int64_t c = chunk_base(ci);
         if (PIPE && ci + 1 < n_chunks) {
-            bool vn[4];
-            const int64_t pn = chunk_base(ci + 1) + 4 * alane;
-            chunk_valid(pn, vn);
-            op.fetch(pn, ld_safe(chunk_base(ci + 1)), vn, raw_next);
+            Pos qn;
+            make_pos(chunk_base(ci + 1), qn);
+            op.fetch(qn, raw_next);
         }
         // ---- segment heads of this chunk -> LDS
         *reinterpret_cast<int4 *>(hid + 4 * lane) = make_int4(-1, -1, -1, -1);
@@ -302,20 +397,19 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
         const int32_t hj[4] = {h4.x, h4.y, h4.z, h4.w};
 
         // ---- this step's data
-        const int64_t p0 = c + 4 * alane;
-        bool valid[4];
-        chunk_valid(p0, valid);
-        if (!PIPE && ci > 0) op.fetch(p0, ld_safe(c), valid, raw_cur);
-        op.load(raw_cur, valid);
+        Pos q;
+        make_pos(c, q);
+        if (!PIPE && ci > 0) op.fetch(q, raw_cur);
+        op.load(raw_cur, q);
 
         // ---- segment structure of this step: ray id of every element (scan order k, address j = DIR>0 ? k : 3-k)
         StepHeads hd;
-        resolve_heads<DIR>(hj, valid, carry_rid, hd);
+        resolve_heads<DIR>(hj, q.valid, carry_rid, hd);
         if constexpr (Op::NEEDS_RID) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int j = DIR > 0 ? k : 3 - k;
-                op.pre(j, p0 + j, valid[j], hd.rid[k]);
+                op.pre(j, q.p0() + j, q.valid[j], hd.rid[k]);
             }
         }
         // ---- stage A: scan of op.x, results to op.emit
@@ -325,35 +419,31 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
             for (int k = 0; k < 4; ++k) {
                 const int j = DIR > 0 ? k : 3 - k;
 #pragma unroll
-                for (int ch = 0; ch < NCH; ++ch) xa[k][ch] = valid[j] ? op.x(j, ch) : op.identity(ch);
+                for (int ch = 0; ch < NCH; ++ch) xa[k][ch] = q.valid[j] ? op.x(j, ch) : op.identity(ch);
             }
             scan_values<NCH>(hd, xa, carry, incl, prev, [&](int ch) { return op.identity(ch); },
                              [&](int ch, float u, float v) { return op.comb(ch, u, v); });
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int j = DIR > 0 ? k : 3 - k;
-                op.emit(j, p0 + j, valid[j], hd.is_head[k], hd.rid[k], hd.prev_rid[k], incl[k], prev[k]);
+                op.emit(j, q.p0() + j, q.valid[j], hd.is_head[k], hd.rid[k], hd.prev_rid[k], incl[k], prev[k]);
             }
+            if constexpr (Op::TOTALS) flush_totals<NCH>(hd, prev, [&](int32_t rid, const float *t) { op.ray_done(rid, t); });
         }
-        // ---- stage B (optional): additive scan of values derived from stage A's results
+        // ---- stage B (optional): per-ray totals of values derived from stage A's results
         if constexpr (Op::NCHB > 0) {
-            constexpr int NB = Op::NCHB > 0 ? Op::NCHB : 1;
-            float xb[4][NB], incl[4][NB], prev[4][NB];
+            float xb[4][NCB], incl[4][NCB], prev[4][NCB];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int j = DIR > 0 ? k : 3 - k;
 #pragma unroll
-                for (int ch = 0; ch < NB; ++ch) xb[k][ch] = valid[j] ? op.xb(j, ch) : 0.0f;
+                for (int ch = 0; ch < NCB; ++ch) xb[k][ch] = q.valid[j] ? op.xb(j, ch) : 0.0f;
             }
-            scan_values<NB>(hd, xb, carry_b, incl, prev, [](int) { return 0.0f; }, [](int, float u, float v) { return u + v; });
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int j = DIR > 0 ? k : 3 - k;
-                op.emit_b(j, p0 + j, valid[j], hd.is_head[k], hd.rid[k], hd.prev_rid[k], incl[k], prev[k]);
-            }
+            scan_values<NCB>(hd, xb, carry_b, incl, prev, [](int) { return 0.0f; }, [](int, float u, float v) { return u + v; });
+            flush_totals<NCB>(hd, prev, [&](int32_t rid, const float *t) { op.ray_done_b(rid, t); });
         }
-        op.store(p0, valid);
-        carry_rid = __shfl(hd.rid[3], 63, NFA_WAVE);
+        op.store(q);
+        carry_rid = last_lane(hd.rid[3]);
         if (PIPE) raw_cur = raw_next;
     }
     // remaining owned rays are all empty (their start equals e_hi / e_lo)
@@ -366,7 +456,7 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
         break;
     }
     if (carry_rid >= 0 && lane == 0) {
-        op.ray_done(carry_rid, carry);
+        if constexpr (Op::TOTALS) op.ray_done(carry_rid, carry);
         if constexpr (Op::NCHB > 0) op.ray_done_b(carry_rid, carry_b);
     }
 }
@@ -377,7 +467,7 @@ __global__ __launch_bounds__(64 * SEG_WAVES_PER_BLOCK) void seg_kernel(Op op, co
                                                                        int64_t n_rays, int64_t n_tiles)
 {
     __shared__ __attribute__((aligned(16))) int32_t hid_all[SEG_WAVES_PER_BLOCK * SEG_CHUNK];
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t tile = (int64_t)blockIdx.x * SEG_WAVES_PER_BLOCK + wave;
     if (tile >= n_tiles) return;
     seg_run_tile<DIR, PIPE>(op, packed_info, tiles, n_rays, tile, hid_all + wave * SEG_CHUNK);
@@ -406,6 +496,7 @@ struct OpBase1 {  // one additive channel
     static constexpr int NCH = 1;
     static constexpr int NCHB = 0;
     static constexpr bool NEEDS_RID = false;
+    static constexpr bool TOTALS = false;
     __device__ __forceinline__ float identity(int) const { return 0.0f; }
     __device__ __forceinline__ float comb(int, float a, float b) const { return a + b; }
     __device__ __forceinline__ void ray_done(int, const float *) const {}
@@ -418,15 +509,17 @@ struct ScanOp {
     static constexpr int NCH = 1;
     static constexpr int NCHB = 0;
     static constexpr bool NEEDS_RID = false;
+    static constexpr bool TOTALS = false;
     struct Raw { F4 x; };
     const float *in;
     float *out;
     float xin[4], res[4];
     __device__ __forceinline__ float identity(int) const { return PROD ? 1.0f : 0.0f; }
     __device__ __forceinline__ float comb(int, float a, float b) const { return PROD ? a * b : a + b; }
-    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const { ld4<VEC>(in, p0, ps, valid, r.x); }
-    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const { ld4<VEC>(in, q, r.x); }
+    __device__ __forceinline__ void load(const Raw &r, const Pos &pos)
     {
+        const bool *valid = pos.valid;
 #pragma unroll
         for (int j = 0; j < 4; ++j) xin[j] = sel(r.x, j, valid, identity(0));
     }
@@ -435,7 +528,7 @@ struct ScanOp {
     {
         res[j] = EXCL ? (is_head ? identity(0) : prev[0]) : incl[0];
     }
-    __device__ __forceinline__ void store(int64_t p0, const bool valid[4]) { store4<VEC>(out, p0, valid, res); }
+    __device__ __forceinline__ void store(const Pos &q) { store4<VEC>(out, q, res); }
     __device__ __forceinline__ void ray_done(int, const float *) const {}
     __device__ __forceinline__ void empty_ray(int) const {}
 };
@@ -448,14 +541,15 @@ struct ProdBwdOp : OpBase1 {
     const float *in, *outv, *g;
     float *gin;
     float q[4], den[4], res[4];
-    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
+    __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
-        ld4<VEC>(outv, p0, ps, valid, r.o);
-        ld4<VEC>(g, p0, ps, valid, r.g);
-        ld4<VEC>(in, p0, ps, valid, r.in);
+        ld4<VEC>(outv, q, r.o);
+        ld4<VEC>(g, q, r.g);
+        ld4<VEC>(in, q, r.in);
     }
-    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    __device__ __forceinline__ void load(const Raw &r, const Pos &pos)
     {
+        const bool *valid = pos.valid;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { q[j] = sel(r.g, j, valid, 0.0f) * sel(r.o, j, valid, 0.0f); den[j] = sel(r.in, j, valid, 1.0f); }
     }
@@ -465,7 +559,7 @@ struct ProdBwdOp : OpBase1 {
         const float sres = EXCL ? (is_head ? 0.0f : prev[0]) : incl[0];
         res[j] = sres / fmaxf(den[j], 1e-10f);
     }
-    __device__ __forceinline__ void store(int64_t p0, const bool valid[4]) { store4<VEC>(gin, p0, valid, res); }
+    __device__ __forceinline__ void store(const Pos &q) { store4<VEC>(gin, q, res); }
 };
 
 // ---- transmittance / alpha / weights from density, volrend.py:256-264, :358-362
@@ -475,15 +569,16 @@ struct DensityFwdOp : OpBase1 {
     const float *ts, *te, *sig, *prefix;
     float *w, *tr, *al;
     float xs[4], pf[4], rw[4], rt[4], ra[4];
-    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
+    __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
-        ld4<VEC>(ts, p0, ps, valid, r.a);
-        ld4<VEC>(te, p0, ps, valid, r.b);
-        ld4<VEC>(sig, p0, ps, valid, r.s);
-        if (prefix) ld4<VEC>(prefix, p0, ps, valid, r.pf);
+        ld4<VEC>(ts, q, r.a);
+        ld4<VEC>(te, q, r.b);
+        ld4<VEC>(sig, q, r.s);
+        if (prefix) ld4<VEC>(prefix, q, r.pf);
     }
-    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    __device__ __forceinline__ void load(const Raw &r, const Pos &pos)
     {
+        const bool *valid = pos.valid;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             xs[j] = valid[j] ? r.s.v[j] * (r.b.v[j] - r.a.v[j]) : 0.0f;
@@ -499,11 +594,14 @@ struct DensityFwdOp : OpBase1 {
         const float a = 1.0f - expf(-xs[j]);
         rt[j] = T; ra[j] = a; rw[j] = T * a;
     }
-    __device__ __forceinline__ void store(int64_t p0, const bool valid[4])
+    __device__ __forceinline__ void store(const Pos &q)
     {
-        if (w) store4<VEC>(w, p0, valid, rw);
-        if (tr) store4<VEC>(tr, p0, valid, rt);
-        if (al) store4<VEC>(al, p0, valid, ra);
+        const bool *valid = q.valid;
+        const int64_t p0 = q.p0();
+        (void)valid; (void)p0;
+        if (w) store4<VEC>(w, q, rw);
+        if (tr) store4<VEC>(tr, q, rt);
+        if (al) store4<VEC>(al, q, ra);
     }
 };
 
@@ -513,19 +611,21 @@ struct AlphaFwdOp {
     static constexpr int NCH = 1;
     static constexpr int NCHB = 0;
     static constexpr bool NEEDS_RID = false;
+    static constexpr bool TOTALS = false;
     struct Raw { F4 a, pf; };
     const float *al, *prefix;
     float *w, *tr;
     float a4[4], pf[4], rw[4], rt[4];
     __device__ __forceinline__ float identity(int) const { return 1.0f; }
     __device__ __forceinline__ float comb(int, float a, float b) const { return a * b; }
-    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
+    __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
-        ld4<VEC>(al, p0, ps, valid, r.a);
-        if (prefix) ld4<VEC>(prefix, p0, ps, valid, r.pf);
+        ld4<VEC>(al, q, r.a);
+        if (prefix) ld4<VEC>(prefix, q, r.pf);
     }
-    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    __device__ __forceinline__ void load(const Raw &r, const Pos &pos)
     {
+        const bool *valid = pos.valid;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { a4[j] = sel(r.a, j, valid, 0.0f); pf[j] = prefix ? r.pf.v[j] : 1.0f; }
     }
@@ -536,10 +636,13 @@ struct AlphaFwdOp {
         if (prefix) T *= pf[j];
         rt[j] = T; rw[j] = T * a4[j];
     }
-    __device__ __forceinline__ void store(int64_t p0, const bool valid[4])
+    __device__ __forceinline__ void store(const Pos &q)
     {
-        if (w) store4<VEC>(w, p0, valid, rw);
-        if (tr) store4<VEC>(tr, p0, valid, rt);
+        const bool *valid = q.valid;
+        const int64_t p0 = q.p0();
+        (void)valid; (void)p0;
+        if (w) store4<VEC>(w, q, rw);
+        if (tr) store4<VEC>(tr, q, rt);
     }
     __device__ __forceinline__ void ray_done(int, const float *) const {}
     __device__ __forceinline__ void empty_ray(int) const {}
@@ -552,18 +655,19 @@ struct DensityBwdOp : OpBase1 {
     const float *ts, *te, *tr, *al, *gw, *gt, *ga;
     float *gsig, *gx;
     float T[4], A[4], GW[4], GA[4], dlt[4], q[4], rs[4], rx[4];
-    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
+    __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
-        ld4<VEC>(ts, p0, ps, valid, r.a);
-        ld4<VEC>(te, p0, ps, valid, r.b);
-        ld4<VEC>(tr, p0, ps, valid, r.T);
-        ld4<VEC>(al, p0, ps, valid, r.A);
-        if (gw) ld4<VEC>(gw, p0, ps, valid, r.gw);
-        if (gt) ld4<VEC>(gt, p0, ps, valid, r.gt);
-        if (ga) ld4<VEC>(ga, p0, ps, valid, r.ga);
+        ld4<VEC>(ts, q, r.a);
+        ld4<VEC>(te, q, r.b);
+        ld4<VEC>(tr, q, r.T);
+        ld4<VEC>(al, q, r.A);
+        if (gw) ld4<VEC>(gw, q, r.gw);
+        if (gt) ld4<VEC>(gt, q, r.gt);
+        if (ga) ld4<VEC>(ga, q, r.ga);
     }
-    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    __device__ __forceinline__ void load(const Raw &r, const Pos &pos)
     {
+        const bool *valid = pos.valid;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             T[j] = sel(r.T, j, valid, 0.0f); A[j] = sel(r.A, j, valid, 0.0f);
@@ -582,10 +686,13 @@ struct DensityBwdOp : OpBase1 {
         const float B = GW[j] * T[j] * om + GA[j] * om - E;
         rx[j] = B; rs[j] = dlt[j] * B;
     }
-    __device__ __forceinline__ void store(int64_t p0, const bool valid[4])
+    __device__ __forceinline__ void store(const Pos &q)
     {
-        if (gsig) store4<VEC>(gsig, p0, valid, rs);
-        if (gx) store4<VEC>(gx, p0, valid, rx);
+        const bool *valid = q.valid;
+        const int64_t p0 = q.p0();
+        (void)valid; (void)p0;
+        if (gsig) store4<VEC>(gsig, q, rs);
+        if (gx) store4<VEC>(gx, q, rx);
     }
 };
 
@@ -596,15 +703,16 @@ struct AlphaBwdOp : OpBase1 {
     const float *al, *tr, *gw, *gt;
     float *galpha;
     float T[4], A[4], GW[4], q[4], res[4];
-    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
+    __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
-        ld4<VEC>(tr, p0, ps, valid, r.T);
-        ld4<VEC>(al, p0, ps, valid, r.A);
-        if (gw) ld4<VEC>(gw, p0, ps, valid, r.gw);
-        if (gt) ld4<VEC>(gt, p0, ps, valid, r.gt);
+        ld4<VEC>(tr, q, r.T);
+        ld4<VEC>(al, q, r.A);
+        if (gw) ld4<VEC>(gw, q, r.gw);
+        if (gt) ld4<VEC>(gt, q, r.gt);
     }
-    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    __device__ __forceinline__ void load(const Raw &r, const Pos &pos)
     {
+        const bool *valid = pos.valid;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             T[j] = sel(r.T, j, valid, 0.0f); A[j] = sel(r.A, j, valid, 0.0f);
@@ -619,7 +727,7 @@ struct AlphaBwdOp : OpBase1 {
         const float E = is_head ? 0.0f : prev[0];
         res[j] = GW[j] * T[j] - E / fmaxf(1.0f - A[j], 1e-10f);
     }
-    __device__ __forceinline__ void store(int64_t p0, const bool valid[4]) { store4<VEC>(galpha, p0, valid, res); }
+    __device__ __forceinline__ void store(const Pos &q) { store4<VEC>(galpha, q, res); }
 };
 
 // ---- visibility mask, volrend.py:412-418 / :474-480.  COUNT adds the per-ray number of visible
@@ -629,6 +737,7 @@ struct VisibilityOp {
     static constexpr int NCH = 1;
     static constexpr int NCHB = COUNT ? 1 : 0;
     static constexpr bool NEEDS_RID = false;
+    static constexpr bool TOTALS = false;
     struct Raw { F4 s, pf, a, b; };
     const float *ts, *te, *val, *prefix;
     float eps, thre;
@@ -638,17 +747,18 @@ struct VisibilityOp {
     uint8_t m[4];
     __device__ __forceinline__ float identity(int) const { return DENSITY ? 0.0f : 1.0f; }
     __device__ __forceinline__ float comb(int, float a, float b) const { return DENSITY ? a + b : a * b; }
-    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
+    __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
-        ld4<VEC>(val, p0, ps, valid, r.s);
-        if (prefix) ld4<VEC>(prefix, p0, ps, valid, r.pf);
+        ld4<VEC>(val, q, r.s);
+        if (prefix) ld4<VEC>(prefix, q, r.pf);
         if (DENSITY) {
-            ld4<VEC>(ts, p0, ps, valid, r.a);
-            ld4<VEC>(te, p0, ps, valid, r.b);
+            ld4<VEC>(ts, q, r.a);
+            ld4<VEC>(te, q, r.b);
         }
     }
-    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    __device__ __forceinline__ void load(const Raw &r, const Pos &pos)
     {
+        const bool *valid = pos.valid;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             pf[j] = prefix ? r.pf.v[j] : 1.0f;
@@ -667,20 +777,20 @@ struct VisibilityOp {
         m[j] = (valid && v) ? 1 : 0;
     }
     __device__ __forceinline__ float xb(int j, int) const { return (float)m[j]; }
-    __device__ __forceinline__ void emit_b(int, int64_t, bool, bool is_head, int, int prev_rid, const float *, const float prev[1]) const
-    {
-        if (is_head && prev_rid >= 0) cnts[prev_rid] = (int64_t)prev[0];
-    }
     __device__ __forceinline__ void ray_done_b(int rid, const float tot[1]) const { cnts[rid] = (int64_t)tot[0]; }
-    __device__ __forceinline__ void store(int64_t p0, const bool valid[4])
+    __device__ __forceinline__ void store(const Pos &q)
     {
-        if (VEC && valid[0] && valid[1] && valid[2] && valid[3]) {
-            *reinterpret_cast<uchar4 *>(vis + p0) = make_uchar4(m[0], m[1], m[2], m[3]);
+        const bool *valid = q.valid;
+        const int64_t p0 = q.p0();
+        (void)valid; (void)p0;
+        uint8_t *b = vis + q.c;
+        if (VEC && q.all) {
+            *reinterpret_cast<uchar4 *>(b + q.off) = make_uchar4(m[0], m[1], m[2], m[3]);
         } else {
-            volatile uint8_t *pv = vis;
+            volatile uint8_t *pv = b;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (valid[j]) pv[p0 + j] = m[j];
+                if (q.valid[j]) pv[q.off + j] = m[j];
         }
     }
     __device__ __forceinline__ void ray_done(int, const float *) const {}
@@ -691,15 +801,15 @@ struct VisibilityOp {
 };
 
 struct U4 { uint32_t w; };  // 4 mask bytes, raw
-__device__ __forceinline__ void load_mask4(const uint8_t *vis, bool vec, int64_t p0, int64_t ps, const bool valid[4], U4 &m)
+__device__ __forceinline__ void load_mask4(const uint8_t *vis, bool vec, const Pos &q, U4 &m)
 {
+    const uint8_t *b = vis + q.c;
     if (vec) {
-        const bool any = valid[0] | valid[1] | valid[2] | valid[3];
-        m.w = *reinterpret_cast<const uint32_t *>(vis + (any ? p0 : ps));
+        m.w = *reinterpret_cast<const uint32_t *>(b + (q.any ? q.off : q.safe));
     } else {
         uint32_t w = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w |= (uint32_t)vis[valid[j] ? p0 + j : ps] << (8 * j);
+        for (int j = 0; j < 4; ++j) w |= (uint32_t)b[q.valid[j] ? q.off + j : q.safe] << (8 * j);
         m.w = w;
     }
 }
@@ -719,14 +829,15 @@ struct CompactOp : OpBase1 {
     int64_t *o_ri;
     float *o_ts, *o_te;
     float m[4], a[4], b[4];
-    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
+    __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
-        load_mask4(vis, vis_vec != 0, p0, ps, valid, r.m);
-        ld4<VEC>(ts, p0, ps, valid, r.a);
-        ld4<VEC>(te, p0, ps, valid, r.b);
+        load_mask4(vis, vis_vec != 0, q, r.m);
+        ld4<VEC>(ts, q, r.a);
+        ld4<VEC>(te, q, r.b);
     }
-    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    __device__ __forceinline__ void load(const Raw &r, const Pos &pos)
     {
+        const bool *valid = pos.valid;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { m[j] = mask_sel(r.m, j, valid); a[j] = r.a.v[j]; b[j] = r.b.v[j]; }
     }
@@ -738,7 +849,7 @@ struct CompactOp : OpBase1 {
             o_ri[dst] = rid; o_ts[dst] = a[j]; o_te[dst] = b[j];
         }
     }
-    __device__ __forceinline__ void store(int64_t, const bool *) const {}
+    __device__ __forceinline__ void store(const Pos &) const {}
 };
 
 // ---- per-ray accumulation of w * values[:, d0:d0+C], volrend.py:532-547
@@ -747,6 +858,7 @@ struct AccumOp {
     static constexpr int NCH = C;
     static constexpr int NCHB = 0;
     static constexpr bool NEEDS_RID = false;
+    static constexpr bool TOTALS = true;
     struct Raw { F4 w; float v[4][C]; };
     const float *w, *vals;  // vals may be null (C == 1): accumulate w
     int32_t D, d0;
@@ -755,18 +867,19 @@ struct AccumOp {
     float xv[4][C];
     __device__ __forceinline__ float identity(int) const { return 0.0f; }
     __device__ __forceinline__ float comb(int, float a, float b) const { return a + b; }
-    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
+    __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
-        ld4<VEC>(w, p0, ps, valid, r.w);
+        ld4<VEC>(w, q, r.w);
         if (vals) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int ch = 0; ch < C; ++ch) r.v[j][ch] = vals[(valid[j] ? p0 + j : ps) * D + d0 + ch];
+                for (int ch = 0; ch < C; ++ch) r.v[j][ch] = vals[(q.c + (q.valid[j] ? q.off + j : q.safe)) * D + d0 + ch];
         }
     }
-    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    __device__ __forceinline__ void load(const Raw &r, const Pos &pos)
     {
+        const bool *valid = pos.valid;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -781,11 +894,8 @@ struct AccumOp {
             *o = accumulate ? *o + tot[ch] : tot[ch];
         }
     }
-    __device__ __forceinline__ void emit(int, int64_t, bool, bool is_head, int, int prev_rid, const float *, const float prev[C]) const
-    {
-        if (is_head && prev_rid >= 0) put(prev_rid, prev);
-    }
-    __device__ __forceinline__ void store(int64_t, const bool *) const {}
+    __device__ __forceinline__ void emit(int, int64_t, bool, bool, int, int, const float *, const float *) const {}
+    __device__ __forceinline__ void store(const Pos &) const {}
     __device__ __forceinline__ void ray_done(int rid, const float tot[C]) const { put(rid, tot); }
     __device__ __forceinline__ void empty_ray(int rid) const
     {
@@ -803,18 +913,18 @@ struct AccumBwdOp : OpBase1 {
     int first;  // first channel group: g_w is written, later groups add to it
     float *gw, *gv;
     float ww[4], res[4], vv[4][C];
-    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
+    __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
-        ld4<VEC>(w, p0, ps, valid, r.w);
-        if (gw && !first) ld4<VEC>(gw, p0, ps, valid, r.g);
+        ld4<VEC>(w, q, r.w);
+        if (gw && !first) ld4<VEC>(gw, q, r.g);
         if (vals) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int ch = 0; ch < C; ++ch) r.v[j][ch] = vals[(valid[j] ? p0 + j : ps) * D + d0 + ch];
+                for (int ch = 0; ch < C; ++ch) r.v[j][ch] = vals[(q.c + (q.valid[j] ? q.off + j : q.safe)) * D + d0 + ch];
         }
     }
-    __device__ __forceinline__ void load(const Raw &r, const bool *)
+    __device__ __forceinline__ void load(const Raw &r, const Pos &)
     {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -839,46 +949,48 @@ struct AccumBwdOp : OpBase1 {
             }
         }
     }
-    __device__ __forceinline__ void store(int64_t p0, const bool valid[4])
+    __device__ __forceinline__ void store(const Pos &q)
     {
-        if (gw) store4<VEC>(gw, p0, valid, res);
+        const bool *valid = q.valid;
+        const int64_t p0 = q.p0();
+        (void)valid; (void)p0;
+        if (gw) store4<VEC>(gw, q, res);
     }
 };
 
 // 4 x rgb (12 consecutive floats at 3*p), raw.  With VEC the 48 bytes are three aligned 16 B loads from
 // p0 when all 4 elements are valid, else from the step's base (always inside the array); the few
 // lanes that straddle a range end re-read their valid elements one by one in fix_rgb12.
-__device__ __forceinline__ void load_rgb12(const float *rgb, bool vec, int64_t p0, int64_t ps, const bool valid[4], float c[12])
+__device__ __forceinline__ void load_rgb12(const float *rgb, bool vec, const Pos &q, float c[12])
 {
+    const float *b = rgb + 3 * q.c;
     if (vec) {
-        const bool all = valid[0] & valid[1] & valid[2] & valid[3];
-        const float4 *q = reinterpret_cast<const float4 *>(rgb + 3 * (all ? p0 : ps));
-        const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+        const float4 *v = reinterpret_cast<const float4 *>(b + 3 * (q.all ? q.off : q.safe));
+        const float4 q0 = v[0], q1 = v[1], q2 = v[2];
         c[0] = q0.x; c[1] = q0.y; c[2] = q0.z; c[3] = q0.w; c[4] = q1.x; c[5] = q1.y;
         c[6] = q1.z; c[7] = q1.w; c[8] = q2.x; c[9] = q2.y; c[10] = q2.z; c[11] = q2.w;
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) c[3 * j + k] = rgb[3 * (valid[j] ? p0 + j : ps) + k];
+            for (int k = 0; k < 3; ++k) c[3 * j + k] = b[3 * (q.valid[j] ? q.off + j : q.safe) + k];
     }
 }
-__device__ __forceinline__ void fix_rgb12(const float *rgb, bool vec, int64_t p0, const bool valid[4], const float raw[12], float c[12])
+__device__ __forceinline__ void fix_rgb12(const float *rgb, bool vec, const Pos &q, const float raw[12], float c[12])
 {
-    const bool all = valid[0] & valid[1] & valid[2] & valid[3];
-    const bool any = valid[0] | valid[1] | valid[2] | valid[3];
 #pragma unroll
     for (int k = 0; k < 12; ++k) c[k] = raw[k];
-    if (vec && any && !all) {  // rare: first / last lane of a range
+    if (vec && q.any && !q.all) {  // rare: first / last lane of a range
+        const float *b = rgb + 3 * q.c;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) c[3 * j + k] = valid[j] ? rgb[3 * (p0 + j) + k] : 0.0f;
+            for (int k = 0; k < 3; ++k) c[3 * j + k] = q.valid[j] ? b[3 * (q.off + j) + k] : 0.0f;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) c[3 * j + k] = valid[j] ? c[3 * j + k] : 0.0f;
+        for (int k = 0; k < 3; ++k) c[3 * j + k] = q.valid[j] ? c[3 * j + k] : 0.0f;
 }
 
 // ---- the three accumulations of `rendering` fused: colours(3), opacity, depth  (volrend.py:140-151)
@@ -887,24 +999,25 @@ struct RenderAccumOp {
     static constexpr int NCH = 5;
     static constexpr int NCHB = 0;
     static constexpr bool NEEDS_RID = false;
-    struct Raw { F4 w, a, b; float c[12]; int64_t p0; };
+    static constexpr bool TOTALS = true;
+    struct Raw { F4 w, a, b; float c[12]; };
     const float *w, *rgb, *ts, *te;
     float *colors, *opac, *depth;
     float xv[4][5];
     __device__ __forceinline__ float identity(int) const { return 0.0f; }
     __device__ __forceinline__ float comb(int, float a, float b) const { return a + b; }
-    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
+    __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
-        ld4<VEC>(w, p0, ps, valid, r.w);
-        ld4<VEC>(ts, p0, ps, valid, r.a);
-        ld4<VEC>(te, p0, ps, valid, r.b);
-        load_rgb12(rgb, VEC, p0, ps, valid, r.c);
-        r.p0 = p0;
+        ld4<VEC>(w, q, r.w);
+        ld4<VEC>(ts, q, r.a);
+        ld4<VEC>(te, q, r.b);
+        load_rgb12(rgb, VEC, q, r.c);
     }
-    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    __device__ __forceinline__ void load(const Raw &r, const Pos &pos)
     {
+        const bool *valid = pos.valid;
         float c[12];
-        fix_rgb12(rgb, VEC, r.p0, valid, r.c, c);
+        fix_rgb12(rgb, VEC, pos, r.c, c);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float ww = sel(r.w, j, valid, 0.0f);
@@ -919,11 +1032,8 @@ struct RenderAccumOp {
         colors[3 * (int64_t)rid] = t[0]; colors[3 * (int64_t)rid + 1] = t[1]; colors[3 * (int64_t)rid + 2] = t[2];
         opac[rid] = t[3]; depth[rid] = t[4];
     }
-    __device__ __forceinline__ void emit(int, int64_t, bool, bool is_head, int, int prev_rid, const float *, const float prev[5]) const
-    {
-        if (is_head && prev_rid >= 0) put(prev_rid, prev);
-    }
-    __device__ __forceinline__ void store(int64_t, const bool *) const {}
+    __device__ __forceinline__ void emit(int, int64_t, bool, bool, int, int, const float *, const float *) const {}
+    __device__ __forceinline__ void store(const Pos &) const {}
     __device__ __forceinline__ void ray_done(int rid, const float t[5]) const { put(rid, t); }
     __device__ __forceinline__ void empty_ray(int rid) const
     {
@@ -934,25 +1044,25 @@ struct RenderAccumOp {
 
 template <bool VEC>
 struct RenderAccumBwdOp : OpBase1 {
-    struct Raw { F4 w, a, b; float c[12]; int64_t p0; };
+    struct Raw { F4 w, a, b; float c[12]; };
     const float *w, *rgb, *ts, *te, *gc, *go, *gd;
     float *gw, *grgb;
     float ww[4], mid[4], res[4], c[12], gr[12];
     bool full;
-    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
+    __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
-        ld4<VEC>(w, p0, ps, valid, r.w);
-        ld4<VEC>(ts, p0, ps, valid, r.a);
-        ld4<VEC>(te, p0, ps, valid, r.b);
-        load_rgb12(rgb, VEC, p0, ps, valid, r.c);
-        r.p0 = p0;
+        ld4<VEC>(w, q, r.w);
+        ld4<VEC>(ts, q, r.a);
+        ld4<VEC>(te, q, r.b);
+        load_rgb12(rgb, VEC, q, r.c);
     }
-    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    __device__ __forceinline__ void load(const Raw &r, const Pos &pos)
     {
+        const bool *valid = pos.valid;
         full = VEC && valid[0] && valid[1] && valid[2] && valid[3];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { ww[j] = r.w.v[j]; mid[j] = (r.a.v[j] + r.b.v[j]) / 2.0f; }
-        fix_rgb12(rgb, VEC, r.p0, valid, r.c, c);
+        fix_rgb12(rgb, VEC, pos, r.c, c);
     }
     __device__ __forceinline__ float x(int, int) const { return 0.0f; }
     __device__ __forceinline__ void emit(int j, int64_t, bool valid, bool, int rid, int, const float *, const float *)
@@ -970,9 +1080,12 @@ struct RenderAccumBwdOp : OpBase1 {
         }
         res[j] = g;
     }
-    __device__ __forceinline__ void store(int64_t p0, const bool valid[4])
+    __device__ __forceinline__ void store(const Pos &q)
     {
-        if (gw) store4<VEC>(gw, p0, valid, res);
+        const bool *valid = q.valid;
+        const int64_t p0 = q.p0();
+        (void)valid; (void)p0;
+        if (gw) store4<VEC>(gw, q, res);
         if (grgb) {
             if (full) {
                 float4 *q = reinterpret_cast<float4 *>(grgb + 3 * p0);
@@ -998,21 +1111,21 @@ struct RenderAccumBwdOp : OpBase1 {
 template <bool VEC>
 struct RenderFusedFwdOp : OpBase1 {
     static constexpr int NCHB = 5;
-    struct Raw { F4 a, b, s; float c[12]; int64_t p0; };
+    struct Raw { F4 a, b, s; float c[12]; };
     const float *ts, *te, *sig, *rgb;
     float *w, *tr, *al, *colors, *opac, *depth;
     float xs[4], mid[4], rw[4], rt[4], ra[4], c[12];
-    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
+    __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
-        ld4<VEC>(ts, p0, ps, valid, r.a);
-        ld4<VEC>(te, p0, ps, valid, r.b);
-        ld4<VEC>(sig, p0, ps, valid, r.s);
-        load_rgb12(rgb, VEC, p0, ps, valid, r.c);
-        r.p0 = p0;
+        ld4<VEC>(ts, q, r.a);
+        ld4<VEC>(te, q, r.b);
+        ld4<VEC>(sig, q, r.s);
+        load_rgb12(rgb, VEC, q, r.c);
     }
-    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    __device__ __forceinline__ void load(const Raw &r, const Pos &pos)
     {
-        fix_rgb12(rgb, VEC, r.p0, valid, r.c, c);
+        const bool *valid = pos.valid;
+        fix_rgb12(rgb, VEC, pos, r.c, c);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             xs[j] = valid[j] ? r.s.v[j] * (r.b.v[j] - r.a.v[j]) : 0.0f;
@@ -1036,21 +1149,20 @@ struct RenderFusedFwdOp : OpBase1 {
         colors[3 * (int64_t)rid] = t[0]; colors[3 * (int64_t)rid + 1] = t[1]; colors[3 * (int64_t)rid + 2] = t[2];
         opac[rid] = t[3]; depth[rid] = t[4];
     }
-    __device__ __forceinline__ void emit_b(int, int64_t, bool, bool is_head, int, int prev_rid, const float *, const float prev[5]) const
-    {
-        if (is_head && prev_rid >= 0) put(prev_rid, prev);
-    }
     __device__ __forceinline__ void ray_done_b(int rid, const float t[5]) const { put(rid, t); }
     __device__ __forceinline__ void empty_ray(int rid) const
     {
         const float z[5] = {0, 0, 0, 0, 0};
         put(rid, z);
     }
-    __device__ __forceinline__ void store(int64_t p0, const bool valid[4])
+    __device__ __forceinline__ void store(const Pos &q)
     {
-        if (w) store4<VEC>(w, p0, valid, rw);
-        if (tr) store4<VEC>(tr, p0, valid, rt);
-        if (al) store4<VEC>(al, p0, valid, ra);
+        const bool *valid = q.valid;
+        const int64_t p0 = q.p0();
+        (void)valid; (void)p0;
+        if (w) store4<VEC>(w, q, rw);
+        if (tr) store4<VEC>(tr, q, rt);
+        if (al) store4<VEC>(al, q, ra);
     }
 };
 
@@ -1061,27 +1173,27 @@ struct RenderFusedFwdOp : OpBase1 {
 template <bool VEC>
 struct RenderFusedBwdOp : OpBase1 {
     static constexpr bool NEEDS_RID = true;
-    struct Raw { F4 a, b, T, A, gw, gt, ga; float c[12]; int64_t p0; };
+    struct Raw { F4 a, b, T, A, gw, gt, ga; float c[12]; };
     const float *ts, *te, *rgb, *tr, *al, *gc, *go, *gd, *gw, *gt, *ga;
     float *gsig, *grgb;
     float T[4], A[4], GW[4], GT[4], GA[4], dlt[4], mid[4], q[4], rs[4], c[12], gr[12];
     bool full;
-    __device__ __forceinline__ void fetch(int64_t p0, int64_t ps, const bool valid[4], Raw &r) const
+    __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
-        ld4<VEC>(ts, p0, ps, valid, r.a);
-        ld4<VEC>(te, p0, ps, valid, r.b);
-        ld4<VEC>(tr, p0, ps, valid, r.T);
-        ld4<VEC>(al, p0, ps, valid, r.A);
-        if (gw) ld4<VEC>(gw, p0, ps, valid, r.gw);
-        if (gt) ld4<VEC>(gt, p0, ps, valid, r.gt);
-        if (ga) ld4<VEC>(ga, p0, ps, valid, r.ga);
-        load_rgb12(rgb, VEC, p0, ps, valid, r.c);
-        r.p0 = p0;
+        ld4<VEC>(ts, q, r.a);
+        ld4<VEC>(te, q, r.b);
+        ld4<VEC>(tr, q, r.T);
+        ld4<VEC>(al, q, r.A);
+        if (gw) ld4<VEC>(gw, q, r.gw);
+        if (gt) ld4<VEC>(gt, q, r.gt);
+        if (ga) ld4<VEC>(ga, q, r.ga);
+        load_rgb12(rgb, VEC, q, r.c);
     }
-    __device__ __forceinline__ void load(const Raw &r, const bool valid[4])
+    __device__ __forceinline__ void load(const Raw &r, const Pos &pos)
     {
+        const bool *valid = pos.valid;
         full = VEC && valid[0] && valid[1] && valid[2] && valid[3];
-        fix_rgb12(rgb, VEC, r.p0, valid, r.c, c);
+        fix_rgb12(rgb, VEC, pos, r.c, c);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             T[j] = sel(r.T, j, valid, 0.0f); A[j] = sel(r.A, j, valid, 0.0f);
@@ -1117,9 +1229,12 @@ struct RenderFusedBwdOp : OpBase1 {
         const float Bv = GW[j] * T[j] * om + GA[j] * om - E;
         rs[j] = dlt[j] * Bv;
     }
-    __device__ __forceinline__ void store(int64_t p0, const bool valid[4])
+    __device__ __forceinline__ void store(const Pos &q)
     {
-        if (gsig) store4<VEC>(gsig, p0, valid, rs);
+        const bool *valid = q.valid;
+        const int64_t p0 = q.p0();
+        (void)valid; (void)p0;
+        if (gsig) store4<VEC>(gsig, q, rs);
         if (grgb) {
             if (full) {
                 float4 *qq = reinterpret_cast<float4 *>(grgb + 3 * p0);
