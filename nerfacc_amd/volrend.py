@@ -38,6 +38,7 @@ class _RenderFromDensity(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, t_starts, t_ends, sigmas, prefix_trans, seg: SegInfo, want_weights: bool):
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None, not as zero tensors
         ts, te, sg, pf = _f32c(t_starts), _f32c(t_ends), _f32c(sigmas), _f32c(prefix_trans)
         dev = B.require_device(ts, te, sg, pf)
         n = sg.numel()
@@ -86,6 +87,7 @@ class _RenderFromAlpha(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, alphas, prefix_trans, seg: SegInfo, want_weights: bool):
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None, not as zero tensors
         al, pf = _f32c(alphas), _f32c(prefix_trans)
         dev = B.require_device(al, pf)
         n = al.numel()
@@ -126,6 +128,7 @@ class _Accumulate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, weights, values, seg: SegInfo):
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None, not as zero tensors
         w, v = _f32c(weights), _f32c(values)
         dev = B.require_device(w, v)
         D = 1 if v is None else v.shape[-1]
@@ -161,6 +164,7 @@ class _RenderAccumulate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, weights, rgbs, t_starts, t_ends, seg: SegInfo):
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None, not as zero tensors
         w, c, ts, te = _f32c(weights), _f32c(rgbs), _f32c(t_starts), _f32c(t_ends)
         dev = B.require_device(w, c, ts, te)
         R = seg.n_rays
@@ -201,6 +205,7 @@ class _RenderFused(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, t_starts, t_ends, sigmas, rgbs, seg: SegInfo):
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None, not as zero tensors
         ts, te, sg, c = _f32c(t_starts), _f32c(t_ends), _f32c(sigmas), _f32c(rgbs)
         dev = B.require_device(ts, te, sg, c)
         R, n = seg.n_rays, sg.numel()
