@@ -92,6 +92,100 @@ NFA_HD float fast_forward_exact(float t, float target, float dt)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Stepper: the same shortcut with memory.  The stable increment of a binade depends on (dt, binade)
+// only -- not on where in the binade the march currently is -- so once it has been observed it can be
+// reused by every later march of the same ray in that binade (a ray alternates between skipping and
+// emitting a dozen times but crosses a binade boundary once or twice).  Two things are tracked:
+//   q_stable / q_binade : the increment observed twice in a row inside binade q_binade;
+//   aligned             : the current t was reached by a step with that increment (or by a jump), so the
+//                         NEXT step has it too.  In the exact-tie case (dt/ulp = k + 1/2) the first step
+//                         after an arbitrary t may differ by one ulp, hence a freshly assigned t or a
+//                         new binade is not aligned until one matching step has been observed.
+// A jump takes n = min(steps left in the binade, steps for which the loop condition holds, max_steps)
+// steps at once; the condition count comes from an fp32 estimate that is then VERIFIED on the actual
+// float (the condition is monotone in t), so there is no safety margin and no serial tail: a march is
+// one jump plus the final failed test.  Under-estimating n is always safe (the caller loops).
+struct Stepper {
+    uint32_t q_stable, q_binade;  // q_binade = biased exponent (bits >> 23), 0 = none
+    uint32_t obs_q, obs_binade;   // the previous observed in-binade step
+    bool aligned;
+};
+NFA_HD void stepper_init(Stepper &s) { s.q_stable = 0; s.q_binade = 0; s.obs_q = 0; s.obs_binade = 0; s.aligned = false; }
+// after t has been assigned a value that is not the result of a step
+NFA_HD void stepper_reset(Stepper &s) { s.aligned = false; s.obs_binade = 0; }
+
+// Precondition: t + half < thr (the serial loop would take a step).  Takes n >= 1 steps exactly as the serial
+// loop `while (t + half < thr) t += dt` would (never past the point where the condition turns false, never
+// more than max_steps >= 1), all with the same exact increment *inc, and returns n; returns 0 (t unchanged)
+// when t + dt == t (no progress).
+NFA_HD uint32_t stepper_advance(Stepper &s, float &t, float dt, float half, float thr, uint32_t max_steps, float *inc)
+{
+    const uint32_t bt = f32_bits(t);
+    const uint32_t e = bt >> 23;  // sign must be 0 for a jump: e in [1, 254]
+    if (s.aligned && e == s.q_binade && max_steps > 1u) {
+        const uint32_t q = s.q_stable;
+        const uint32_t room = (bt | 0x7FFFFFu) - bt;                 // bit patterns left in the binade (Bb - 1 - bt)
+        if (q <= room) {
+            const float step_val = bits_f32(bt + q) - t;               // exact value of one step
+            // steps that keep the result inside the binade: floor(room / q), from an fp32 quotient (both < 2^24)
+            uint32_t n_b = (uint32_t)((float)room / (float)q);
+            if (n_b * q > room) n_b--;
+            // steps for which the loop condition holds: t_i + half < thr for i = 0..n-1 (true for i = 0)
+            const float est = ((thr - half) - t) / step_val;
+            uint32_t n = n_b;
+            if (est < (float)n_b) n = (uint32_t)fmaxf(est, 0.0f) + 2u;
+            if (n > n_b) n = n_b;
+            if (n > max_steps) n = max_steps;
+            // verify the last condition test of the jump; walk back at most 4 steps, else a single step
+            int tries = 0;
+            while (n > 1u && !(bits_f32(bt + (n - 1u) * q) + half < thr)) {
+                n--;
+                if (++tries == 4 && n > 1u) { n = 1u; break; }
+            }
+            if (n >= 1u) {
+                t = bits_f32(bt + n * q);
+                *inc = step_val;
+                s.obs_q = q; s.obs_binade = e;
+                return n;
+            }
+        }
+    }
+    const float tn = t + dt;
+    if (tn == t) return 0u;
+    const uint32_t bn = f32_bits(tn);
+    if ((bn >> 23) == e && (int32_t)bt > 0 && e != 0u && e < 254u) {  // same binade, positive, normal
+        const uint32_t q = bn - bt;
+        if (e == s.q_binade && q == s.q_stable) {
+            s.aligned = true;
+        } else if (s.obs_binade == e && s.obs_q == q) {
+            s.q_stable = q; s.q_binade = e; s.aligned = true;
+        } else {
+            s.aligned = false;
+        }
+        s.obs_q = q; s.obs_binade = e;
+    } else {
+        s.aligned = false;
+        s.obs_binade = 0;
+    }
+    *inc = tn - t;  // exact (Sterbenz: tn/2 <= t <= 2 tn whenever the loop runs with dt <= t; otherwise still the value used)
+    t = tn;
+    return 1u;
+}
+
+// fast_forward_serial through the stepper (one-shot state): used by tests and by the serial traversal
+NFA_HD float fast_forward_stepper(float t, float target, float dt)
+{
+    const float half = dt * 0.5f;
+    Stepper s;
+    stepper_init(s);
+    for (;;) {
+        if (!(t + half < target)) return t;
+        float inc;
+        if (stepper_advance(s, t, dt, half, target, 0xFFFFFFFFu, &inc) == 0u) return target;
+    }
+}
+
 // t_last after marching to `target` (step <= 0: jump there, grid.cu:155,198).
 NFA_HD float fast_forward(float t_last, float target, float step, float cone_angle)
 {

@@ -81,23 +81,23 @@ struct RunsParams {
 //   EV_SPAN(thr)   start of a grid span: skip to thr only if the previous step was not emitted
 //                  (grid.cu:153-163, `if (!continuous)`)
 constexpr int EV_MAX = 32;  // measured on cfg2: 16 entries 630 us, 32 entries 566 us (fewer mid-walk flushes win over occupancy)
-using evt_t = uint64_t;      // 2 bits per entry
 enum { EV_EMPTY = 0, EV_OCC = 1, EV_SPAN = 2, EV_NONE = 3 };
 
 struct RunState {
     float t_last;
     bool continuous;
     int32_t n_samples, n_runs;
+    Stepper stp;  // remembered stable increment of the current binade (march.h)
     // open run
     bool open, run_cont;
     float run_t0, run_inc;
     int32_t run_n;
     // brick cache
     int32_t brick_id;
-    unsigned long long brick_word;
+    uint32_t brick_lo, brick_hi;
     // event list: open (unmerged) entry in registers, closed entries in LDS
     int32_t ev_cnt;
-    evt_t ev_types;  // 2 bits per closed entry
+    uint32_t ev_occ, ev_span;  // kind of closed entry k: bit k of ev_span -> EV_SPAN, else bit k of ev_occ -> EV_OCC / EV_EMPTY
     int32_t open_type;
     float open_thr;
 };
@@ -117,51 +117,36 @@ __device__ __forceinline__ void close_run(RunState &st, const RunsParams &p, int
 }
 
 // Advance t_last while the step's mid-point is before `thr`; with `emit` every step is a sample
-// and is appended to the ray's run list.  Same arithmetic as march.h's fast_forward_exact
-// (observed serial steps + exact in-binade jumps), plus the sample budget of traverse_steps_limit.
+// and is appended to the ray's run list.  march.h's Stepper does the arithmetic: one exact jump per
+// binade (the stable increment is remembered across the marches of a ray), plus the sample budget of
+// traverse_steps_limit.
 __device__ __forceinline__ void march(RunState &st, float thr, float dt, float half, bool emit, int32_t limit,
                                       const RunsParams &p, int64_t tid)
 {
-    uint32_t prev_q = 0;
     for (;;) {
         if (!(st.t_last + half < thr)) return;
-        if (emit && limit > 0 && st.n_samples >= limit) return;
+        uint32_t budget = 0xFFFFFFFFu;
+        if (emit && limit > 0) {
+            if (st.n_samples >= limit) return;
+            budget = (uint32_t)(limit - st.n_samples);
+        }
         const float t = st.t_last;
-        float tn = t + dt;
-        if (tn == t) {  // no progress (see oracle): skipping jumps to the target, emission stops
-            if (!emit) st.t_last = thr;
+        float tn = t, inc;
+        const uint32_t n = stepper_advance(st.stp, tn, dt, half, thr, budget, &inc);
+        if (n == 0u) {  // no progress (see oracle): skipping jumps to the target, emission stops
+            if (!emit) { st.t_last = thr; stepper_reset(st.stp); }
             return;
         }
-        const uint32_t bt = f32_bits(t), bn = f32_bits(tn);
-        uint32_t q = 0;
-        float nf = 0.0f;
-        if ((bt >> 23) == (bn >> 23) && (int32_t)bt > 0 && (bt >> 23) != 0) {
-            q = bn - bt;
-            const uint32_t Bb = (bn | 0x7FFFFFu) + 1u;
-            if (q == prev_q && (Bb >> 23) < 255u) {
-                const float nx = (float)(Bb - bn - 1u) / (float)q;
-                const float ny = ((thr - half) - tn) / (tn - t);
-                nf = fminf(nx, ny) * 0.99999f - 4.0f;
-            }
-        }
-        if (emit) {  // the observed step t -> tn is a sample
-            const float inc = tn - t;  // exact (Sterbenz)
+        if (emit) {  // n samples t, t + inc, ... (exact sums)
             if (st.open && st.continuous && inc == st.run_inc) {
-                st.run_n++;
+                st.run_n += (int32_t)n;
             } else {
                 close_run(st, p, tid);
-                st.open = true; st.run_t0 = t; st.run_inc = inc; st.run_n = 1; st.run_cont = st.continuous;
+                st.open = true; st.run_t0 = t; st.run_inc = inc; st.run_n = (int32_t)n; st.run_cont = st.continuous;
             }
-            st.n_samples++;
+            st.n_samples += (int32_t)n;
             st.continuous = true;
-            if (limit > 0) nf = fminf(nf, (float)(limit - st.n_samples));
         }
-        if (nf >= 1.0f) {  // jump: every skipped step has the bit-pattern increment q
-            const uint32_t n = (uint32_t)nf;
-            tn = bits_f32(bn + n * q);
-            if (emit) { st.run_n += (int32_t)n; st.n_samples += (int32_t)n; }
-        }
-        prev_q = q;
         st.t_last = tn;
     }
 }
@@ -173,7 +158,7 @@ __device__ __forceinline__ void process_events(RunState &st, const float *ev_thr
 {
     const float half = dt * 0.5f;
     for (int k = 0; k < st.ev_cnt; ++k) {
-        const int type = (int)((st.ev_types >> (2 * k)) & 3u);
+        const int type = ((st.ev_span >> k) & 1u) ? EV_SPAN : (int)((st.ev_occ >> k) & 1u);
         const float thr = ev_thr[k * 256 + threadIdx.x];
         if (limit > 0 && st.n_samples >= limit) break;  // grid.cu:184: nothing moves once the limit is hit
         if (type == EV_SPAN && st.continuous) continue;
@@ -181,13 +166,14 @@ __device__ __forceinline__ void process_events(RunState &st, const float *ev_thr
         if (type == EV_EMPTY) st.continuous = false;
     }
     st.ev_cnt = 0;
-    st.ev_types = 0;
+    st.ev_occ = 0u; st.ev_span = 0u;
 }
 
 __device__ __forceinline__ void push_closed(RunState &st, float *ev_thr, int type, float thr)
 {
     ev_thr[st.ev_cnt * 256 + threadIdx.x] = thr;
-    st.ev_types |= (evt_t)type << (2 * st.ev_cnt);
+    st.ev_occ |= (uint32_t)(type & 1) << st.ev_cnt;
+    st.ev_span |= (uint32_t)(type >> 1) << st.ev_cnt;
     st.ev_cnt++;
 }
 
@@ -234,23 +220,30 @@ __device__ __forceinline__ void runs_span(const nfa_traverse_args &a, const Runs
     int32_t cells_left = a.res[0] + a.res[1] + a.res[2] + 3;
 
     // Phase 1: the reference's cell loop (grid.cu:184-272) reduced to the DDA and one event per run of
-    // cells of one kind.  Straight-line predicated code: the only branches are the brick reload and
-    // the loop exit (span end, or list full -> consume it and resume).  Row EV_MAX of the LDS list is
-    // a dummy slot that absorbs the write when the kind did not change.
+    // cells of one kind.  Straight-line predicated code, 32-bit integer ops only: the only branches are the
+    // brick reload and the loop exit (span end, or list full -> consume it and resume).  The open entry's
+    // threshold is written to slot ev_cnt on EVERY cell; the slot becomes a closed entry when the kind
+    // changes (ev_cnt advances) and is overwritten otherwise.
+    // The first cell always closes the EV_SPAN entry opened above: its kind bit is set here.
+    st.ev_span |= 1u << st.ev_cnt;
+    float *ev_col = ev_thr + threadIdx.x;
     bool span_done = false;
     while (!span_done) {
         for (;;) {
-            const int32_t bid = lvl_brick_base + ((cur[0] >> 2) * p.by + (cur[1] >> 2)) * p.bz + (cur[2] >> 2);
+            const int32_t bid = lvl_brick_base + (int32_t)__umul24(__umul24(cur[0] >> 2, p.by) + (cur[1] >> 2), p.bz) + (cur[2] >> 2);
             if (bid != st.brick_id) {
                 st.brick_id = bid;
                 const uint32_t cw = COARSE_LDS ? coarse_lds[bid >> 5] : p.coarse[bid >> 5];
-                st.brick_word = ((cw >> (bid & 31)) & 1u) ? p.bricks[bid] : 0ull;
+                const unsigned long long w = ((cw >> (bid & 31)) & 1u) ? p.bricks[bid] : 0ull;
+                st.brick_lo = (uint32_t)w; st.brick_hi = (uint32_t)(w >> 32);
             }
-            const int bit = ((cur[0] & 3) << 4) | ((cur[1] & 3) << 2) | (cur[2] & 3);
-            const int type = (int)((st.brick_word >> bit) & 1ull);  // EV_EMPTY / EV_OCC
+            // bit ((x&3)<<4 | (y&3)<<2 | (z&3)) of the 64-bit brick word, on 32-bit halves
+            const uint32_t half_w = (cur[0] & 2) ? st.brick_hi : st.brick_lo;
+            const int sh = ((cur[0] & 1) << 4) | ((cur[1] & 3) << 2) | (cur[2] & 3);
+            const int type = (int)((half_w >> sh) & 1u);  // EV_EMPTY / EV_OCC
             const bool changed = type != st.open_type;
-            ev_thr[(changed ? st.ev_cnt : EV_MAX) * 256 + threadIdx.x] = st.open_thr;
-            st.ev_types |= changed ? ((evt_t)st.open_type << (2 * st.ev_cnt)) : (evt_t)0;
+            ev_col[st.ev_cnt * 256] = st.open_thr;
+            st.ev_occ |= (changed ? (uint32_t)(st.open_type & 1) : 0u) << st.ev_cnt;
             st.ev_cnt += changed ? 1 : 0;
             st.open_type = type;
             st.open_thr = fminf(fminf(tdist[0], fminf(tdist[1], tdist[2])), this_tmax);  // t_traverse, non-decreasing
@@ -261,8 +254,9 @@ __device__ __forceinline__ void runs_span(const nfa_traverse_args &a, const Runs
             cur[0] += s0 ? step[0] : 0; tdist[0] += s0 ? delta[0] : 0.0f;
             cur[1] += s1 ? step[1] : 0; tdist[1] += s1 ? delta[1] : 0.0f;
             cur[2] += s2 ? step[2] : 0; tdist[2] += s2 ? delta[2] : 0.0f;
-            const bool done = s0 ? (cur[0] == overflow[0]) : (s1 ? (cur[1] == overflow[1]) : (cur[2] == overflow[2]));
-            span_done = done || (--cells_left <= 0);
+            const int32_t c_sel = s0 ? cur[0] : (s1 ? cur[1] : cur[2]);
+            const int32_t o_sel = s0 ? overflow[0] : (s1 ? overflow[1] : overflow[2]);
+            span_done = (c_sel == o_sel) || (--cells_left <= 0);
             if (span_done || st.ev_cnt == EV_MAX) break;
         }
         if (!span_done) process_events(st, ev_thr, dt, limit, p, tid);
@@ -273,8 +267,8 @@ template <bool FUSED, bool COARSE_LDS>
 __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, const RunsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    float *ev_thr = reinterpret_cast<float *>(lds_raw);          // [EV_MAX + 1][256], last row = dummy slot
-    uint32_t *coarse_lds = lds_raw + (EV_MAX + 1) * 256;          // [n_coarse_words] (COARSE_LDS only)
+    float *ev_thr = reinterpret_cast<float *>(lds_raw);          // [EV_MAX][256]
+    uint32_t *coarse_lds = lds_raw + EV_MAX * 256;          // [n_coarse_words] (COARSE_LDS only)
     if (COARSE_LDS) {
         for (int i = threadIdx.x; i < p.n_coarse_words; i += blockDim.x) coarse_lds[i] = p.coarse[i];
         __syncthreads();
@@ -292,10 +286,10 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
         const float d[3] = {a.rays_d[3 * tid], a.rays_d[3 * tid + 1], a.rays_d[3 * tid + 2]};
         const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
         RunState st;
-        st.t_last = near_plane; st.continuous = false;
+        st.t_last = near_plane; st.continuous = false; stepper_init(st.stp);
         st.n_samples = 0; st.n_runs = 0; st.open = false; st.run_cont = false; st.run_t0 = 0.f; st.run_inc = 0.f;
-        st.run_n = 0; st.brick_id = -1; st.brick_word = 0ull;
-        st.ev_cnt = 0; st.ev_types = 0; st.open_type = EV_NONE; st.open_thr = 0.f;
+        st.run_n = 0; st.brick_id = -1; st.brick_lo = st.brick_hi = 0u;
+        st.ev_cnt = 0; st.ev_occ = 0u; st.ev_span = 0u; st.open_type = EV_NONE; st.open_thr = 0.f;
         if (FUSED) {
             float tmin, tmax, lo, hi;
             bool hit = true;
@@ -453,8 +447,10 @@ __global__ __launch_bounds__(256) void expand_runs_kernel(int64_t n_rays, float 
                     const uint32_t e = pos[j];
                     const uint32_t kk = pr - (e & 0x7FFFFFFu);
                     const float inc = (t0 + dt) - t0;  // the run's exact per-step increment
-                    ts4[k] = (float)((double)t0 + (double)kk * (double)inc);
-                    te4[k] = (float)((double)t0 + (double)(kk + 1) * (double)inc);
+                    // t0 + k * inc is exactly representable for every sample of a run (that is what makes it a run),
+                    // so one fused multiply-add (single rounding of the exact value) reproduces the serial sums
+                    ts4[k] = __builtin_fmaf((float)kk, inc, t0);
+                    te4[k] = __builtin_fmaf((float)(kk + 1), inc, t0);
                     ri4[k] = r0 + (e >> 27);
                     valid[k] = true;
                 }
@@ -534,7 +530,7 @@ int nfa_traverse_runs(const nfa_traverse_args *pa, const uint64_t *bricks, const
     p.max_runs = max_runs;
     p.overflow = overflow_count;
     const bool lds = p.n_coarse_words <= COARSE_LDS_WORDS;
-    const size_t shmem = (size_t)(EV_MAX + 1) * 256 * 4 + (lds ? (size_t)p.n_coarse_words * 4 : 0);
+    const size_t shmem = (size_t)EV_MAX * 256 * 4 + (lds ? (size_t)p.n_coarse_words * 4 : 0);
     const unsigned grid = grid_1d(a.n_rays, 256, 1 << 20);
     if (fused) {
         if (lds) hipLaunchKernelGGL((runs_kernel<true, true>), dim3(grid), dim3(256), shmem, s, a, p);

@@ -11,11 +11,78 @@ from conftest import ROOT
 
 HARNESS = r'''
 #include "march.h"
+#include <math.h>
+#include <vector>
 extern "C" void ff_batch(const float* t, const float* target, const float* dt, long n, float* a, float* b) {
     for (long i = 0; i < n; ++i) {
         a[i] = nfa::fast_forward_serial(t[i], target[i], dt[i]);
         b[i] = nfa::fast_forward_exact(t[i], target[i], dt[i]);
     }
+}
+extern "C" void ff_batch_stepper(const float* t, const float* target, const float* dt, long n, float* a, float* b) {
+    for (long i = 0; i < n; ++i) {
+        a[i] = nfa::fast_forward_serial(t[i], target[i], dt[i]);
+        b[i] = nfa::fast_forward_stepper(t[i], target[i], dt[i]);
+    }
+}
+// One ray: events (thr[k], emit[k]) consumed in order, as traverse2.hip's march() does (skip or emit while
+// the step's mid-point is before thr; budget of `limit` samples).  Serial reference vs Stepper + run records
+// expanded with one fused multiply-add per value (what expand_runs_kernel does).
+// Returns the number of samples; out_* hold (ts, te) of both versions; t_last[2] the final positions.
+extern "C" long ray_events(float t0, float dt, const float* thr, const int* emit, long n_ev, int limit, long cap,
+                           float* ts_a, float* te_a, float* ts_b, float* te_b, float* t_last, long* n_b_out, long* n_jumps) {
+    const float half = dt * 0.5f;
+    // ---- serial
+    long na = 0;
+    {
+        float t = t0;
+        for (long k = 0; k < n_ev; ++k) {
+            if (limit > 0 && na >= limit) break;
+            while (t + half < thr[k]) {
+                if (emit[k] && limit > 0 && na >= limit) break;
+                const float tn = t + dt;
+                if (tn == t) { if (!emit[k]) t = thr[k]; break; }
+                if (emit[k]) { if (na < cap) { ts_a[na] = t; te_a[na] = tn; } na++; }
+                t = tn;
+            }
+        }
+        t_last[0] = t;
+    }
+    // ---- stepper + runs
+    struct Run { float t0, inc; long n; };
+    std::vector<Run> runs;
+    long nb = 0, jumps = 0;
+    {
+        nfa::Stepper s; nfa::stepper_init(s);
+        float t = t0;
+        bool open = false, continuous = false;
+        for (long k = 0; k < n_ev; ++k) {
+            if (limit > 0 && nb >= limit) break;
+            for (;;) {
+                if (!(t + half < thr[k])) break;
+                uint32_t budget = 0xFFFFFFFFu;
+                if (emit[k] && limit > 0) { if (nb >= limit) break; budget = (uint32_t)(limit - nb); }
+                float tn = t, inc;
+                const uint32_t n = nfa::stepper_advance(s, tn, dt, half, thr[k], budget, &inc);
+                if (n == 0) { if (!emit[k]) { t = thr[k]; nfa::stepper_reset(s); } break; }
+                if (n > 1) jumps++;
+                if (emit[k]) {
+                    if (open && continuous && inc == runs.back().inc) runs.back().n += n;
+                    else { runs.push_back({t, inc, (long)n}); open = true; }
+                    nb += n; continuous = true;
+                }
+                t = tn;
+            }
+            if (!emit[k]) continuous = false;
+        }
+        t_last[1] = t;
+    }
+    long w = 0;
+    for (auto& r : runs)
+        for (long i = 0; i < r.n; ++i, ++w)
+            if (w < cap) { ts_b[w] = fmaf((float)i, r.inc, r.t0); te_b[w] = fmaf((float)(i + 1), r.inc, r.t0); }
+    *n_b_out = nb; *n_jumps = jumps;
+    return na;
 }
 '''
 
@@ -67,3 +134,67 @@ def test_fast_forward_exact_matches_serial(tmp_path):
     # the headline case: 650 serial steps from the camera to the box
     a, b = _run(lib, np.zeros(1), np.array([2.2]), np.array([2 * 3 ** 0.5 / 1024]))
     assert a[0] == b[0] and abs(a[0] - 2.2) < 4e-3
+
+
+def test_stepper_matches_serial(tmp_path):
+    """march.h's Stepper (remembered stable increment, verified jump counts, no safety margin) gives the
+    serial loop's result bit for bit: single marches, and whole rays of alternating skip / emit events with
+    the run records expanded by fused multiply-adds, with and without a sample budget."""
+    lib = _build(tmp_path)
+    rng = np.random.default_rng(1)
+    n = 200000
+    t = (rng.random(n) * 4).astype(np.float32)
+    t[: n // 10] = 0.0
+    dt = (10 ** rng.uniform(-3.2, -1.5, n)).astype(np.float32)
+    target = (t + rng.random(n) * 8).astype(np.float32)
+    t2 = np.concatenate([np.nextafter((2.0 ** rng.integers(-3, 4, 5000)).astype(np.float32), np.float32(0)),
+                         (2.0 ** rng.integers(-3, 4, 5000)).astype(np.float32) * (1 + rng.integers(0, 5, 5000) * 2.0 ** -23),
+                         rng.random(5000).astype(np.float32)]).astype(np.float32)
+    dt2 = np.concatenate([(2.0 ** rng.integers(-12, -4, 5000)).astype(np.float32),
+                          (2.0 ** rng.integers(-12, -4, 5000) * 1.5).astype(np.float32),
+                          (rng.random(5000) * 2e-4 + 1e-5).astype(np.float32)])
+    target2 = (t2 + rng.random(t2.size).astype(np.float32) * 3).astype(np.float32)
+    t3 = np.array([1e8, 5.0, -1.0, -0.5, 3.0, 0.0, 16777216.0, 0.0], np.float32)
+    tg3 = np.array([2e8, 1.0, 2.0, -0.25, 3.0, 1e-30, 16777300.0, 2.2], np.float32)
+    dt3 = np.array([1e-3, 0.1, 0.01, 0.125, 0.5, 1e-3, 1.0, 2 * 3 ** 0.5 / 1024], np.float32)
+    for tt, tg, dd in ((t, target, dt), (t2, target2, dt2), (t3, tg3, dt3)):
+        tt, tg, dd = (np.ascontiguousarray(a, np.float32) for a in (tt, tg, dd))
+        a, b = np.empty_like(tt), np.empty_like(tt)
+        p = lambda x: x.ctypes.data_as(C.c_void_p)
+        lib.ff_batch_stepper(p(tt), p(tg), p(dd), C.c_long(tt.size), p(a), p(b))
+        assert (a.view(np.uint32) == b.view(np.uint32)).all()
+
+    lib.ray_events.restype = C.c_long
+    cap = 1 << 16
+    bufs = [np.empty(cap, np.float32) for _ in range(4)]
+    tl = np.empty(2, np.float32)
+    nb, nj = C.c_long(), C.c_long()
+    total_jumps = total_samples = 0
+    for case in range(3000):
+        kind = case % 6
+        t0 = np.float32([0.0, rng.random() * 4, 2.0 - 1e-5 * rng.random(), rng.random() * 1e-3, 3.9, 0.7][kind])
+        if kind == 2:
+            dtv = np.float32(2.0 ** rng.integers(-11, -6) * [1.0, 1.5][case % 2])       # exact ties across the 2.0 edge
+        elif kind == 4:
+            dtv = np.float32(2 * 3 ** 0.5 / 1024)                                        # the bench's step across 4.0
+        else:
+            dtv = np.float32(10 ** rng.uniform(-3.3, -1.8))
+        n_ev = int(rng.integers(1, 40))
+        gaps = rng.random(n_ev) * [0.05, 0.5, 0.01, 2.0][case % 4]
+        gaps[rng.random(n_ev) < 0.2] = 0.0                                               # repeated thresholds
+        thr = (t0 + np.cumsum(gaps)).astype(np.float32)
+        if case % 17 == 0:
+            thr[-1] = np.float32(1e10) if dtv > 1e-2 else thr[-1]
+        emit = (rng.random(n_ev) < 0.5).astype(np.int32)
+        limit = int([0, 0, 7, 64][case % 4])
+        na = lib.ray_events(C.c_float(float(t0)), C.c_float(float(dtv)), thr.ctypes.data_as(C.c_void_p),
+                            emit.ctypes.data_as(C.c_void_p), C.c_long(n_ev), C.c_int(limit), C.c_long(cap),
+                            *[b.ctypes.data_as(C.c_void_p) for b in bufs], tl.ctypes.data_as(C.c_void_p),
+                            C.byref(nb), C.byref(nj))
+        assert na == nb.value, (case, na, nb.value)
+        assert tl.view(np.uint32)[0] == tl.view(np.uint32)[1], (case, tl)
+        m = min(na, cap)
+        assert (bufs[0][:m].view(np.uint32) == bufs[2][:m].view(np.uint32)).all(), case
+        assert (bufs[1][:m].view(np.uint32) == bufs[3][:m].view(np.uint32)).all(), case
+        total_jumps += nj.value; total_samples += na
+    assert total_samples > 100000 and total_jumps > 3000     # the shortcut is actually exercised
