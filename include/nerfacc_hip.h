@@ -124,13 +124,16 @@ int nfa_traverse_grids(const nfa_traverse_args *args, nfa_stream_t stream);
  *                      more runs are counted in *overflow_count and must be filled with
  *                      nfa_traverse_grids(mode 1, ray_filter = run_cnts, ray_filter_min = max_runs).
  *                      args->mode: 0 = all rays, 2 = honour rays_mask (+ traverse_steps_limit).
+ *                      near_hint: the value (most of) args->near_planes hold, NaN if unknown; a pure
+ *                      accelerator (the march from a common near plane to the grid is tabulated once on
+ *                      the host), rays with another near plane are unaffected, results never change.
  *   nfa_expand_runs    runs + exclusive cumsum of the counts -> t_starts, t_ends, ray_indices. */
 int64_t nfa_bricks_words(int32_t n_grids, const int32_t *res);
 int nfa_pack_bricks(const uint8_t *binaries, int32_t n_grids, const int32_t *res, uint64_t *bricks,
                     uint32_t *coarse, nfa_stream_t stream);
 int nfa_traverse_runs(const nfa_traverse_args *args, const uint64_t *bricks, const uint32_t *coarse,
                       int32_t *run_cnts, uint64_t *runs, int32_t max_runs, int32_t *overflow_count,
-                      nfa_stream_t stream);
+                      float near_hint, nfa_stream_t stream);
 int nfa_expand_runs(int64_t n_rays, float step_size, const int32_t *run_cnts, const uint64_t *runs,
                     int32_t max_runs, const int64_t *sm_starts, const int64_t *sm_cnts, float *t_starts,
                     float *t_ends, int64_t *ray_indices, nfa_stream_t stream);

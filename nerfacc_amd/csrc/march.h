@@ -173,6 +173,69 @@ NFA_HD uint32_t stepper_advance(Stepper &s, float &t, float dt, float half, floa
     return 1u;
 }
 
+// ------------------------------------------------------------------------------------------
+// Approach table.  Every ray of a batch that starts at the same near plane with the same step walks
+// the SAME sequence near, near + dt, ... until it reaches its grid (~650 steps, ~10 binades, for a camera
+// 2.2 units away); only where it stops differs.  The table holds, per binade, the first point of that
+// sequence at which the stepper is aligned (T, with its stable increment q): a ray looks up the binade
+// its target falls into, continues from that point and is one jump away from its stop.  Built on the host
+// (it needs only near and dt), passed by value; exact because the stop condition is monotone in t and T
+// is a point of the very sequence the serial loop would visit.
+constexpr int APPROACH_MAX = 40;
+struct ApproachTable {
+    uint32_t near_bits;   // bit pattern of the near plane the table was built for
+    uint32_t e_lo, n;     // entry i belongs to binade (biased exponent) e_lo + i; n == 0: no table
+    float T[APPROACH_MAX];
+    uint32_t q[APPROACH_MAX];  // 0 = no entry for this binade
+};
+
+NFA_HD void approach_table_build(ApproachTable &tb, float near, float dt)
+{
+    tb.near_bits = f32_bits(near);
+    tb.e_lo = 0; tb.n = 0;
+    for (int i = 0; i < APPROACH_MAX; ++i) { tb.T[i] = 0.0f; tb.q[i] = 0u; }
+    if (!(dt > 0.0f) || !(near >= 0.0f)) return;
+    const float half = dt * 0.5f;
+    const float inf = bits_f32(0x7F800000u);
+    Stepper s;
+    stepper_init(s);
+    float t = near;
+    for (int it = 0; it < 64 * APPROACH_MAX; ++it) {
+        float inc;
+        if (stepper_advance(s, t, dt, half, inf, 0xFFFFFFFFu, &inc) == 0u) break;
+        const uint32_t e = f32_bits(t) >> 23;
+        if (s.aligned && e == s.q_binade) {
+            if (tb.n == 0) tb.e_lo = e;
+            const uint32_t i = e - tb.e_lo;
+            if (i >= (uint32_t)APPROACH_MAX) break;
+            if (tb.q[i] == 0u) { tb.T[i] = t; tb.q[i] = s.q_stable; if (i + 1 > tb.n) tb.n = i + 1; }
+        }
+        if (e >= 127u + 40u) break;
+    }
+}
+
+// Continue a SKIPPING march that still stands on the near plane from the table: moves t (and the
+// stepper) to the furthest tabulated point that the serial loop would pass on its way to thr.
+NFA_HD void approach_table_apply(const ApproachTable &tb, Stepper &s, float &t, float half, float thr)
+{
+    if (tb.n == 0u || f32_bits(t) != tb.near_bits) return;
+    const float c = thr - half;
+    if (!(c > 0.0f)) return;
+    uint32_t ec = f32_bits(c) >> 23;
+    if (ec > tb.e_lo + tb.n - 1u) ec = tb.e_lo + tb.n - 1u;  // targets beyond the table: its last binade
+    for (int d = 0; d < 2; ++d) {
+        const uint32_t e = ec - (uint32_t)d;
+        if (e < tb.e_lo || e > ec) return;
+        const uint32_t i = e - tb.e_lo;
+        const float T = tb.T[i];
+        if (tb.q[i] != 0u && T > t && T + half < thr) {
+            t = T;
+            s.q_stable = tb.q[i]; s.q_binade = e; s.obs_q = tb.q[i]; s.obs_binade = e; s.aligned = true;
+            return;
+        }
+    }
+}
+
 // fast_forward_serial through the stepper (one-shot state): used by tests and by the serial traversal
 NFA_HD float fast_forward_stepper(float t, float target, float dt)
 {

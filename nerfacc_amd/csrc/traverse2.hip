@@ -70,6 +70,7 @@ struct RunsParams {
     unsigned long long *runs;    // [n_rays, max_runs]
     int32_t max_runs;
     int32_t *overflow;           // [1] number of rays with more runs than max_runs
+    ApproachTable approach;      // shared start of every ray's march (march.h); n == 0: none
 };
 
 // Events recorded by the cell walk (phase 1) and consumed by the marcher (phase 2).  Along a ray
@@ -88,6 +89,7 @@ struct RunState {
     bool continuous;
     int32_t n_samples, n_runs;
     Stepper stp;  // remembered stable increment of the current binade (march.h)
+    bool at_near; // t_last is still the near plane
     // open run
     bool open, run_cont;
     float run_t0, run_inc;
@@ -123,6 +125,10 @@ __device__ __forceinline__ void close_run(RunState &st, const RunsParams &p, int
 __device__ __forceinline__ void march(RunState &st, float thr, float dt, float half, bool emit, int32_t limit,
                                       const RunsParams &p, int64_t tid)
 {
+    if (st.at_near) {  // first march of the ray: the way from the near plane is the same for all rays
+        st.at_near = false;
+        if (!emit) approach_table_apply(p.approach, st.stp, st.t_last, half, thr);
+    }
     for (;;) {
         if (!(st.t_last + half < thr)) return;
         uint32_t budget = 0xFFFFFFFFu;
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
         const float d[3] = {a.rays_d[3 * tid], a.rays_d[3 * tid + 1], a.rays_d[3 * tid + 2]};
         const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
         RunState st;
-        st.t_last = near_plane; st.continuous = false; stepper_init(st.stp);
+        st.t_last = near_plane; st.continuous = false; stepper_init(st.stp); st.at_near = true;
         st.n_samples = 0; st.n_runs = 0; st.open = false; st.run_cont = false; st.run_t0 = 0.f; st.run_inc = 0.f;
         st.run_n = 0; st.brick_id = -1; st.brick_lo = st.brick_hi = 0u;
         st.ev_cnt = 0; st.ev_occ = 0u; st.ev_span = 0u; st.open_type = EV_NONE; st.open_thr = 0.f;
@@ -499,7 +505,7 @@ int nfa_pack_bricks(const uint8_t *binaries, int32_t n_grids, const int32_t *res
 }
 
 int nfa_traverse_runs(const nfa_traverse_args *pa, const uint64_t *bricks, const uint32_t *coarse, int32_t *run_cnts,
-                      uint64_t *runs, int32_t max_runs, int32_t *overflow_count, nfa_stream_t stream)
+                      uint64_t *runs, int32_t max_runs, int32_t *overflow_count, float near_hint, nfa_stream_t stream)
 {
     NFA_REQUIRE(pa != nullptr, "traverse_runs: null args");
     const nfa_traverse_args &a = *pa;
@@ -529,6 +535,10 @@ int nfa_traverse_runs(const nfa_traverse_args *pa, const uint64_t *bricks, const
     p.runs = reinterpret_cast<unsigned long long *>(runs);
     p.max_runs = max_runs;
     p.overflow = overflow_count;
+    // near_hint: the value most (or all) entries of near_planes hold, NaN if unknown.  Rays whose near plane
+    // differs bit-wise simply do not use the table.
+    if (near_hint == near_hint) approach_table_build(p.approach, near_hint, a.step_size);
+    else p.approach.n = 0;
     const bool lds = p.n_coarse_words <= COARSE_LDS_WORDS;
     const size_t shmem = (size_t)EV_MAX * 256 * 4 + (lds ? (size_t)p.n_coarse_words * 4 : 0);
     const unsigned grid = grid_1d(a.n_rays, 256, 1 << 20);

@@ -106,7 +106,8 @@ class OccGridEstimator(AbstractEstimator):
             near_planes += torch.rand_like(near_planes) * render_step_size
 
         ray_indices, t_starts, t_ends, packed_info = _traverse_samples(
-            rays_o, rays_d, self.binaries, self.aabbs, near_planes, far_planes, render_step_size, cone_angle)
+            rays_o, rays_d, self.binaries, self.aabbs, near_planes, far_planes, render_step_size, cone_angle,
+            near_hint=near_plane)
 
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None or alpha_fn is not None):
             alpha_thre = min(alpha_thre, self._occs_mean())

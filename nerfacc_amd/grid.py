@@ -228,7 +228,7 @@ def _get_bricks(binaries: Tensor):
 @torch.no_grad()
 def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size, cone_angle,
                       rays_mask=None, traverse_steps_limit=None, t_sorted=None, t_indices=None, hits=None,
-                      return_terminate=False):
+                      return_terminate=False, near_hint=None):
     """Sampler fast path: (ray_indices, t_starts, t_ends, packed_info) straight from the traversal.
 
     Same values as ``intervals.vals[is_left]``, ``intervals.vals[is_right]``,
@@ -268,8 +268,9 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
             bricks, coarse = _get_bricks(binaries)
             run_cnts = torch.empty(n_rays, dtype=torch.int32, device=dev)
             runs = torch.empty((n_rays, MAX_RUNS), dtype=torch.int64, device=dev)
+            # near_hint: the scalar near plane when the caller built near_planes from one (accelerator only)
             B.call("nfa_traverse_runs", C.byref(a), B.ptr(bricks), B.ptr(coarse), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
-                   B.ptr(meta[1:2]), B.stream())
+                   B.ptr(meta[1:2]), float("nan") if near_hint is None else float(near_hint), B.stream())
         else:
             _launch(a)
         sm_starts = _exclusive_cumsum(sm_cnts, meta[0:1])

@@ -25,11 +25,24 @@ extern "C" void ff_batch_stepper(const float* t, const float* target, const floa
         b[i] = nfa::fast_forward_stepper(t[i], target[i], dt[i]);
     }
 }
+// number of stepper_advance calls of one skipping march from t0 to thr, with / without the approach table
+extern "C" int approach_calls(float t0, float dt, float thr, int use_table, float* t_out) {
+    const float half = dt * 0.5f;
+    nfa::Stepper s; nfa::stepper_init(s);
+    nfa::ApproachTable tb; tb.n = 0;
+    if (use_table) nfa::approach_table_build(tb, t0, dt);
+    float t = t0;
+    nfa::approach_table_apply(tb, s, t, half, thr);
+    int calls = 0;
+    while (t + half < thr) { float inc; if (nfa::stepper_advance(s, t, dt, half, thr, 0xFFFFFFFFu, &inc) == 0u) break; calls++; }
+    *t_out = t;
+    return calls;
+}
 // One ray: events (thr[k], emit[k]) consumed in order, as traverse2.hip's march() does (skip or emit while
 // the step's mid-point is before thr; budget of `limit` samples).  Serial reference vs Stepper + run records
 // expanded with one fused multiply-add per value (what expand_runs_kernel does).
 // Returns the number of samples; out_* hold (ts, te) of both versions; t_last[2] the final positions.
-extern "C" long ray_events(float t0, float dt, const float* thr, const int* emit, long n_ev, int limit, long cap,
+extern "C" long ray_events(float t0, float dt, const float* thr, const int* emit, long n_ev, int limit, int use_table, long cap,
                            float* ts_a, float* te_a, float* ts_b, float* te_b, float* t_last, long* n_b_out, long* n_jumps) {
     const float half = dt * 0.5f;
     // ---- serial
@@ -54,10 +67,13 @@ extern "C" long ray_events(float t0, float dt, const float* thr, const int* emit
     long nb = 0, jumps = 0;
     {
         nfa::Stepper s; nfa::stepper_init(s);
+        nfa::ApproachTable tb; tb.n = 0;
+        if (use_table) nfa::approach_table_build(tb, use_table == 2 ? t0 + 1.0f : t0, dt);  // 2: table of another near plane
         float t = t0;
-        bool open = false, continuous = false;
+        bool open = false, continuous = false, at_near = true;
         for (long k = 0; k < n_ev; ++k) {
             if (limit > 0 && nb >= limit) break;
+            if (at_near) { at_near = false; if (!emit[k]) nfa::approach_table_apply(tb, s, t, half, thr[k]); }
             for (;;) {
                 if (!(t + half < thr[k])) break;
                 uint32_t budget = 0xFFFFFFFFu;
@@ -136,6 +152,11 @@ def test_fast_forward_exact_matches_serial(tmp_path):
     assert a[0] == b[0] and abs(a[0] - 2.2) < 4e-3
 
 
+def a_serial(lib, t, thr, dt):
+    a, _ = _run(lib, np.array([t]), np.array([thr]), np.array([dt]))
+    return a[0]
+
+
 def test_stepper_matches_serial(tmp_path):
     """march.h's Stepper (remembered stable increment, verified jump counts, no safety margin) gives the
     serial loop's result bit for bit: single marches, and whole rays of alternating skip / emit events with
@@ -187,8 +208,11 @@ def test_stepper_matches_serial(tmp_path):
             thr[-1] = np.float32(1e10) if dtv > 1e-2 else thr[-1]
         emit = (rng.random(n_ev) < 0.5).astype(np.int32)
         limit = int([0, 0, 7, 64][case % 4])
+        if case % 5 == 1:
+            thr += np.float32(rng.random() * 6)      # grid far from the near plane: the approach table's case
+            emit[0] = 0
         na = lib.ray_events(C.c_float(float(t0)), C.c_float(float(dtv)), thr.ctypes.data_as(C.c_void_p),
-                            emit.ctypes.data_as(C.c_void_p), C.c_long(n_ev), C.c_int(limit), C.c_long(cap),
+                            emit.ctypes.data_as(C.c_void_p), C.c_long(n_ev), C.c_int(limit), C.c_int(case % 3), C.c_long(cap),
                             *[b.ctypes.data_as(C.c_void_p) for b in bufs], tl.ctypes.data_as(C.c_void_p),
                             C.byref(nb), C.byref(nj))
         assert na == nb.value, (case, na, nb.value)
@@ -198,3 +222,11 @@ def test_stepper_matches_serial(tmp_path):
         assert (bufs[1][:m].view(np.uint32) == bufs[3][:m].view(np.uint32)).all(), case
         total_jumps += nj.value; total_samples += na
     assert total_samples > 100000 and total_jumps > 3000     # the shortcut is actually exercised
+    # the headline case (camera 2.2 .. 4.2 units from the box, bench step): ~30-40 calls without the table, a handful with
+    lib.approach_calls.restype = C.c_int
+    out = [C.c_float(), C.c_float()]
+    for thr in (2.2, 2.9, 3.99, 4.01, 4.4, 0.9):
+        c0 = lib.approach_calls(C.c_float(0.0), C.c_float(2 * 3 ** 0.5 / 1024), C.c_float(thr), 0, C.byref(out[0]))
+        c1 = lib.approach_calls(C.c_float(0.0), C.c_float(2 * 3 ** 0.5 / 1024), C.c_float(thr), 1, C.byref(out[1]))
+        assert out[0].value == out[1].value == float(a_serial(lib, 0.0, thr, 2 * 3 ** 0.5 / 1024))
+        assert c0 >= 15 and c1 <= 4, (thr, c0, c1)
