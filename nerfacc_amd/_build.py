@@ -21,7 +21,7 @@ SOURCES = ["grid.hip", "traverse2.hip", "segscan.hip", "pdf.hip"]
 ARCH = os.environ.get("NERFACC_AMD_ARCH", "gfx950")
 # -ffp-contract=off: the traversal must not fuse a*b+c (floating-point contract)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", f"--offload-arch={ARCH}",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function"] + os.environ.get("NERFACC_AMD_EXTRA_FLAGS", "").split()  # tuning experiments
 
 
 def hipcc() -> str | None:

@@ -26,6 +26,12 @@
 #else
 #define NFA_HD static inline
 #endif
+// reciprocal for ESTIMATES that are verified afterwards (1 ulp hardware rcp on the device)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NFA_RCP(x) __builtin_amdgcn_rcpf(x)
+#else
+#define NFA_RCP(x) (1.0f / (x))
+#endif
 
 namespace nfa {
 
@@ -128,15 +134,16 @@ NFA_HD uint32_t stepper_advance(Stepper &s, float &t, float dt, float half, floa
         const uint32_t room = (bt | 0x7FFFFFu) - bt;                 // bit patterns left in the binade (Bb - 1 - bt)
         if (q <= room) {
             const float step_val = bits_f32(bt + q) - t;               // exact value of one step
-            // steps that keep the result inside the binade: floor(room / q), from an fp32 quotient (both < 2^24)
-            uint32_t n_b = (uint32_t)((float)room / (float)q);
-            if (n_b * q > room) n_b--;
-            // steps for which the loop condition holds: t_i + half < thr for i = 0..n-1 (true for i = 0)
-            const float est = ((thr - half) - t) / step_val;
-            uint32_t n = n_b;
-            if (est < (float)n_b) n = (uint32_t)fmaxf(est, 0.0f) + 2u;
-            if (n > n_b) n = n_b;
+            // steps for which the loop condition holds: t_i + half < thr for i = 0..n-1 (true for i = 0).  An
+            // ESTIMATE (fast reciprocal on the device), verified below.
+            const float est = ((thr - half) - t) * NFA_RCP(step_val);
+            uint32_t n = est < 8388608.0f ? (uint32_t)fmaxf(est, 0.0f) + 2u : 0x800000u;
             if (n > max_steps) n = max_steps;
+            // steps that keep the result inside the binade: floor(room / q); only computed when it binds
+            if ((uint64_t)n * q > (uint64_t)room) {
+                n = (uint32_t)((float)room / (float)q);  // both < 2^24: the quotient is off by at most one
+                if (n * q > room) n--;
+            }
             // verify the last condition test of the jump; walk back at most 4 steps, else a single step
             int tries = 0;
             while (n > 1u && !(bits_f32(bt + (n - 1u) * q) + half < thr)) {

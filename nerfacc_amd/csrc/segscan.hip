@@ -276,6 +276,54 @@ __device__ __forceinline__ void flush_totals(const StepHeads &hd, const float pr
     }
 }
 
+// Stage-B flavour of scan_values + flush_totals: only the per-ray totals are wanted, so the scan runs
+// channel by channel (about ten live registers per channel instead of N x 12) and every finished ray's
+// value goes straight to done(rid, ch, total).  xb(k, ch) yields the input of element k (scan order).
+template <int N, class FX, class FD>
+__device__ __forceinline__ void scan_totals(const StepHeads &hd, FX &&xb, float carry[N], FD &&done)
+{
+    bool f[4];
+    int nf = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { f[k] = hd.is_head[k] && hd.prev_rid[k] >= 0; nf += f[k] ? 1 : 0; }
+    const int32_t rid1 = f[0] ? hd.prev_rid[0] : (f[1] ? hd.prev_rid[1] : (f[2] ? hd.prev_rid[2] : hd.prev_rid[3]));
+    const bool more = __ballot(nf > 1) != 0ull;  // wave-uniform, rare: a lane closing two or more rays
+#pragma unroll
+    for (int ch = 0; ch < N; ++ch) {
+        float li[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float x = xb(k, ch);
+            li[k] = (k == 0 || hd.is_head[k]) ? x : li[k - 1 < 0 ? 0 : k - 1] + x;
+        }
+        float av[1] = {li[3]};
+        auto ident = [](int) { return 0.0f; };
+        auto add = [](int, float u, float v) { return u + v; };
+        values_step<0, 1>(hd, av, ident, add); values_step<1, 1>(hd, av, ident, add);
+        values_step<2, 1>(hd, av, ident, add); values_step<3, 1>(hd, av, ident, add);
+        values_step<4, 1>(hd, av, ident, add); values_step<5, 1>(hd, av, ident, add);
+        float pv = dpp_prev_lane(0.0f, av[0]);
+        if (hd.open_prefix) pv = carry[ch] + pv;
+        // prev[k]: inclusive value of the element before k
+        float prev[4], incl = pv;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            prev[k] = incl;
+            incl = hd.lh[k] >= 0 ? li[k] : pv + li[k];
+        }
+        if (nf > 0) done(rid1, ch, f[0] ? prev[0] : (f[1] ? prev[1] : (f[2] ? prev[2] : prev[3])));
+        if (more) {
+            bool seen = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (f[k] && seen) done(hd.prev_rid[k], ch, prev[k]);
+                seen = seen || f[k];
+            }
+        }
+        carry[ch] = last_lane(incl);
+    }
+}
+
 __device__ __forceinline__ int64_t uniform64(int64_t v)
 {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)v);
@@ -300,7 +348,7 @@ __device__ __forceinline__ int64_t uniform64(int64_t v)
 //              const float incl[NCH], const float prev[NCH]);
 //        incl = inclusive scan value at this element; prev = inclusive value of the previous
 //        element in scan order (in that element's own ray; exclusive value = is_head ? identity : prev)
-//   float xb(int j, int ch);  void ray_done_b(int rid, const float total[NCHB]);     (stage B)
+//   float xb(int j, int ch);  void ray_done_b(int rid, int ch, float total);          (stage B)
 //   void  store(const Pos &q);
 //   void  empty_ray(int rid);
 // Everything that is the same for the whole wave (tile bounds, step base, loop control) is kept in
@@ -411,6 +459,7 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
                 const int j = DIR > 0 ? k : 3 - k;
                 op.pre(j, q.p0() + j, q.valid[j], hd.rid[k]);
             }
+            op.store_pre(q);
         }
         // ---- stage A: scan of op.x, results to op.emit
         {
@@ -430,19 +479,15 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
             }
             if constexpr (Op::TOTALS) flush_totals<NCH>(hd, prev, [&](int32_t rid, const float *t) { op.ray_done(rid, t); });
         }
-        // ---- stage B (optional): per-ray totals of values derived from stage A's results
-        if constexpr (Op::NCHB > 0) {
-            float xb[4][NCB], incl[4][NCB], prev[4][NCB];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int j = DIR > 0 ? k : 3 - k;
-#pragma unroll
-                for (int ch = 0; ch < NCB; ++ch) xb[k][ch] = q.valid[j] ? op.xb(j, ch) : 0.0f;
-            }
-            scan_values<NCB>(hd, xb, carry_b, incl, prev, [](int) { return 0.0f; }, [](int, float u, float v) { return u + v; });
-            flush_totals<NCB>(hd, prev, [&](int32_t rid, const float *t) { op.ray_done_b(rid, t); });
-        }
+        // ---- stage B (optional): per-ray totals of values derived from stage A's results.  The per-element
+        //      outputs are complete after stage A: they are stored first (their registers are free for stage B
+        //      and the stores are in flight while it runs).
         op.store(q);
+        if constexpr (Op::NCHB > 0) {
+            scan_totals<NCB>(hd,
+                             [&](int k, int ch) { const int j = DIR > 0 ? k : 3 - k; return q.valid[j] ? op.xb(j, ch) : 0.0f; },
+                             carry_b, [&](int32_t rid, int ch, float t) { op.ray_done_b(rid, ch, t); });
+        }
         carry_rid = last_lane(hd.rid[3]);
         if (PIPE) raw_cur = raw_next;
     }
@@ -457,7 +502,10 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
     }
     if (carry_rid >= 0 && lane == 0) {
         if constexpr (Op::TOTALS) op.ray_done(carry_rid, carry);
-        if constexpr (Op::NCHB > 0) op.ray_done_b(carry_rid, carry_b);
+        if constexpr (Op::NCHB > 0) {
+#pragma unroll
+            for (int ch = 0; ch < NCB; ++ch) op.ray_done_b(carry_rid, ch, carry_b[ch]);
+        }
     }
 }
 
@@ -479,7 +527,7 @@ static void launch_seg(const Op &op, const int64_t *packed_info, const int64_t *
 {
     const longlong2 *tiles = reinterpret_cast<const longlong2 *>(tiles_raw);
     const unsigned grid = (unsigned)ceil_div64(n_tiles, SEG_WAVES_PER_BLOCK);
-    static const bool pipe = getenv("NFA_SEG_PIPELINE") ? atoi(getenv("NFA_SEG_PIPELINE")) != 0 : true;
+    static const bool pipe = getenv("NFA_SEG_PIPELINE") ? atoi(getenv("NFA_SEG_PIPELINE")) != 0 : false;  // measured: no gain, more VGPRs
     if (pipe)
         hipLaunchKernelGGL((seg_kernel<DIR, true, Op>), dim3(grid), dim3(64 * SEG_WAVES_PER_BLOCK), 0, s, op, packed_info, tiles,
                            n_rays, n_tiles);
@@ -777,7 +825,7 @@ struct VisibilityOp {
         m[j] = (valid && v) ? 1 : 0;
     }
     __device__ __forceinline__ float xb(int j, int) const { return (float)m[j]; }
-    __device__ __forceinline__ void ray_done_b(int rid, const float tot[1]) const { cnts[rid] = (int64_t)tot[0]; }
+    __device__ __forceinline__ void ray_done_b(int rid, int, float tot) const { cnts[rid] = (int64_t)tot; }
     __device__ __forceinline__ void store(const Pos &q)
     {
         const bool *valid = q.valid;
@@ -1149,7 +1197,12 @@ struct RenderFusedFwdOp : OpBase1 {
         colors[3 * (int64_t)rid] = t[0]; colors[3 * (int64_t)rid + 1] = t[1]; colors[3 * (int64_t)rid + 2] = t[2];
         opac[rid] = t[3]; depth[rid] = t[4];
     }
-    __device__ __forceinline__ void ray_done_b(int rid, const float t[5]) const { put(rid, t); }
+    __device__ __forceinline__ void ray_done_b(int rid, int ch, float t) const
+    {
+        if (ch < 3) colors[3 * (int64_t)rid + ch] = t;
+        else if (ch == 3) opac[rid] = t;
+        else depth[rid] = t;
+    }
     __device__ __forceinline__ void empty_ray(int rid) const
     {
         const float z[5] = {0, 0, 0, 0, 0};
@@ -1170,36 +1223,36 @@ struct RenderFusedFwdOp : OpBase1 {
 //      from the per-ray output gradients (needs the ray id before the scan: NEEDS_RID), added to the
 //      gradients arriving at extras' weights / trans / alphas, and pushed through the transmittance
 //      chain.  Same expressions as RenderAccumBwdOp followed by DensityBwdOp.
-template <bool VEC>
+template <bool VEC, bool EXTRA /* gradients arrive at weights / trans / alphas too */>
 struct RenderFusedBwdOp : OpBase1 {
     static constexpr bool NEEDS_RID = true;
     struct Raw { F4 a, b, T, A, gw, gt, ga; float c[12]; };
     const float *ts, *te, *rgb, *tr, *al, *gc, *go, *gd, *gw, *gt, *ga;
     float *gsig, *grgb;
     float T[4], A[4], GW[4], GT[4], GA[4], dlt[4], mid[4], q[4], rs[4], c[12], gr[12];
-    bool full;
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
         ld4<VEC>(ts, q, r.a);
         ld4<VEC>(te, q, r.b);
         ld4<VEC>(tr, q, r.T);
         ld4<VEC>(al, q, r.A);
-        if (gw) ld4<VEC>(gw, q, r.gw);
-        if (gt) ld4<VEC>(gt, q, r.gt);
-        if (ga) ld4<VEC>(ga, q, r.ga);
+        if (EXTRA) {
+            if (gw) ld4<VEC>(gw, q, r.gw);
+            if (gt) ld4<VEC>(gt, q, r.gt);
+            if (ga) ld4<VEC>(ga, q, r.ga);
+        }
         load_rgb12(rgb, VEC, q, r.c);
     }
     __device__ __forceinline__ void load(const Raw &r, const Pos &pos)
     {
         const bool *valid = pos.valid;
-        full = VEC && valid[0] && valid[1] && valid[2] && valid[3];
         fix_rgb12(rgb, VEC, pos, r.c, c);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             T[j] = sel(r.T, j, valid, 0.0f); A[j] = sel(r.A, j, valid, 0.0f);
-            GW[j] = (gw && valid[j]) ? r.gw.v[j] : 0.0f;
-            GT[j] = (gt && valid[j]) ? r.gt.v[j] : 0.0f;
-            GA[j] = (ga && valid[j]) ? r.ga.v[j] : 0.0f;
+            GW[j] = (EXTRA && gw && valid[j]) ? r.gw.v[j] : 0.0f;
+            GT[j] = (EXTRA && gt && valid[j]) ? r.gt.v[j] : 0.0f;
+            GA[j] = (EXTRA && ga && valid[j]) ? r.ga.v[j] : 0.0f;
             dlt[j] = r.b.v[j] - r.a.v[j];
             mid[j] = (r.a.v[j] + r.b.v[j]) / 2.0f;
         }
@@ -1221,6 +1274,25 @@ struct RenderFusedBwdOp : OpBase1 {
         GW[j] = g + GW[j];
         q[j] = GW[j] * wj + GT[j] * T[j];
     }
+    // g_rgb is complete before the scan: stored first (frees its registers, stores in flight during the scan)
+    __device__ __forceinline__ void store_pre(const Pos &pq)
+    {
+        if (!grgb) return;
+        float *b = grgb + 3 * pq.c;
+        if (VEC && pq.all) {
+            float4 *qq = reinterpret_cast<float4 *>(b + 3 * pq.off);
+            qq[0] = make_float4(gr[0], gr[1], gr[2], gr[3]);
+            qq[1] = make_float4(gr[4], gr[5], gr[6], gr[7]);
+            qq[2] = make_float4(gr[8], gr[9], gr[10], gr[11]);
+        } else {
+            volatile float *pv = b;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (pq.valid[j]) {
+                    pv[3 * (pq.off + j)] = gr[3 * j]; pv[3 * (pq.off + j) + 1] = gr[3 * j + 1]; pv[3 * (pq.off + j) + 2] = gr[3 * j + 2];
+                }
+        }
+    }
     __device__ __forceinline__ float x(int j, int) const { return q[j]; }
     __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int, int, const float *, const float prev[1])
     {
@@ -1229,27 +1301,9 @@ struct RenderFusedBwdOp : OpBase1 {
         const float Bv = GW[j] * T[j] * om + GA[j] * om - E;
         rs[j] = dlt[j] * Bv;
     }
-    __device__ __forceinline__ void store(const Pos &q)
+    __device__ __forceinline__ void store(const Pos &pq)
     {
-        const bool *valid = q.valid;
-        const int64_t p0 = q.p0();
-        (void)valid; (void)p0;
-        if (gsig) store4<VEC>(gsig, q, rs);
-        if (grgb) {
-            if (full) {
-                float4 *qq = reinterpret_cast<float4 *>(grgb + 3 * p0);
-                qq[0] = make_float4(gr[0], gr[1], gr[2], gr[3]);
-                qq[1] = make_float4(gr[4], gr[5], gr[6], gr[7]);
-                qq[2] = make_float4(gr[8], gr[9], gr[10], gr[11]);
-            } else {
-                volatile float *pv = grgb;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (valid[j]) {
-                        pv[3 * (p0 + j)] = gr[3 * j]; pv[3 * (p0 + j) + 1] = gr[3 * j + 1]; pv[3 * (p0 + j) + 2] = gr[3 * j + 2];
-                    }
-            }
-        }
+        if (gsig) store4<VEC>(gsig, pq, rs);
     }
 };
 
@@ -1683,12 +1737,14 @@ int nfa_render_fused_bwd(const float *t_starts, const float *t_ends, const float
     NFA_REQUIRE(t_starts && t_ends && rgbs && trans && alphas && (grad_sigmas || grad_rgbs), "render_fused_bwd: null pointer");
     hipStream_t s = as_stream(stream);
     const bool vec = all_aligned16(t_starts, t_ends, rgbs, trans, alphas, g_weights, g_trans, g_alphas, grad_sigmas, grad_rgbs);
-#define NFA_FB(V)                                                                                          \
-    do { RenderFusedBwdOp<V> op; op.ts = t_starts; op.te = t_ends; op.rgb = rgbs; op.tr = trans; op.al = alphas; \
+#define NFA_FB(V, X)                                                                                       \
+    do { RenderFusedBwdOp<V, X> op; op.ts = t_starts; op.te = t_ends; op.rgb = rgbs; op.tr = trans; op.al = alphas; \
          op.gc = g_colors; op.go = g_opacities; op.gd = g_depths; op.gw = g_weights; op.gt = g_trans; op.ga = g_alphas; \
          op.gsig = grad_sigmas; op.grgb = grad_rgbs;                                                         \
          launch_seg<-1>(op, packed_info, tiles, n_rays, n_tiles, s); } while (0)
-    if (vec) NFA_FB(true); else NFA_FB(false);
+    const bool extra = g_weights || g_trans || g_alphas;
+    if (vec) { if (extra) NFA_FB(true, true); else NFA_FB(true, false); }
+    else     { if (extra) NFA_FB(false, true); else NFA_FB(false, false); }
 #undef NFA_FB
     NFA_CHECK_LAUNCH("render_fused_bwd");
     return NFA_OK;
