@@ -120,7 +120,8 @@ int nfa_traverse_grids(const nfa_traverse_args *args, nfa_stream_t stream);
  *   nfa_pack_bricks    torch.bool grid -> 4x4x4-cell 64-bit bricks + 1 bit per brick ("coarse");
  *                      bricks has nfa_bricks_words() entries, coarse (words+31)/32 uint32.
  *   nfa_traverse_runs  per ray: sample count (args->sm_cnts), terminate plane, run count and up to
- *                      max_runs (<= 32) runs {t_first:f32 | n:31, continues_previous:1}; rays with
+ *                      max_runs (<= 32) run records {t_first:f32 | k_start:31, continues_previous:1} in
+ *                      runs[max_runs][n_rays] (slot-major: record i of ray r at runs[i * n_rays + r]); rays with
  *                      more runs are counted in *overflow_count and must be filled with
  *                      nfa_traverse_grids(mode 1, ray_filter = run_cnts, ray_filter_min = max_runs).
  *                      args->mode: 0 = all rays, 2 = honour rays_mask (+ traverse_steps_limit).

@@ -63,4 +63,35 @@ __device__ __forceinline__ int64_t wave_incl_sum_i64(int64_t v)
     return v;
 }
 
+// Cross-lane moves as DPP modifiers (one VALU instruction each, no LDS crossbar round trip):
+// step s < 4 shifts by 2^s inside each row of 16 lanes, step 4 broadcasts lane 15 of rows 0 / 2 to rows 1 / 3,
+// step 5 broadcasts lane 31 to rows 2 and 3.  Lanes without a source keep `old`.
+template <int S>
+__device__ __forceinline__ int32_t dpp_step(int32_t old, int32_t src)
+{
+    static_assert(S >= 0 && S < 6, "dpp_step");
+    if constexpr (S == 0) return __builtin_amdgcn_update_dpp(old, src, 0x111, 0xf, 0xf, false);       // row_shr:1
+    else if constexpr (S == 1) return __builtin_amdgcn_update_dpp(old, src, 0x112, 0xf, 0xf, false);  // row_shr:2
+    else if constexpr (S == 2) return __builtin_amdgcn_update_dpp(old, src, 0x114, 0xf, 0xf, false);  // row_shr:4
+    else if constexpr (S == 3) return __builtin_amdgcn_update_dpp(old, src, 0x118, 0xf, 0xf, false);  // row_shr:8
+    else if constexpr (S == 4) return __builtin_amdgcn_update_dpp(old, src, 0x142, 0xa, 0xf, false);  // row_bcast:15
+    else return __builtin_amdgcn_update_dpp(old, src, 0x143, 0xc, 0xf, false);                        // row_bcast:31
+}
+template <int S>
+__device__ __forceinline__ float dpp_step(float old, float src)
+{
+    return __int_as_float(dpp_step<S>(__float_as_int(old), __float_as_int(src)));
+}
+// value of the previous lane (lane 0 keeps `old`)
+__device__ __forceinline__ int32_t dpp_prev_lane(int32_t old, int32_t src)
+{
+    return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xf, 0xf, false);  // wave_shr:1
+}
+__device__ __forceinline__ float dpp_prev_lane(float old, float src)
+{
+    return __int_as_float(dpp_prev_lane(__float_as_int(old), __float_as_int(src)));
+}
+__device__ __forceinline__ int32_t last_lane(int32_t v) { return __builtin_amdgcn_readlane(v, 63); }
+__device__ __forceinline__ float last_lane(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+
 }  // namespace nfa

@@ -67,7 +67,8 @@ struct RunsParams {
     int32_t n_coarse_words;
     int32_t bx, by, bz;
     int32_t *run_cnts;           // [n_rays]
-    unsigned long long *runs;    // [n_rays, max_runs]
+    unsigned long long *runs;    // [max_runs, n_rays] (slot-major: a wave reads one slot of 32 rays as one 256 B line)
+    int64_t n_rays;
     int32_t max_runs;
     int32_t *overflow;           // [1] number of rays with more runs than max_runs
     ApproachTable approach;      // shared start of every ray's march (march.h); n == 0: none
@@ -111,7 +112,7 @@ __device__ __forceinline__ void close_run(RunState &st, const RunsParams &p, int
     if (!st.open) return;
     if (st.n_runs < p.max_runs) {
         const uint32_t k_start = (uint32_t)(st.n_samples - st.run_n);
-        p.runs[tid * p.max_runs + st.n_runs] =
+        p.runs[(int64_t)st.n_runs * p.n_rays + tid] =
             (unsigned long long)f32_bits(st.run_t0) | ((unsigned long long)(k_start | (st.run_cont ? 0x80000000u : 0u)) << 32);
     }
     st.n_runs++;
@@ -355,10 +356,12 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
 
 // ------------------------------------------------------------------------------------------
 // Expansion: runs -> (t_starts, t_ends, ray_indices).  One wave per batch of EXP_RPW rays.
-// Staging is a flat parallel copy: entry q of the batch belongs to the ray found by a 5-step search
-// over the per-ray run offsets, and its output position is ray start + k_start, so all loads are
-// independent.  LDS entry = {pos : 27 | local ray : 5, t_first}; a ray whose runs overflowed gets
-// one sentinel entry (t_first = NaN) so that its output range is skipped (the serial kernel fills it).
+// Staging: each half-wave lane copies alternate run records of "its" ray (slot-major records: one 256 B
+// line per slot and batch, independent loads) to LDS entry {pos : 27 | local ray : 5, t_first}, pos = the
+// run's first output relative to the batch; a ray whose runs overflowed gets one sentinel entry
+// (t_first = NaN) so that its output range is skipped (the serial kernel fills it).  Outputs are then
+// produced chunk by chunk (256 per step, 16 B per lane and array) with a scatter + "most recent entry"
+// scan that tells every output its run.
 __global__ __launch_bounds__(256) void expand_runs_kernel(int64_t n_rays, float dt, const int32_t *__restrict__ run_cnts,
                                                           const unsigned long long *__restrict__ runs, int32_t max_runs,
                                                           const int64_t *__restrict__ sm_starts,
@@ -368,13 +371,11 @@ __global__ __launch_bounds__(256) void expand_runs_kernel(int64_t n_rays, float 
 {
     __shared__ uint32_t s_pos[4][EXP_QMAX];
     __shared__ float s_t0[4][EXP_QMAX];
-    __shared__ int32_t s_base[4][EXP_RPW + 1];   // exclusive run offsets of the batch's rays
-    __shared__ uint32_t s_rel[4][EXP_RPW];       // output offset of each ray inside the batch
+    __shared__ __attribute__((aligned(16))) int32_t s_own[4][256];  // entry that starts at each output of the current chunk
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     uint32_t *pos = s_pos[wave];
     float *t0s = s_t0[wave];
-    int32_t *base = s_base[wave];
-    uint32_t *rels = s_rel[wave];
+    int32_t *slot = s_own[wave];
     const int64_t n_batches = ceil_div64(n_rays, EXP_RPW);
     for (int64_t batch = (int64_t)blockIdx.x * 4 + wave; batch < n_batches; batch += (int64_t)gridDim.x * 4) {
         const int64_t r0 = batch * EXP_RPW;
@@ -398,60 +399,98 @@ __global__ __launch_bounds__(256) void expand_runs_kernel(int64_t n_rays, float 
             if (lane >= off) incl += u;
         }
         const int32_t Q = __shfl(incl, EXP_RPW - 1, 64);
-        if (lane < EXP_RPW) { base[lane] = incl - c; rels[lane] = (uint32_t)(s - W0); }
-        if (lane == 0) base[EXP_RPW] = Q;
         // overflow flag per local ray as a wave-uniform mask
         const unsigned long long ovf_mask = __ballot(own && c_real > max_runs);
         __builtin_amdgcn_wave_barrier();
-        for (int32_t q = lane; q < Q; q += 64) {
-            int lo = 0, hi = EXP_RPW;  // last local ray with base <= q
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (base[mid] <= q) lo = mid; else hi = mid;
-            }
-            const int rl = lo;
+        {   // staging: lane -> (ray rl, half); the two half-waves take alternate slots of every ray.  The loads of
+            // different slots do not depend on each other (slot-major records: one 256 B line per slot and batch).
+            const int rl = lane & (EXP_RPW - 1), half = lane >> 5;
+            const int32_t c_rl = __shfl(c, rl, 64);
+            const int32_t base_rl = __shfl(incl - c, rl, 64);
+            const uint32_t rel_rl = (uint32_t)(__shfl(s, rl, 64) - W0);
             const bool ovf = (ovf_mask >> rl) & 1ull;
-            uint32_t k_start = 0;
-            float t0 = __builtin_nanf("");
-            if (!ovf) {
-                const unsigned long long rec = runs[(r0 + rl) * max_runs + (q - base[rl])];
-                k_start = (uint32_t)(rec >> 32) & 0x7FFFFFFFu;
-                t0 = bits_f32((uint32_t)rec);
+            int32_t c_max = c_rl;
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) c_max = max(c_max, __shfl_xor(c_max, off, 64));
+            const unsigned long long *col = runs + r0 + rl;
+            for (int32_t i0 = 0; i0 < c_max; i0 += 8) {
+                unsigned long long rec[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int32_t i = i0 + 2 * u + half;
+                    rec[u] = (i < c_rl && !ovf) ? col[(int64_t)i * n_rays] : 0ull;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int32_t i = i0 + 2 * u + half;
+                    if (i < c_rl) {
+                        const uint32_t k_start = ovf ? 0u : ((uint32_t)(rec[u] >> 32) & 0x7FFFFFFFu);
+                        const float t0 = ovf ? __builtin_nanf("") : bits_f32((uint32_t)rec[u]);
+                        pos[base_rl + i] = ((rel_rl + k_start) & 0x7FFFFFFu) | ((uint32_t)rl << 27);
+                        t0s[base_rl + i] = t0;
+                    }
+                }
             }
-            pos[q] = ((rels[rl] + k_start) & 0x7FFFFFFu) | ((uint32_t)rl << 27);
-            t0s[q] = t0;
         }
         __builtin_amdgcn_wave_barrier();
         if (Q > 0 && W1 > W0) {
+            // Each 256-output chunk: scatter the indices of the entries that start in it into a 1 KiB LDS
+            // line, then a "most recent entry" scan (4 elements per lane + 6 DPP steps, carry across chunks)
+            // gives every output its run -- no per-element search.
             const int64_t c_first = (W0 / 256) * 256;
+            int32_t q_next = 0;       // first entry not yet scattered (entries are sorted by position)
+            int32_t carry_j = -1;     // entry covering the end of the previous chunk
             for (int64_t cb = c_first; cb < W1; cb += 256) {
+                const int64_t lo64 = cb - W0;                           // chunk start relative to the window (may be < 0)
+                *reinterpret_cast<int4 *>(slot + 4 * lane) = make_int4(-1, -1, -1, -1);
+                __builtin_amdgcn_wave_barrier();
+                for (;;) {
+                    const int32_t q = q_next + lane;
+                    bool take = false;
+                    if (q < Q) {
+                        const int64_t rel = (int64_t)(pos[q] & 0x7FFFFFFu) - lo64;
+                        take = rel < 256;                                // rel >= 0: earlier entries were consumed
+                        if (take) slot[(int)rel] = q;
+                    }
+                    const int cnt = __builtin_popcountll(__ballot(take));
+                    q_next += cnt;
+                    if (cnt < 64) break;
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int4 o4 = *reinterpret_cast<const int4 *>(slot + 4 * lane);
+                __builtin_amdgcn_wave_barrier();
+                // most recent entry at or before each element
+                int32_t j4[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+                for (int k = 1; k < 4; ++k) j4[k] = j4[k] >= 0 ? j4[k] : j4[k - 1];
+                int32_t ah = j4[3];
+                { int32_t u = dpp_step<0>(-1, ah); ah = ah >= 0 ? ah : u; }
+                { int32_t u = dpp_step<1>(-1, ah); ah = ah >= 0 ? ah : u; }
+                { int32_t u = dpp_step<2>(-1, ah); ah = ah >= 0 ? ah : u; }
+                { int32_t u = dpp_step<3>(-1, ah); ah = ah >= 0 ? ah : u; }
+                { int32_t u = dpp_step<4>(-1, ah); ah = ah >= 0 ? ah : u; }
+                { int32_t u = dpp_step<5>(-1, ah); ah = ah >= 0 ? ah : u; }
+                int32_t pj = dpp_prev_lane(-1, ah);
+                if (pj < 0) pj = carry_j;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) j4[k] = j4[k] >= 0 ? j4[k] : pj;
+                carry_j = nfa::last_lane(j4[3]);
+
                 const int64_t p0 = cb + 4 * lane;
                 bool valid[4];
                 float ts4[4], te4[4];
                 int64_t ri4[4];
-                int32_t j = -1;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int64_t pa = p0 + k;
+                    const int32_t j = j4[k];
                     valid[k] = false;
                     ts4[k] = te4[k] = 0.f; ri4[k] = 0;
-                    if (pa < W0 || pa >= W1) continue;
-                    const uint32_t pr = (uint32_t)(pa - W0);
-                    if (j < 0) {  // last entry with position <= pr
-                        int32_t lo = 0, hi = Q;
-                        while (lo < hi) {
-                            const int32_t mid = (lo + hi) >> 1;
-                            if ((pos[mid] & 0x7FFFFFFu) <= pr) lo = mid + 1; else hi = mid;
-                        }
-                        j = lo - 1;
-                    } else {
-                        while (j + 1 < Q && (pos[j + 1] & 0x7FFFFFFu) <= pr) ++j;
-                    }
-                    if (j < 0) continue;
+                    if (pa < W0 || pa >= W1 || j < 0) continue;
                     const float t0 = t0s[j];
                     if (t0 != t0) continue;  // sentinel: overflowed ray, filled by the serial kernel
                     const uint32_t e = pos[j];
-                    const uint32_t kk = pr - (e & 0x7FFFFFFu);
+                    const uint32_t kk = (uint32_t)(pa - W0) - (e & 0x7FFFFFFu);
                     const float inc = (t0 + dt) - t0;  // the run's exact per-step increment
                     // t0 + k * inc is exactly representable for every sample of a run (that is what makes it a run),
                     // so one fused multiply-add (single rounding of the exact value) reproduces the serial sums
@@ -534,6 +573,7 @@ int nfa_traverse_runs(const nfa_traverse_args *pa, const uint64_t *bricks, const
     p.run_cnts = run_cnts;
     p.runs = reinterpret_cast<unsigned long long *>(runs);
     p.max_runs = max_runs;
+    p.n_rays = a.n_rays;
     p.overflow = overflow_count;
     // near_hint: the value most (or all) entries of near_planes hold, NaN if unknown.  Rays whose near plane
     // differs bit-wise simply do not use the table.

@@ -267,7 +267,7 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
         if use_runs:
             bricks, coarse = _get_bricks(binaries)
             run_cnts = torch.empty(n_rays, dtype=torch.int32, device=dev)
-            runs = torch.empty((n_rays, MAX_RUNS), dtype=torch.int64, device=dev)
+            runs = torch.empty((MAX_RUNS, n_rays), dtype=torch.int64, device=dev)  # slot-major run records
             # near_hint: the scalar near plane when the caller built near_planes from one (accelerator only)
             B.call("nfa_traverse_runs", C.byref(a), B.ptr(bricks), B.ptr(coarse), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
                    B.ptr(meta[1:2]), float("nan") if near_hint is None else float(near_hint), B.stream())
