@@ -14,7 +14,7 @@ from torch import Tensor
 from torch.autograd.function import once_differentiable
 
 from . import _backend as B
-from ._segments import SegInfo, seginfo_from_packed
+from ._segments import SegInfo, batched_native, seginfo_from_packed
 
 _KIND = {"inclusive_sum": 0, "exclusive_sum": 1, "inclusive_prod": 2, "exclusive_prod": 3}
 
@@ -97,7 +97,10 @@ def inclusive_sum(inputs: Tensor, packed_info: Optional[Tensor] = None, normaliz
     tensor([ 1.,  3.,  3.,  7., 12.,  6., 13., 21., 30.])
     """
     if packed_info is None:
-        return torch.cumsum(inputs, dim=-1)
+        seg = batched_native(inputs)
+        if seg is None:
+            return torch.cumsum(inputs, dim=-1)
+        return _PackedSum.apply(inputs.contiguous().view(-1), seg, _KIND["inclusive_sum"], normalize).view(inputs.shape)
     seg = _check_packed(inputs, packed_info)
     return _PackedSum.apply(inputs, seg, _KIND["inclusive_sum"], normalize)
 
@@ -105,7 +108,10 @@ def inclusive_sum(inputs: Tensor, packed_info: Optional[Tensor] = None, normaliz
 def exclusive_sum(inputs: Tensor, packed_info: Optional[Tensor] = None, normalize: bool = False) -> Tensor:
     """Exclusive sum (ref: scan.py:56-102)."""
     if packed_info is None:
-        return torch.cumsum(torch.cat([torch.zeros_like(inputs[..., :1]), inputs[..., :-1]], dim=-1), dim=-1)
+        seg = batched_native(inputs)
+        if seg is None:
+            return torch.cumsum(torch.cat([torch.zeros_like(inputs[..., :1]), inputs[..., :-1]], dim=-1), dim=-1)
+        return _PackedSum.apply(inputs.contiguous().view(-1), seg, _KIND["exclusive_sum"], normalize).view(inputs.shape)
     seg = _check_packed(inputs, packed_info)
     return _PackedSum.apply(inputs, seg, _KIND["exclusive_sum"], normalize)
 
@@ -113,7 +119,10 @@ def exclusive_sum(inputs: Tensor, packed_info: Optional[Tensor] = None, normaliz
 def inclusive_prod(inputs: Tensor, packed_info: Optional[Tensor] = None) -> Tensor:
     """Inclusive product (ref: scan.py:105-146)."""
     if packed_info is None:
-        return torch.cumprod(inputs, dim=-1)
+        seg = batched_native(inputs)
+        if seg is None:
+            return torch.cumprod(inputs, dim=-1)
+        return _PackedProd.apply(inputs.contiguous().view(-1), seg, _KIND["inclusive_prod"]).view(inputs.shape)
     seg = _check_packed(inputs, packed_info)
     return _PackedProd.apply(inputs, seg, _KIND["inclusive_prod"])
 
@@ -121,6 +130,9 @@ def inclusive_prod(inputs: Tensor, packed_info: Optional[Tensor] = None) -> Tens
 def exclusive_prod(inputs: Tensor, packed_info: Optional[Tensor] = None) -> Tensor:
     """Exclusive product (ref: scan.py:149-186)."""
     if packed_info is None:
-        return torch.cumprod(torch.cat([torch.ones_like(inputs[..., :1]), inputs[..., :-1]], dim=-1), dim=-1)
+        seg = batched_native(inputs)
+        if seg is None:
+            return torch.cumprod(torch.cat([torch.ones_like(inputs[..., :1]), inputs[..., :-1]], dim=-1), dim=-1)
+        return _PackedProd.apply(inputs.contiguous().view(-1), seg, _KIND["exclusive_prod"]).view(inputs.shape)
     seg = _check_packed(inputs, packed_info)
     return _PackedProd.apply(inputs, seg, _KIND["exclusive_prod"])

@@ -16,7 +16,7 @@ from torch import Tensor
 from torch.autograd.function import once_differentiable
 
 from . import _backend as B
-from ._segments import SegInfo, resolve, seginfo_from_ray_indices
+from ._segments import SegInfo, batched_native, resolve, seginfo_from_ray_indices
 from .scan import exclusive_prod, exclusive_sum
 
 
@@ -331,6 +331,21 @@ def _finish_rendering(colors, opacities, depths, extras, rgbs, render_bkgd):
     return colors, opacities, depths, extras
 
 
+def _batched_as_packed(fn, tensors, packed_info, ray_indices, **kw):
+    """Batched ``(..., S)`` CUDA float32 inputs: run the packed native op on the flat view with uniform
+    segments (the reference composes torch.cumsum / cumprod here, volrend.py:203-206,259-264) and give
+    the outputs the batched shape back.  Returns None when the torch composition must be used."""
+    if packed_info is not None or ray_indices is not None:
+        return None
+    useg = batched_native(*tensors)
+    if useg is None:
+        return None
+    shape = next(t for t in tensors if t is not None).shape
+    flat = [None if t is None else t.contiguous().view(-1) for t in tensors]
+    out = fn(*flat[:-1], packed_info=useg.packed_info, prefix_trans=flat[-1], **kw)
+    return tuple(o.view(shape) for o in out) if isinstance(out, tuple) else out.view(shape)
+
+
 def render_transmittance_from_alpha(
     alphas: Tensor,
     packed_info: Optional[Tensor] = None,
@@ -339,6 +354,9 @@ def render_transmittance_from_alpha(
     prefix_trans: Optional[Tensor] = None,
 ) -> Tensor:
     """Transmittance ``T_i = prod_{j<i}(1 - alpha_j)`` (ref: volrend.py:161-206)."""
+    out = _batched_as_packed(render_transmittance_from_alpha, (alphas, prefix_trans), packed_info, ray_indices)
+    if out is not None:
+        return out
     seg = resolve(alphas.numel(), packed_info, ray_indices, n_rays) if alphas.dim() == 1 else None
     if _use_fused(seg, alphas, prefix_trans) and not _prefix_needs_grad(prefix_trans):
         _, trans = _RenderFromAlpha.apply(alphas, prefix_trans, seg, False)
@@ -359,6 +377,9 @@ def render_transmittance_from_density(
     prefix_trans: Optional[Tensor] = None,
 ) -> Tuple[Tensor, Tensor]:
     """``T_i = exp(-sum_{j<i} sigma_j delta_j)`` and ``alpha_i`` (ref: volrend.py:209-264)."""
+    out = _batched_as_packed(render_transmittance_from_density, (t_starts, t_ends, sigmas, prefix_trans), packed_info, ray_indices)
+    if out is not None:
+        return out
     seg = resolve(sigmas.numel(), packed_info, ray_indices, n_rays) if sigmas.dim() == 1 else None
     if _use_fused(seg, t_starts, t_ends, sigmas, prefix_trans) and not _prefix_needs_grad(prefix_trans):
         _, trans, alphas = _RenderFromDensity.apply(t_starts, t_ends, sigmas, prefix_trans, seg, False)
@@ -379,6 +400,9 @@ def render_weight_from_alpha(
     prefix_trans: Optional[Tensor] = None,
 ) -> Tuple[Tensor, Tensor]:
     """``w_i = T_i alpha_i``; returns (weights, transmittance) (ref: volrend.py:267-309)."""
+    out = _batched_as_packed(render_weight_from_alpha, (alphas, prefix_trans), packed_info, ray_indices)
+    if out is not None:
+        return out
     seg = resolve(alphas.numel(), packed_info, ray_indices, n_rays) if alphas.dim() == 1 else None
     if _use_fused(seg, alphas, prefix_trans) and not _prefix_needs_grad(prefix_trans):
         return _RenderFromAlpha.apply(alphas, prefix_trans, seg, True)
@@ -398,6 +422,9 @@ def render_weight_from_density(
 ) -> Tuple[Tensor, Tensor, Tensor]:
     """``w_i = T_i (1 - exp(-sigma_i delta_i))``; returns (weights, transmittance, alphas)
     (ref: volrend.py:312-362)."""
+    out = _batched_as_packed(render_weight_from_density, (t_starts, t_ends, sigmas, prefix_trans), packed_info, ray_indices)
+    if out is not None:
+        return out
     seg = resolve(sigmas.numel(), packed_info, ray_indices, n_rays) if sigmas.dim() == 1 else None
     if _use_fused(seg, t_starts, t_ends, sigmas, prefix_trans) and not _prefix_needs_grad(prefix_trans):
         return _RenderFromDensity.apply(t_starts, t_ends, sigmas, prefix_trans, seg, True)
@@ -432,6 +459,9 @@ def render_visibility_from_alpha(
 ) -> Tensor:
     """Visibility mask ``T >= early_stop_eps`` and, if ``alpha_thre > 0``, ``alpha >= alpha_thre``
     (ref: volrend.py:365-418)."""
+    out = _batched_as_packed(render_visibility_from_alpha, (alphas, prefix_trans), packed_info, ray_indices, early_stop_eps=early_stop_eps, alpha_thre=alpha_thre)
+    if out is not None:
+        return out
     seg = resolve(alphas.numel(), packed_info, ray_indices, n_rays) if alphas.dim() == 1 else None
     if _use_fused(seg, alphas, prefix_trans):
         return _visibility_native(seg, None, None, alphas, prefix_trans, early_stop_eps, alpha_thre)
@@ -456,6 +486,9 @@ def render_visibility_from_density(
     prefix_trans: Optional[Tensor] = None,
 ) -> Tensor:
     """Visibility mask from densities (ref: volrend.py:421-480)."""
+    out = _batched_as_packed(render_visibility_from_density, (t_starts, t_ends, sigmas, prefix_trans), packed_info, ray_indices, early_stop_eps=early_stop_eps, alpha_thre=alpha_thre)
+    if out is not None:
+        return out
     seg = resolve(sigmas.numel(), packed_info, ray_indices, n_rays) if sigmas.dim() == 1 else None
     if _use_fused(seg, t_starts, t_ends, sigmas, prefix_trans):
         return _visibility_native(seg, t_starts, t_ends, sigmas, prefix_trans, early_stop_eps, alpha_thre)

@@ -351,6 +351,48 @@ def test_rendering_fused_pass_is_bit_identical_to_two_passes(dev, oracle):
     assert torch.equal(sig.grad, sig2.grad) and torch.equal(rgb.grad, rgb2.grad) and torch.equal(c, c2)
 
 
+def test_batched_inputs_take_the_native_path(dev):
+    """Batched (R, S) CUDA tensors run on the flat segmented engine with uniform segments (the reference
+    composes torch.cumsum / cumprod, scan.py:42-44, volrend.py:203-206): same values as that composition
+    (golden batched vectors come from the reference itself), forward and backward."""
+    g = load_golden("batched_volrend")
+    rng = np.random.default_rng(3)
+    R, S = 1037, 48
+    x = torch.from_numpy(rng.uniform(0.1, 1.0, (R, S)).astype(np.float32)).to(dev)
+    assert_close(na.inclusive_sum(x), torch.cumsum(x.double(), -1).float(), atol=2e-5, rtol=1e-5)
+    assert_close(na.exclusive_sum(x), (torch.cumsum(x.double(), -1) - x.double()).float(), atol=2e-5, rtol=1e-5)
+    assert_close(na.inclusive_prod(x), torch.cumprod(x.double(), -1).float(), atol=1e-6, rtol=2e-5)
+    assert_close(na.exclusive_prod(x[:, :12]), (torch.cumprod(x[:, :12].double(), -1) / x[:, :12].double()).float(),
+                 atol=1e-6, rtol=2e-5)
+    assert na.inclusive_sum(x[0]).shape == (S,) and na.exclusive_sum(x.view(17, 61, S)).shape == (17, 61, S)
+    ts = torch.from_numpy(np.sort(rng.uniform(0, 4, (R, S + 1)).astype(np.float32), -1)).to(dev)
+    t0, t1 = ts[:, :-1].contiguous(), ts[:, 1:].contiguous()
+    sig = torch.from_numpy(rng.uniform(0, 8, (R, S)).astype(np.float32)).to(dev).requires_grad_(True)
+    gw = torch.from_numpy(rng.normal(size=(R, S)).astype(np.float32)).to(dev)
+    w, tr, al = na.render_weight_from_density(t0, t1, sig)
+    ((w * gw).sum() + 0.5 * tr.sum()).backward()
+    sig2 = sig.detach().clone().requires_grad_(True)
+    sdt = sig2 * (t1 - t0)
+    tr2 = torch.exp(-(torch.cumsum(sdt, -1) - sdt)); al2 = 1 - torch.exp(-sdt); w2 = tr2 * al2
+    ((w2 * gw).sum() + 0.5 * tr2.sum()).backward()
+    assert_close(w, w2, atol=1e-5); assert_close(tr, tr2, atol=1e-5); assert_close(al, al2, atol=1e-6)
+    assert_close(sig.grad, sig2.grad, atol=3e-5, rtol=1e-4)
+    a = torch.from_numpy(rng.uniform(0, 0.3, (R, S)).astype(np.float32)).to(dev).requires_grad_(True)
+    w, tr = na.render_weight_from_alpha(a)
+    (w * gw).sum().backward()
+    a2 = a.detach().clone().requires_grad_(True)
+    tr2 = torch.cumprod(torch.cat([torch.ones_like(a2[:, :1]), 1 - a2[:, :-1]], -1), -1)
+    ((tr2 * a2) * gw).sum().backward()
+    assert_close(w, tr2 * a2, atol=1e-5); assert_close(a.grad, a2.grad, atol=3e-5, rtol=1e-4)
+    vis = na.render_visibility_from_density(t0, t1, sig.detach(), early_stop_eps=1e-2, alpha_thre=1e-3)
+    ref = (tr.new_tensor(0) + torch.exp(-(torch.cumsum(sdt, -1) - sdt)) >= 1e-2) & (al2 >= 1e-3)
+    assert vis.shape == (R, S) and (vis != ref).float().mean() < 1e-4
+    # the reference's own batched vectors
+    gts, gte = T(g["ts"], dev), T(g["te"], dev)
+    w, tr, al = na.render_weight_from_density(gts, gte, T(g["sig"], dev))
+    assert_close(w, g["w"], atol=1e-5); assert_close(tr, g["trans"], atol=1e-5); assert_close(al, g["alphas"], atol=1e-6)
+
+
 def test_ray_aabb_intersect(dev, oracle):
     g = load_golden("ray_aabb")
     tm, tM, hit = na.ray_aabb_intersect(T(g["rays_o"], dev), T(g["rays_d"], dev), T(g["aabbs"], dev))
