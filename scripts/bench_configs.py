@@ -85,6 +85,21 @@ def cfg5(dev, R, steps, warmup, res=512, G=4):
                 ms_per_step=dt * 1e3, rays_per_s=R / dt, samples_after_compaction=int(m), native=ks)
 
 
+def api_traverse(dev, R, steps, warmup):
+    """The API-faithful traverse_grids (intervals + samples + masks) on the cfg-2 workload."""
+    w = bench.make_workload(dev, R)
+    est = w["estimator"]
+
+    def step():
+        iv, sm, _ = na.traverse_grids(w["rays_o"], w["rays_d"], est.binaries, est.aabbs, step_size=w["step"])
+        return iv.vals.numel(), sm.vals.numel()
+
+    dt, ks, (E, M) = timed(step, steps, warmup)
+    nbytes = 14 * E + 13 * M + 36 * R + R * 32 + est.binaries.numel()
+    return dict(config="api traverse_grids on cfg2: R=%d, E=%d edges, M=%d samples" % (R, E, M), ms_per_step=dt * 1e3,
+                rays_per_s=R / dt, algorithmic_bytes=nbytes, achieved_GBps=nbytes / dt / 1e9, native=ks)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("cfgs", nargs="*", default=["cfg3", "cfg5"])
@@ -97,6 +112,8 @@ if __name__ == "__main__":
     for c in a.cfgs:
         if c == "cfg3":
             out = cfg3(dev, a.rays or 1 << 20, a.steps, a.warmup)
+        elif c == "trav":
+            out = api_traverse(dev, a.rays or 1 << 20, a.steps, a.warmup)
         else:
             out = cfg5(dev, a.rays or 1 << 21, a.steps, a.warmup, res=a.res)
         print(json.dumps(out), flush=True)
