@@ -128,7 +128,8 @@ int nfa_traverse_grids(const nfa_traverse_args *args, nfa_stream_t stream);
  *                      near_hint: the value (most of) args->near_planes hold, NaN if unknown; a pure
  *                      accelerator (the march from a common near plane to the grid is tabulated once on
  *                      the host), rays with another near plane are unaffected, results never change.
- *   nfa_expand_runs    runs + exclusive cumsum of the counts -> t_starts, t_ends, ray_indices. */
+ *   nfa_expand_runs    runs + exclusive cumsum of the counts -> (t_starts, t_ends) or, when t_mids is given,
+ *                      the API's sample values (t_start + t_end) / 2; and ray_indices. */
 int64_t nfa_bricks_words(int32_t n_grids, const int32_t *res);
 int nfa_pack_bricks(const uint8_t *binaries, int32_t n_grids, const int32_t *res, uint64_t *bricks,
                     uint32_t *coarse, nfa_stream_t stream);
@@ -137,7 +138,13 @@ int nfa_traverse_runs(const nfa_traverse_args *args, const uint64_t *bricks, con
                       float near_hint, nfa_stream_t stream);
 int nfa_expand_runs(int64_t n_rays, float step_size, const int32_t *run_cnts, const uint64_t *runs,
                     int32_t max_runs, const int64_t *sm_starts, const int64_t *sm_cnts, float *t_starts,
-                    float *t_ends, int64_t *ray_indices, nfa_stream_t stream);
+                    float *t_ends, float *t_mids, int64_t *ray_indices, nfa_stream_t stream);
+/* The interval stream of the API's traverse_grids from the same run records (ref: grid.cu:219-262; edge
+ * values, ray_indices, is_left, is_right); iv_cnts as written by nfa_traverse_runs when args->iv_cnts is set
+ * (edges = samples + one leading edge per chain of continuous samples), iv_starts its exclusive cumsum. */
+int nfa_expand_intervals(int64_t n_rays, float step_size, const int32_t *run_cnts, const uint64_t *runs,
+                         int32_t max_runs, const int64_t *iv_starts, const int64_t *iv_cnts, float *vals,
+                         int64_t *ray_indices, uint8_t *is_left, uint8_t *is_right, nfa_stream_t stream);
 
 /* ------------------------------------------------------------------ packed segments */
 

@@ -88,7 +88,7 @@ enum { EV_EMPTY = 0, EV_OCC = 1, EV_SPAN = 2, EV_NONE = 3 };
 struct RunState {
     float t_last;
     bool continuous;
-    int32_t n_samples, n_runs;
+    int32_t n_samples, n_runs, n_chains;  // n_chains: samples emitted while not continuous (each adds one edge)
     Stepper stp;  // remembered stable increment of the current binade (march.h)
     bool at_near; // t_last is still the near plane
     // open run
@@ -150,6 +150,7 @@ __device__ __forceinline__ void march(RunState &st, float thr, float dt, float h
             } else {
                 close_run(st, p, tid);
                 st.open = true; st.run_t0 = t; st.run_inc = inc; st.run_n = (int32_t)n; st.run_cont = st.continuous;
+                st.n_chains += st.continuous ? 0 : 1;
             }
             st.n_samples += (int32_t)n;
             st.continuous = true;
@@ -285,6 +286,7 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
         if (a.mode == 2 && a.rays_mask != nullptr && !a.rays_mask[tid]) {
             if (a.terminate_planes) a.terminate_planes[tid] = a.near_planes[tid];
             a.sm_cnts[tid] = 0;
+            if (a.iv_cnts) a.iv_cnts[tid] = 0;
             p.run_cnts[tid] = 0;
             continue;
         }
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
         const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
         RunState st;
         st.t_last = near_plane; st.continuous = false; stepper_init(st.stp); st.at_near = true;
-        st.n_samples = 0; st.n_runs = 0; st.open = false; st.run_cont = false; st.run_t0 = 0.f; st.run_inc = 0.f;
+        st.n_samples = 0; st.n_runs = 0; st.n_chains = 0; st.open = false; st.run_cont = false; st.run_t0 = 0.f; st.run_inc = 0.f;
         st.run_n = 0; st.brick_id = -1; st.brick_lo = st.brick_hi = 0u;
         st.ev_cnt = 0; st.ev_occ = 0u; st.ev_span = 0u; st.open_type = EV_NONE; st.open_thr = 0.f;
         if (FUSED) {
@@ -347,6 +349,7 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
         close_run(st, p, tid);
         if (a.terminate_planes) a.terminate_planes[tid] = st.t_last;
         a.sm_cnts[tid] = st.n_samples;
+        if (a.iv_cnts) a.iv_cnts[tid] = st.n_samples + st.n_chains;  // edges = samples + one leading edge per chain
         // rays with > 2^21 samples go to the serial fill too (the expansion packs a 27-bit batch offset)
         if (st.n_samples > (1 << 21) && st.n_runs <= p.max_runs) st.n_runs = p.max_runs + 1;
         p.run_cnts[tid] = st.n_runs;
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(256) void expand_runs_kernel(int64_t n_rays, float 
                                                           const int64_t *__restrict__ sm_starts,
                                                           const int64_t *__restrict__ sm_cnts,
                                                           float *__restrict__ t_starts, float *__restrict__ t_ends,
-                                                          int64_t *__restrict__ ray_indices, int vec)
+                                                          float *__restrict__ t_mids, int64_t *__restrict__ ray_indices, int vec)
 {
     __shared__ uint32_t s_pos[4][EXP_QMAX];
     __shared__ float s_t0[4][EXP_QMAX];
@@ -499,16 +502,194 @@ __global__ __launch_bounds__(256) void expand_runs_kernel(int64_t n_rays, float 
                     ri4[k] = r0 + (e >> 27);
                     valid[k] = true;
                 }
+                if (t_mids) {  // API form of the samples (ref grid.cu:244: vals = (t_next + t_last) * 0.5f)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ts4[k] = (te4[k] + ts4[k]) * 0.5f;
+                }
                 if (vec && valid[0] && valid[1] && valid[2] && valid[3]) {
-                    *reinterpret_cast<float4 *>(t_starts + p0) = make_float4(ts4[0], ts4[1], ts4[2], ts4[3]);
-                    *reinterpret_cast<float4 *>(t_ends + p0) = make_float4(te4[0], te4[1], te4[2], te4[3]);
+                    if (t_mids) {
+                        *reinterpret_cast<float4 *>(t_mids + p0) = make_float4(ts4[0], ts4[1], ts4[2], ts4[3]);
+                    } else {
+                        *reinterpret_cast<float4 *>(t_starts + p0) = make_float4(ts4[0], ts4[1], ts4[2], ts4[3]);
+                        *reinterpret_cast<float4 *>(t_ends + p0) = make_float4(te4[0], te4[1], te4[2], te4[3]);
+                    }
                     longlong2 *rp = reinterpret_cast<longlong2 *>(ray_indices + p0);
                     rp[0] = make_longlong2(ri4[0], ri4[1]);
                     rp[1] = make_longlong2(ri4[2], ri4[3]);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (valid[k]) { t_starts[p0 + k] = ts4[k]; t_ends[p0 + k] = te4[k]; ray_indices[p0 + k] = ri4[k]; }
+                        if (valid[k]) {
+                            if (t_mids) t_mids[p0 + k] = ts4[k];
+                            else { t_starts[p0 + k] = ts4[k]; t_ends[p0 + k] = te4[k]; }
+                            ray_indices[p0 + k] = ri4[k];
+                        }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Expansion of the INTERVAL stream of the API's traverse_grids (ref grid.cu:219-262): a chain of
+// continuous samples has one edge more than samples.  Run j of a ray (k_start_j samples before it, L_j chain
+// starts before it) owns the edges [k_start_j + L_j, ...): its leading edge t_first if it starts a chain,
+// then the end t_first + m * inc of each of its samples.  is_right is false exactly at chain starts, is_left
+// is false exactly before a chain start (or the end of the ray's edges).  Same batch / chunk structure as
+// expand_runs_kernel; one lane per ray stages that ray's records (it needs the running count of chain starts).
+__global__ __launch_bounds__(256) void expand_intervals_kernel(int64_t n_rays, float dt, const int32_t *__restrict__ run_cnts,
+                                                               const unsigned long long *__restrict__ runs, int32_t max_runs,
+                                                               const int64_t *__restrict__ iv_starts,
+                                                               const int64_t *__restrict__ iv_cnts,
+                                                               float *__restrict__ vals, int64_t *__restrict__ ray_indices,
+                                                               uint8_t *__restrict__ is_left, uint8_t *__restrict__ is_right, int vec)
+{
+    __shared__ uint32_t s_pos[4][EXP_QMAX];
+    __shared__ float s_t0[4][EXP_QMAX];
+    __shared__ uint8_t s_cont[4][EXP_QMAX];
+    __shared__ __attribute__((aligned(16))) int32_t s_own[4][256 + 4];  // + look-ahead slot for the chunk's last edge
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    uint32_t *pos = s_pos[wave];
+    float *t0s = s_t0[wave];
+    uint8_t *conts = s_cont[wave];
+    int32_t *slot = s_own[wave];
+    const int64_t n_batches = ceil_div64(n_rays, EXP_RPW);
+    for (int64_t batch = (int64_t)blockIdx.x * 4 + wave; batch < n_batches; batch += (int64_t)gridDim.x * 4) {
+        const int64_t r0 = batch * EXP_RPW;
+        const int64_t ray = r0 + lane;
+        const bool mine = lane < EXP_RPW && ray < n_rays;
+        int32_t c = 0, c_real = 0;
+        int64_t s = 0, n = 0;
+        if (mine) {
+            c_real = run_cnts[ray];
+            s = iv_starts[ray];
+            n = iv_cnts[ray];
+            c = (c_real > max_runs) ? 1 : c_real;  // overflowed ray: one sentinel entry
+        }
+        const int64_t W0 = __shfl(s, 0, 64);
+        const int last = (int)min((int64_t)EXP_RPW, n_rays - r0) - 1;
+        const int64_t W1 = __shfl(s + n, last, 64);
+        int32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < EXP_RPW; off <<= 1) {
+            const int32_t u = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += u;
+        }
+        const int32_t Q = __shfl(incl, EXP_RPW - 1, 64);
+        __builtin_amdgcn_wave_barrier();
+        if (mine && c > 0) {  // staging, one lane per ray
+            const int32_t base = incl - c;
+            const uint32_t rel = (uint32_t)(s - W0);
+            if (c_real > max_runs) {
+                pos[base] = (rel & 0x7FFFFFFu) | ((uint32_t)lane << 27);
+                t0s[base] = __builtin_nanf("");
+                conts[base] = 0;
+            } else {
+                const unsigned long long *col = runs + ray;
+                uint32_t chains = 0;
+                for (int32_t i0 = 0; i0 < c; i0 += 4) {
+                    unsigned long long rec[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) rec[u] = (i0 + u < c) ? col[(int64_t)(i0 + u) * n_rays] : 0ull;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (i0 + u < c) {
+                            const uint32_t hi = (uint32_t)(rec[u] >> 32);
+                            const uint32_t k_start = hi & 0x7FFFFFFFu, cont = hi >> 31;
+                            pos[base + i0 + u] = ((rel + k_start + chains) & 0x7FFFFFFu) | ((uint32_t)lane << 27);
+                            t0s[base + i0 + u] = bits_f32((uint32_t)rec[u]);
+                            conts[base + i0 + u] = (uint8_t)cont;
+                            chains += cont ? 0u : 1u;
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (Q > 0 && W1 > W0) {
+            const int64_t c_first = (W0 / 256) * 256;
+            int32_t q_next = 0, carry_j = -1;
+            for (int64_t cb = c_first; cb < W1; cb += 256) {
+                const int64_t lo64 = cb - W0;
+                *reinterpret_cast<int4 *>(slot + 4 * lane) = make_int4(-1, -1, -1, -1);
+                if (lane == 0) slot[256] = -1;
+                __builtin_amdgcn_wave_barrier();
+                for (;;) {
+                    const int32_t q = q_next + lane;
+                    bool take = false;
+                    if (q < Q) {
+                        const int64_t relq = (int64_t)(pos[q] & 0x7FFFFFFu) - lo64;
+                        take = relq < 256;
+                        if (relq <= 256) slot[(int)relq] = q;   // relq == 256: look-ahead only, consumed by the next chunk
+                    }
+                    const int cnt = __builtin_popcountll(__ballot(take));
+                    q_next += cnt;
+                    if (cnt < 64) break;
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int4 o4 = *reinterpret_cast<const int4 *>(slot + 4 * lane);
+                const int32_t o_next_chunk = slot[256];
+                __builtin_amdgcn_wave_barrier();
+                const int32_t own4[4] = {o4.x, o4.y, o4.z, o4.w};
+                // chain start flags of p .. p+3 and of p+4 (next lane's first edge, or the look-ahead slot)
+                bool cs[5];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cs[k] = own4[k] >= 0 && conts[own4[k]] == 0;
+                {
+                    const int32_t nxt = __shfl_down((int32_t)(cs[0] ? 1 : 0), 1, 64);
+                    cs[4] = lane == 63 ? (o_next_chunk >= 0 && conts[o_next_chunk] == 0) : (nxt != 0);
+                }
+                int32_t j4[4] = {own4[0], own4[1], own4[2], own4[3]};
+#pragma unroll
+                for (int k = 1; k < 4; ++k) j4[k] = j4[k] >= 0 ? j4[k] : j4[k - 1];
+                int32_t ah = j4[3];
+                { int32_t u = dpp_step<0>(-1, ah); ah = ah >= 0 ? ah : u; }
+                { int32_t u = dpp_step<1>(-1, ah); ah = ah >= 0 ? ah : u; }
+                { int32_t u = dpp_step<2>(-1, ah); ah = ah >= 0 ? ah : u; }
+                { int32_t u = dpp_step<3>(-1, ah); ah = ah >= 0 ? ah : u; }
+                { int32_t u = dpp_step<4>(-1, ah); ah = ah >= 0 ? ah : u; }
+                { int32_t u = dpp_step<5>(-1, ah); ah = ah >= 0 ? ah : u; }
+                int32_t pj = dpp_prev_lane(-1, ah);
+                if (pj < 0) pj = carry_j;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) j4[k] = j4[k] >= 0 ? j4[k] : pj;
+                carry_j = nfa::last_lane(j4[3]);
+
+                const int64_t p0 = cb + 4 * lane;
+                bool valid[4];
+                float v4[4];
+                int64_t ri4[4];
+                uint8_t l4[4], r4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t pa = p0 + k;
+                    const int32_t j = j4[k];
+                    valid[k] = false;
+                    v4[k] = 0.f; ri4[k] = 0; l4[k] = r4[k] = 0;
+                    if (pa < W0 || pa >= W1 || j < 0) continue;
+                    const float t0 = t0s[j];
+                    if (t0 != t0) continue;  // sentinel: overflowed ray, filled by the serial kernel
+                    const uint32_t e = pos[j];
+                    const uint32_t m = (uint32_t)(pa - W0) - (e & 0x7FFFFFFu) + (uint32_t)conts[j];
+                    const float inc = (t0 + dt) - t0;
+                    v4[k] = __builtin_fmaf((float)m, inc, t0);
+                    ri4[k] = r0 + (e >> 27);
+                    r4[k] = cs[k] ? 0 : 1;
+                    l4[k] = (cs[k + 1] || pa + 1 >= W1) ? 0 : 1;
+                    valid[k] = true;
+                }
+                if (vec && valid[0] && valid[1] && valid[2] && valid[3]) {
+                    *reinterpret_cast<float4 *>(vals + p0) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+                    longlong2 *rp = reinterpret_cast<longlong2 *>(ray_indices + p0);
+                    rp[0] = make_longlong2(ri4[0], ri4[1]);
+                    rp[1] = make_longlong2(ri4[2], ri4[3]);
+                    *reinterpret_cast<uchar4 *>(is_left + p0) = make_uchar4(l4[0], l4[1], l4[2], l4[3]);
+                    *reinterpret_cast<uchar4 *>(is_right + p0) = make_uchar4(r4[0], r4[1], r4[2], r4[3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (valid[k]) { vals[p0 + k] = v4[k]; ray_indices[p0 + k] = ri4[k]; is_left[p0 + k] = l4[k]; is_right[p0 + k] = r4[k]; }
                 }
             }
         }
@@ -594,22 +775,42 @@ int nfa_traverse_runs(const nfa_traverse_args *pa, const uint64_t *bricks, const
 }
 
 int nfa_expand_runs(int64_t n_rays, float step_size, const int32_t *run_cnts, const uint64_t *runs, int32_t max_runs,
-                    const int64_t *sm_starts, const int64_t *sm_cnts, float *t_starts, float *t_ends,
+                    const int64_t *sm_starts, const int64_t *sm_cnts, float *t_starts, float *t_ends, float *t_mids,
                     int64_t *ray_indices, nfa_stream_t stream)
 {
     NFA_REQUIRE(n_rays >= 0, "expand_runs: negative n_rays");
     if (n_rays == 0) return NFA_OK;
-    NFA_REQUIRE(run_cnts && runs && sm_starts && sm_cnts && t_starts && t_ends && ray_indices, "expand_runs: null pointer");
+    NFA_REQUIRE(run_cnts && runs && sm_starts && sm_cnts && ray_indices && (t_mids || (t_starts && t_ends)),
+                "expand_runs: null pointer");
     NFA_REQUIRE(max_runs >= 1 && max_runs * EXP_RPW <= EXP_QMAX, "expand_runs: max_runs must be in [1, 32]");
     NFA_REQUIRE(step_size > 0.0f, "expand_runs: step_size must be > 0");
     const int vec = ((reinterpret_cast<uintptr_t>(t_starts) | reinterpret_cast<uintptr_t>(t_ends) |
-                      reinterpret_cast<uintptr_t>(ray_indices)) & 15) == 0;
-    const int64_t n_batches = ceil_div64(n_rays, EXP_RPW);
-    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(n_batches, 4), 1 << 20);
+                      reinterpret_cast<uintptr_t>(t_mids) | reinterpret_cast<uintptr_t>(ray_indices)) & 15) == 0;
+    const unsigned grid = grid_1d(ceil_div64(n_rays, EXP_RPW) * 64, 256, 1 << 20);
     hipLaunchKernelGGL(expand_runs_kernel, dim3(grid), dim3(256), 0, as_stream(stream), n_rays, step_size, run_cnts,
                        reinterpret_cast<const unsigned long long *>(runs), max_runs, sm_starts, sm_cnts, t_starts,
-                       t_ends, ray_indices, vec);
+                       t_ends, t_mids, ray_indices, vec);
     NFA_CHECK_LAUNCH("expand_runs");
+    return NFA_OK;
+}
+
+int nfa_expand_intervals(int64_t n_rays, float step_size, const int32_t *run_cnts, const uint64_t *runs, int32_t max_runs,
+                         const int64_t *iv_starts, const int64_t *iv_cnts, float *vals, int64_t *ray_indices,
+                         uint8_t *is_left, uint8_t *is_right, nfa_stream_t stream)
+{
+    NFA_REQUIRE(n_rays >= 0, "expand_intervals: negative n_rays");
+    if (n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(run_cnts && runs && iv_starts && iv_cnts && vals && ray_indices && is_left && is_right,
+                "expand_intervals: null pointer");
+    NFA_REQUIRE(max_runs >= 1 && max_runs * EXP_RPW <= EXP_QMAX, "expand_intervals: max_runs must be in [1, 32]");
+    NFA_REQUIRE(step_size > 0.0f, "expand_intervals: step_size must be > 0");
+    const int vec = ((reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(ray_indices)) & 15) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(is_left) | reinterpret_cast<uintptr_t>(is_right)) & 3) == 0;
+    const unsigned grid = grid_1d(ceil_div64(n_rays, EXP_RPW) * 64, 256, 1 << 20);
+    hipLaunchKernelGGL(expand_intervals_kernel, dim3(grid), dim3(256), 0, as_stream(stream), n_rays, step_size, run_cnts,
+                       reinterpret_cast<const unsigned long long *>(runs), max_runs, iv_starts, iv_cnts, vals, ray_indices,
+                       is_left, is_right, vec);
+    NFA_CHECK_LAUNCH("expand_intervals");
     return NFA_OK;
 }
 

@@ -127,6 +127,7 @@ def traverse_grids(
     termination planes the reference leaves uninitialised are defined here: the ray's near plane
     for masked rays, the count pass's value for rays without samples.
     """
+    near_hint = 0.0 if near_planes is None else None  # the default near plane is a constant (accelerator only)
     if traverse_steps_limit is None:
         traverse_steps_limit = -1
     if over_allocate:
@@ -168,6 +169,44 @@ def traverse_grids(
             # masks (grid.cu:401-403, examples/utils.py:362-365).
             iv_starts = _exclusive_cumsum(iv_cnts, totals[0:1])
             sm_starts = _exclusive_cumsum(sm_cnts, totals[1:2])
+        elif float(step_size) > 0.0 and float(cone_angle) == 0.0:
+            # constant step: ONE walk (run records) + two coalesced expansions instead of the reference's count and
+            # fill passes (grid.cu:405-471); rays with more than MAX_RUNS runs are filled by the serial kernel.
+            iv_cnts, sm_cnts = torch.empty(n_rays, **i64), torch.empty(n_rays, **i64)
+            meta = torch.zeros(3, **i64)  # [edges, samples, rays with too many runs]
+            a = _traverse_args(rays_o, rays_d, None, binaries, aabbs, t_sorted, t_indices, hits, near_planes,
+                               far_planes, step_size, cone_angle, traverse_steps_limit, 0)
+            a.iv_cnts, a.sm_cnts, a.terminate_planes = B.ptr(iv_cnts), B.ptr(sm_cnts), B.ptr(terminate)
+            bricks, coarse = _get_bricks(binaries)
+            run_cnts = torch.empty(n_rays, dtype=torch.int32, device=dev)
+            runs = torch.empty((MAX_RUNS, n_rays), dtype=torch.int64, device=dev)
+            B.call("nfa_traverse_runs", C.byref(a), B.ptr(bricks), B.ptr(coarse), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
+                   B.ptr(meta[2:3]), float("nan") if near_hint is None else near_hint, B.stream())
+            iv_starts = _exclusive_cumsum(iv_cnts, meta[0:1])
+            sm_starts = _exclusive_cumsum(sm_cnts, meta[1:2])
+            n_iv, n_sm, n_overflow = (int(v) for v in meta.tolist())  # the one device->host read
+            iv_vals = torch.empty(n_iv, dtype=torch.float32, device=dev)
+            iv_ri = torch.empty(n_iv, **i64)
+            iv_l = torch.empty(n_iv, dtype=torch.bool, device=dev)
+            iv_r = torch.empty(n_iv, dtype=torch.bool, device=dev)
+            sm_vals = torch.empty(n_sm, dtype=torch.float32, device=dev)
+            sm_ri = torch.empty(n_sm, **i64)
+            sm_valid = torch.ones(n_sm, dtype=torch.bool, device=dev)
+            if n_sm > 0:
+                B.call("nfa_expand_runs", n_rays, float(step_size), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS, B.ptr(sm_starts),
+                       B.ptr(sm_cnts), None, None, B.ptr(sm_vals), B.ptr(sm_ri), B.stream())
+                B.call("nfa_expand_intervals", n_rays, float(step_size), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
+                       B.ptr(iv_starts), B.ptr(iv_cnts), B.ptr(iv_vals), B.ptr(iv_ri), B.ptr(iv_l), B.ptr(iv_r), B.stream())
+                if n_overflow > 0:
+                    a.mode = 1
+                    a.terminate_planes = None
+                    a.iv_vals, a.iv_ray_indices, a.iv_is_left, a.iv_is_right = (B.ptr(iv_vals), B.ptr(iv_ri), B.ptr(iv_l),
+                                                                                 B.ptr(iv_r))
+                    a.iv_starts = B.ptr(iv_starts)
+                    a.sm_vals, a.sm_ray_indices, a.sm_is_valid = B.ptr(sm_vals), B.ptr(sm_ri), B.ptr(sm_valid)
+                    a.sm_starts = B.ptr(sm_starts)
+                    a.ray_filter, a.ray_filter_min = B.ptr(run_cnts), MAX_RUNS
+                    _launch(a)
         else:  # two passes, grid.cu:405-471
             iv_cnts, sm_cnts = torch.empty(n_rays, **i64), torch.empty(n_rays, **i64)
             a = _traverse_args(rays_o, rays_d, None, binaries, aabbs, t_sorted, t_indices, hits, near_planes,
@@ -281,7 +320,7 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
         if n_sm > 0:
             if use_runs:
                 B.call("nfa_expand_runs", n_rays, float(step_size), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
-                       B.ptr(sm_starts), B.ptr(sm_cnts), B.ptr(t_starts), B.ptr(t_ends), B.ptr(ray_indices), B.stream())
+                       B.ptr(sm_starts), B.ptr(sm_cnts), B.ptr(t_starts), B.ptr(t_ends), None, B.ptr(ray_indices), B.stream())
             if not use_runs or n_overflow > 0:
                 a.mode = 1
                 a.terminate_planes = None
