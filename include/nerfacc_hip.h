@@ -112,6 +112,11 @@ typedef struct nfa_traverse_args {
     /* optional ray filter (mode 1): only rays with ray_filter[r] > ray_filter_min are processed */
     const int32_t *ray_filter;
     int32_t ray_filter_min;
+    /* optional accelerator: the brick-packed copy of binaries made by nfa_pack_bricks (both or neither).
+     * Occupancy is then read from 8-byte bricks (one load per 4x4x4 cells, 1/8 of the bool grid's footprint);
+     * results are identical. */
+    const uint64_t *bricks;
+    const uint32_t *coarse;
 } nfa_traverse_args;
 int nfa_traverse_grids(const nfa_traverse_args *args, nfa_stream_t stream);
 

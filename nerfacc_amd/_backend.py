@@ -37,6 +37,7 @@ class TraverseArgs(C.Structure):
         ("sm_t_starts", _vp), ("sm_t_ends", _vp), ("sm_starts", _vp), ("sm_cnts", _vp),
         ("terminate_planes", _vp),
         ("ray_filter", _vp), ("ray_filter_min", _i32),
+        ("bricks", _vp), ("coarse", _vp),
     ]
 
 

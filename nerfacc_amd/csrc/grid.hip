@@ -82,6 +82,8 @@ struct RayState {
     bool continuous;
     int32_t n_intervals;
     int32_t n_samples;
+    int32_t brick_id;       // brick cache (when the brick-packed grid is given)
+    uint32_t brick_lo, brick_hi;
 };
 
 // One [this_tmin, this_tmax) span inside grid `level`.
@@ -125,8 +127,21 @@ __device__ __forceinline__ void traverse_span(const nfa_traverse_args &a, int64_
 
     while (limit <= 0 || st.n_samples < limit) {
         const float t_traverse = fminf(fminf(tdist[0], fminf(tdist[1], tdist[2])), this_tmax);
-        const int64_t cell = level_base + (int64_t)(cur[0] * a.res[1] * a.res[2] + cur[1] * a.res[2] + cur[2]);
-        if (!a.binaries[cell]) {
+        bool occupied;
+        if (a.bricks) {  // 4x4x4 bricks: bit ((x&3)<<4 | (y&3)<<2 | (z&3)) of word ((x>>2)*by + (y>>2))*bz + (z>>2)
+            const int32_t by = (a.res[1] + 3) >> 2, bz = (a.res[2] + 3) >> 2, bx = (a.res[0] + 3) >> 2;
+            const int32_t bid = level * bx * by * bz + ((cur[0] >> 2) * by + (cur[1] >> 2)) * bz + (cur[2] >> 2);
+            if (bid != st.brick_id) {
+                st.brick_id = bid;
+                const unsigned long long w = ((a.coarse[bid >> 5] >> (bid & 31)) & 1u) ? a.bricks[bid] : 0ull;
+                st.brick_lo = (uint32_t)w; st.brick_hi = (uint32_t)(w >> 32);
+            }
+            const uint32_t half_w = (cur[0] & 2) ? st.brick_hi : st.brick_lo;
+            occupied = (half_w >> (((cur[0] & 1) << 4) | ((cur[1] & 3) << 2) | (cur[2] & 3))) & 1u;
+        } else {
+            occupied = a.binaries[level_base + (int64_t)(cur[0] * a.res[1] * a.res[2] + cur[1] * a.res[2] + cur[2])] != 0;
+        }
+        if (!occupied) {
             st.t_last = fast_forward(st.t_last, t_traverse, step_size, cone);
             st.continuous = false;
         } else {
@@ -222,6 +237,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(const nfa_traverse_args a
         st.continuous = false;
         st.n_intervals = 0;
         st.n_samples = 0;
+        st.brick_id = -1; st.brick_lo = st.brick_hi = 0u;
 
         if (FUSED) {
             // grid.py:158-162 with one grid: events are (t_min: enter 0), (t_max: leave 0).

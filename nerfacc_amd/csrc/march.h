@@ -260,7 +260,17 @@ NFA_HD float fast_forward_stepper(float t, float target, float dt)
 NFA_HD float fast_forward(float t_last, float target, float step, float cone_angle)
 {
     if (step <= 0.0f) return target;
-    return fast_forward_exact(t_last, target, calc_dt(t_last, cone_angle, step));
+    const float dt = calc_dt(t_last, cone_angle, step);
+    // short skips (a few steps from one cell to the next: the common case inside a grid) stay on the plain loop
+    const float half = dt * 0.5f;
+    float t = t_last;
+    for (int i = 0; i < 6; ++i) {
+        if (!(t + half < target)) return t;
+        const float tn = t + dt;
+        if (tn == t) return target;
+        t = tn;
+    }
+    return fast_forward_exact(t, target, dt);
 }
 
 }  // namespace nfa

@@ -59,6 +59,9 @@ def _traverse_args(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indic
     a.near_planes, a.far_planes = B.ptr(near_planes), B.ptr(far_planes)
     a.step_size, a.cone_angle = float(step_size), float(cone_angle)
     a.traverse_steps_limit, a.mode = int(limit), int(mode)
+    bricks, coarse = _get_bricks(binaries)  # cached on the tensor
+    a._keepalive = (bricks, coarse)
+    a.bricks, a.coarse = B.ptr(bricks), B.ptr(coarse)
     return a
 
 
