@@ -661,6 +661,26 @@ def test_propnet_sampling_and_loss(dev):
     assert np.isfinite(loss) and len(est2.prop_cache) == 0 and float(p) != 3.0
 
 
+def test_bench_geometry_bit_exact_vs_oracle(dev, oracle):
+    """The bench's geometry at 64x64 rays (pinhole camera 2.2 units from the box, 128^3 shell grid, step
+    2 sqrt(3)/1024): every ray marches ~650 steps from the near plane before it meets the grid, the case the
+    approach table and the Stepper's jumps exist for.  Sampler output and the API's intervals, bit for bit."""
+    import bench
+    b = bench.make_grid(128, "shell10")
+    o, d = bench.make_rays(64 * 64, "image", rank=3)
+    step = 2 * 3 ** 0.5 / 1024
+    est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=128).to(dev)
+    est.binaries = T(b, dev)
+    ab = est.aabbs.cpu().numpy()
+    for near in (0.0, 0.37):
+        ri, ts, te = est.sampling(T(o, dev), T(d, dev), near_plane=near, render_step_size=step)
+        ori, ots, ote = oracle.occgrid_sampling(o, d, b, ab, near_plane=near, render_step_size=step)
+        assert ri.numel() > 50000
+        assert (ri.cpu().numpy() == ori).all() and (ts.cpu().numpy() == ots).all() and (te.cpu().numpy() == ote).all()
+    res = na.traverse_grids(T(o, dev), T(d, dev), T(b, dev), T(ab, dev), step_size=step)
+    _cmp_traversal(res, oracle.traverse_grids(o, d, b, ab, step_size=step))
+
+
 # ----------------------------------------------------------------------------- full-size properties (BASELINE cfg 2)
 def test_full_size_properties(dev):
     """1024x1024 rays through a 128^3 grid at ~10% occupancy: size-independent invariants."""
