@@ -49,6 +49,9 @@ int nfa_device_arch(char *buf, int buflen); /* gcnArchName of the current device
 int64_t nfa_cumsum_scratch_bytes(int64_t n);
 int nfa_exclusive_cumsum_i64(const int64_t *cnts, int64_t n, int64_t *starts, int64_t *total,
                              void *scratch, nfa_stream_t stream);
+/* Same scan, written as packed_info rows {start, count} (ref: data_specs.py:68-69 stacks them afterwards). */
+int nfa_exclusive_cumsum_pairs_i64(const int64_t *cnts, int64_t n, int64_t *packed_info /*[n,2]*/, int64_t *total,
+                                   void *scratch, nfa_stream_t stream);
 
 /* packed_info[r] = {start, count} of ray r in a ray-sorted index stream; also
  * reports (flags[0]) whether ray_indices is non-decreasing and in range.
@@ -142,13 +145,13 @@ int nfa_traverse_runs(const nfa_traverse_args *args, const uint64_t *bricks, con
                       int32_t *run_cnts, uint64_t *runs, int32_t max_runs, int32_t *overflow_count,
                       float near_hint, nfa_stream_t stream);
 int nfa_expand_runs(int64_t n_rays, float step_size, const int32_t *run_cnts, const uint64_t *runs,
-                    int32_t max_runs, const int64_t *sm_starts, const int64_t *sm_cnts, float *t_starts,
+                    int32_t max_runs, const int64_t *packed_info /*[n_rays,2] {start, count}*/, float *t_starts,
                     float *t_ends, float *t_mids, int64_t *ray_indices, nfa_stream_t stream);
 /* The interval stream of the API's traverse_grids from the same run records (ref: grid.cu:219-262; edge
  * values, ray_indices, is_left, is_right); iv_cnts as written by nfa_traverse_runs when args->iv_cnts is set
- * (edges = samples + one leading edge per chain of continuous samples), iv_starts its exclusive cumsum. */
+ * (edges = samples + one leading edge per chain of continuous samples), iv_packed_info its {start, count} rows. */
 int nfa_expand_intervals(int64_t n_rays, float step_size, const int32_t *run_cnts, const uint64_t *runs,
-                         int32_t max_runs, const int64_t *iv_starts, const int64_t *iv_cnts, float *vals,
+                         int32_t max_runs, const int64_t *iv_packed_info /*[n_rays,2]*/, float *vals,
                          int64_t *ray_indices, uint8_t *is_left, uint8_t *is_right, nfa_stream_t stream);
 
 /* ------------------------------------------------------------------ packed segments */

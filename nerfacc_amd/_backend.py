@@ -44,6 +44,7 @@ class TraverseArgs(C.Structure):
 # name -> argtypes (all return int unless listed in _RESTYPES)
 _SIGS = {
     "nfa_exclusive_cumsum_i64": [_vp, _i64, _vp, _vp, _vp, _vp],
+    "nfa_exclusive_cumsum_pairs_i64": [_vp, _i64, _vp, _vp, _vp, _vp],
     "nfa_pack_info": [_vp, _i64, _i64, _vp, _vp, _vp, _vp],
     "nfa_pack_bits": [_vp, _i64, _vp, _vp],
     "nfa_ray_aabb_intersect": [_vp, _vp, _i64, _vp, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
@@ -51,8 +52,8 @@ _SIGS = {
     "nfa_bricks_words": [_i32, C.POINTER(_i32)],
     "nfa_pack_bricks": [_vp, _i32, C.POINTER(_i32), _vp, _vp, _vp],
     "nfa_traverse_runs": [C.POINTER(TraverseArgs), _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp],
-    "nfa_expand_runs": [_i64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "nfa_expand_intervals": [_i64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "nfa_expand_runs": [_i64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "nfa_expand_intervals": [_i64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "nfa_seg_plan": [_i64, C.POINTER(_i64), C.POINTER(_i64)],
     "nfa_seg_build_tiles": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "nfa_packed_scan": [_int, _int, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],

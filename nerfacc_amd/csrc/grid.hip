@@ -461,6 +461,13 @@ int nfa_exclusive_cumsum_i64(const int64_t *cnts, int64_t n, int64_t *starts, in
     return run_cumsum(cnts, n, 1, starts, 0, total, scratch, as_stream(stream));
 }
 
+int nfa_exclusive_cumsum_pairs_i64(const int64_t *cnts, int64_t n, int64_t *packed_info, int64_t *total, void *scratch,
+                                   nfa_stream_t stream)
+{
+    NFA_REQUIRE(n >= 0 && scratch && (n == 0 || (cnts && packed_info)), "exclusive_cumsum_pairs_i64: bad arguments");
+    return run_cumsum(cnts, n, 1, packed_info, 1, total, scratch, as_stream(stream));
+}
+
 int nfa_pack_info(const int64_t *ray_indices, int64_t n, int64_t n_rays, int64_t *packed_info, int32_t *flags,
                   void *scratch, nfa_stream_t stream)
 {

@@ -365,10 +365,10 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
 // (t_first = NaN) so that its output range is skipped (the serial kernel fills it).  Outputs are then
 // produced chunk by chunk (256 per step, 16 B per lane and array) with a scatter + "most recent entry"
 // scan that tells every output its run.
+template <bool MIDS /* write the API's sample centres instead of (t_starts, t_ends) */>
 __global__ __launch_bounds__(256) void expand_runs_kernel(int64_t n_rays, float dt, const int32_t *__restrict__ run_cnts,
                                                           const unsigned long long *__restrict__ runs, int32_t max_runs,
-                                                          const int64_t *__restrict__ sm_starts,
-                                                          const int64_t *__restrict__ sm_cnts,
+                                                          const longlong2 *__restrict__ packed_info,
                                                           float *__restrict__ t_starts, float *__restrict__ t_ends,
                                                           float *__restrict__ t_mids, int64_t *__restrict__ ray_indices, int vec)
 {
@@ -388,8 +388,9 @@ __global__ __launch_bounds__(256) void expand_runs_kernel(int64_t n_rays, float 
         int64_t s = 0, n = 0;
         if (own) {
             c_real = run_cnts[ray];
-            s = sm_starts[ray];
-            n = sm_cnts[ray];
+            const longlong2 row = packed_info[ray];
+            s = row.x;
+            n = row.y;
             c = (c_real > max_runs) ? 1 : c_real;  // overflowed ray: one sentinel entry
         }
         const int64_t W0 = __shfl(s, 0, 64);
@@ -502,12 +503,12 @@ __global__ __launch_bounds__(256) void expand_runs_kernel(int64_t n_rays, float 
                     ri4[k] = r0 + (e >> 27);
                     valid[k] = true;
                 }
-                if (t_mids) {  // API form of the samples (ref grid.cu:244: vals = (t_next + t_last) * 0.5f)
+                if (MIDS) {  // API form of the samples (ref grid.cu:244: vals = (t_next + t_last) * 0.5f)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) ts4[k] = (te4[k] + ts4[k]) * 0.5f;
                 }
                 if (vec && valid[0] && valid[1] && valid[2] && valid[3]) {
-                    if (t_mids) {
+                    if (MIDS) {
                         *reinterpret_cast<float4 *>(t_mids + p0) = make_float4(ts4[0], ts4[1], ts4[2], ts4[3]);
                     } else {
                         *reinterpret_cast<float4 *>(t_starts + p0) = make_float4(ts4[0], ts4[1], ts4[2], ts4[3]);
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(256) void expand_runs_kernel(int64_t n_rays, float 
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (valid[k]) {
-                            if (t_mids) t_mids[p0 + k] = ts4[k];
+                            if (MIDS) t_mids[p0 + k] = ts4[k];
                             else { t_starts[p0 + k] = ts4[k]; t_ends[p0 + k] = te4[k]; }
                             ray_indices[p0 + k] = ri4[k];
                         }
@@ -540,8 +541,7 @@ __global__ __launch_bounds__(256) void expand_runs_kernel(int64_t n_rays, float 
 // expand_runs_kernel; one lane per ray stages that ray's records (it needs the running count of chain starts).
 __global__ __launch_bounds__(256) void expand_intervals_kernel(int64_t n_rays, float dt, const int32_t *__restrict__ run_cnts,
                                                                const unsigned long long *__restrict__ runs, int32_t max_runs,
-                                                               const int64_t *__restrict__ iv_starts,
-                                                               const int64_t *__restrict__ iv_cnts,
+                                                               const longlong2 *__restrict__ iv_packed_info,
                                                                float *__restrict__ vals, int64_t *__restrict__ ray_indices,
                                                                uint8_t *__restrict__ is_left, uint8_t *__restrict__ is_right, int vec)
 {
@@ -563,8 +563,9 @@ __global__ __launch_bounds__(256) void expand_intervals_kernel(int64_t n_rays, f
         int64_t s = 0, n = 0;
         if (mine) {
             c_real = run_cnts[ray];
-            s = iv_starts[ray];
-            n = iv_cnts[ray];
+            const longlong2 row = iv_packed_info[ray];
+            s = row.x;
+            n = row.y;
             c = (c_real > max_runs) ? 1 : c_real;  // overflowed ray: one sentinel entry
         }
         const int64_t W0 = __shfl(s, 0, 64);
@@ -775,32 +776,37 @@ int nfa_traverse_runs(const nfa_traverse_args *pa, const uint64_t *bricks, const
 }
 
 int nfa_expand_runs(int64_t n_rays, float step_size, const int32_t *run_cnts, const uint64_t *runs, int32_t max_runs,
-                    const int64_t *sm_starts, const int64_t *sm_cnts, float *t_starts, float *t_ends, float *t_mids,
+                    const int64_t *packed_info, float *t_starts, float *t_ends, float *t_mids,
                     int64_t *ray_indices, nfa_stream_t stream)
 {
     NFA_REQUIRE(n_rays >= 0, "expand_runs: negative n_rays");
     if (n_rays == 0) return NFA_OK;
-    NFA_REQUIRE(run_cnts && runs && sm_starts && sm_cnts && ray_indices && (t_mids || (t_starts && t_ends)),
+    NFA_REQUIRE(run_cnts && runs && packed_info && ray_indices && (t_mids || (t_starts && t_ends)),
                 "expand_runs: null pointer");
     NFA_REQUIRE(max_runs >= 1 && max_runs * EXP_RPW <= EXP_QMAX, "expand_runs: max_runs must be in [1, 32]");
     NFA_REQUIRE(step_size > 0.0f, "expand_runs: step_size must be > 0");
     const int vec = ((reinterpret_cast<uintptr_t>(t_starts) | reinterpret_cast<uintptr_t>(t_ends) |
                       reinterpret_cast<uintptr_t>(t_mids) | reinterpret_cast<uintptr_t>(ray_indices)) & 15) == 0;
     const unsigned grid = grid_1d(ceil_div64(n_rays, EXP_RPW) * 64, 256, 1 << 20);
-    hipLaunchKernelGGL(expand_runs_kernel, dim3(grid), dim3(256), 0, as_stream(stream), n_rays, step_size, run_cnts,
-                       reinterpret_cast<const unsigned long long *>(runs), max_runs, sm_starts, sm_cnts, t_starts,
-                       t_ends, t_mids, ray_indices, vec);
+    if (t_mids)
+        hipLaunchKernelGGL(expand_runs_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), n_rays, step_size, run_cnts,
+                           reinterpret_cast<const unsigned long long *>(runs), max_runs,
+                           reinterpret_cast<const longlong2 *>(packed_info), t_starts, t_ends, t_mids, ray_indices, vec);
+    else
+        hipLaunchKernelGGL(expand_runs_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), n_rays, step_size, run_cnts,
+                           reinterpret_cast<const unsigned long long *>(runs), max_runs,
+                           reinterpret_cast<const longlong2 *>(packed_info), t_starts, t_ends, t_mids, ray_indices, vec);
     NFA_CHECK_LAUNCH("expand_runs");
     return NFA_OK;
 }
 
 int nfa_expand_intervals(int64_t n_rays, float step_size, const int32_t *run_cnts, const uint64_t *runs, int32_t max_runs,
-                         const int64_t *iv_starts, const int64_t *iv_cnts, float *vals, int64_t *ray_indices,
+                         const int64_t *iv_packed_info, float *vals, int64_t *ray_indices,
                          uint8_t *is_left, uint8_t *is_right, nfa_stream_t stream)
 {
     NFA_REQUIRE(n_rays >= 0, "expand_intervals: negative n_rays");
     if (n_rays == 0) return NFA_OK;
-    NFA_REQUIRE(run_cnts && runs && iv_starts && iv_cnts && vals && ray_indices && is_left && is_right,
+    NFA_REQUIRE(run_cnts && runs && iv_packed_info && vals && ray_indices && is_left && is_right,
                 "expand_intervals: null pointer");
     NFA_REQUIRE(max_runs >= 1 && max_runs * EXP_RPW <= EXP_QMAX, "expand_intervals: max_runs must be in [1, 32]");
     NFA_REQUIRE(step_size > 0.0f, "expand_intervals: step_size must be > 0");
@@ -808,8 +814,8 @@ int nfa_expand_intervals(int64_t n_rays, float step_size, const int32_t *run_cnt
                     ((reinterpret_cast<uintptr_t>(is_left) | reinterpret_cast<uintptr_t>(is_right)) & 3) == 0;
     const unsigned grid = grid_1d(ceil_div64(n_rays, EXP_RPW) * 64, 256, 1 << 20);
     hipLaunchKernelGGL(expand_intervals_kernel, dim3(grid), dim3(256), 0, as_stream(stream), n_rays, step_size, run_cnts,
-                       reinterpret_cast<const unsigned long long *>(runs), max_runs, iv_starts, iv_cnts, vals, ray_indices,
-                       is_left, is_right, vec);
+                       reinterpret_cast<const unsigned long long *>(runs), max_runs,
+                       reinterpret_cast<const longlong2 *>(iv_packed_info), vals, ray_indices, is_left, is_right, vec);
     NFA_CHECK_LAUNCH("expand_intervals");
     return NFA_OK;
 }

@@ -65,6 +65,17 @@ class OccGridEstimator(AbstractEstimator):
         self._occs_mean_cache = None
 
     # ------------------------------------------------------------------ hot path
+    def _planes(self, rays_o: Tensor, near_plane: float, far_plane: float):
+        """Constant near / far plane tensors (ref :161-162 builds them with full_like on every call); cached per
+        (n_rays, values, device) and never written in place."""
+        key = (rays_o.shape[0], float(near_plane), float(far_plane), rays_o.device, rays_o.dtype)
+        cached = getattr(self, "_planes_cache", None)
+        if cached is None or cached[0] != key:
+            cached = (key, torch.full_like(rays_o[..., 0], fill_value=near_plane),
+                      torch.full_like(rays_o[..., 0], fill_value=far_plane))
+            self._planes_cache = cached
+        return cached[1], cached[2]
+
     def _occs_mean(self) -> float:
         """``self.occs.mean().item()`` (ref :183) cached until ``occs`` changes."""
         key = (self.occs.data_ptr(), self.occs._version)
@@ -96,14 +107,13 @@ class OccGridEstimator(AbstractEstimator):
         ``alpha_fn`` take ``(t_starts, t_ends, ray_indices)`` and return densities / opacities
         ``(N,)``; when given (and a threshold is active) invisible samples are dropped.
         """
-        near_planes = torch.full_like(rays_o[..., 0], fill_value=near_plane)
-        far_planes = torch.full_like(rays_o[..., 0], fill_value=far_plane)
+        near_planes, far_planes = self._planes(rays_o, near_plane, far_plane)
         if t_min is not None:
             near_planes = torch.clamp(near_planes, min=t_min)
         if t_max is not None:
             far_planes = torch.clamp(far_planes, max=t_max)
         if stratified:
-            near_planes += torch.rand_like(near_planes) * render_step_size
+            near_planes = near_planes + torch.rand_like(near_planes) * render_step_size
 
         ray_indices, t_starts, t_ends, packed_info = _traverse_samples(
             rays_o, rays_d, self.binaries, self.aabbs, near_planes, far_planes, render_step_size, cone_angle,

@@ -77,6 +77,15 @@ def _exclusive_cumsum(cnts: Tensor, total_out: Tensor):
     return starts
 
 
+def _cumsum_packed(cnts: Tensor, total_out: Tensor) -> Tensor:
+    """packed_info rows {exclusive start, count} from per-ray counts (one pass, no torch.stack)."""
+    packed = torch.empty((cnts.numel(), 2), dtype=torch.int64, device=cnts.device)
+    scratch = B.cumsum_scratch(cnts.numel(), cnts.device)
+    B.call("nfa_exclusive_cumsum_pairs_i64", B.ptr(cnts), cnts.numel(), B.ptr(packed), B.ptr(total_out), B.ptr(scratch),
+           B.stream())
+    return packed
+
+
 def _prepare(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, rays_mask, t_sorted, t_indices, hits,
              allow_fused: bool):
     dev = B.require_device(rays_o, rays_d, binaries, aabbs)
@@ -143,6 +152,7 @@ def traverse_grids(
     with torch.cuda.device(dev):
         terminate = torch.empty(n_rays, dtype=torch.float32, device=dev)
         totals = torch.empty(2, **i64)
+        iv_packed = sm_packed = None
         if over_allocate:  # grid.cu:364-404
             limit = int(traverse_steps_limit)
             mask_l = torch.ones(n_rays, **i64) if rays_mask is None else rays_mask.to(torch.int64)
@@ -185,8 +195,8 @@ def traverse_grids(
             runs = torch.empty((MAX_RUNS, n_rays), dtype=torch.int64, device=dev)
             B.call("nfa_traverse_runs", C.byref(a), B.ptr(bricks), B.ptr(coarse), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
                    B.ptr(meta[2:3]), float("nan") if near_hint is None else near_hint, B.stream())
-            iv_starts = _exclusive_cumsum(iv_cnts, meta[0:1])
-            sm_starts = _exclusive_cumsum(sm_cnts, meta[1:2])
+            iv_packed = _cumsum_packed(iv_cnts, meta[0:1])
+            sm_packed = _cumsum_packed(sm_cnts, meta[1:2])
             n_iv, n_sm, n_overflow = (int(v) for v in meta.tolist())  # the one device->host read
             iv_vals = torch.empty(n_iv, dtype=torch.float32, device=dev)
             iv_ri = torch.empty(n_iv, **i64)
@@ -196,11 +206,12 @@ def traverse_grids(
             sm_ri = torch.empty(n_sm, **i64)
             sm_valid = torch.ones(n_sm, dtype=torch.bool, device=dev)
             if n_sm > 0:
-                B.call("nfa_expand_runs", n_rays, float(step_size), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS, B.ptr(sm_starts),
-                       B.ptr(sm_cnts), None, None, B.ptr(sm_vals), B.ptr(sm_ri), B.stream())
+                B.call("nfa_expand_runs", n_rays, float(step_size), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS, B.ptr(sm_packed),
+                       None, None, B.ptr(sm_vals), B.ptr(sm_ri), B.stream())
                 B.call("nfa_expand_intervals", n_rays, float(step_size), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
-                       B.ptr(iv_starts), B.ptr(iv_cnts), B.ptr(iv_vals), B.ptr(iv_ri), B.ptr(iv_l), B.ptr(iv_r), B.stream())
+                       B.ptr(iv_packed), B.ptr(iv_vals), B.ptr(iv_ri), B.ptr(iv_l), B.ptr(iv_r), B.stream())
                 if n_overflow > 0:
+                    iv_starts, sm_starts = iv_packed[:, 0].contiguous(), sm_packed[:, 0].contiguous()
                     a.mode = 1
                     a.terminate_planes = None
                     a.iv_vals, a.iv_ray_indices, a.iv_is_left, a.iv_is_right = (B.ptr(iv_vals), B.ptr(iv_ri), B.ptr(iv_l),
@@ -234,8 +245,9 @@ def traverse_grids(
                 a.sm_vals, a.sm_ray_indices, a.sm_is_valid = B.ptr(sm_vals), B.ptr(sm_ri), B.ptr(sm_valid)
                 a.sm_starts = B.ptr(sm_starts)
                 _launch(a)
-        iv_packed = torch.stack([iv_starts, iv_cnts], dim=-1)
-        sm_packed = torch.stack([sm_starts, sm_cnts], dim=-1)
+        if iv_packed is None:
+            iv_packed = torch.stack([iv_starts, iv_cnts], dim=-1)
+            sm_packed = torch.stack([sm_starts, sm_cnts], dim=-1)
     if not over_allocate:
         tag_trusted(iv_packed, n_iv)
         info = tag_trusted(sm_packed, n_sm)
@@ -315,7 +327,7 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
                    B.ptr(meta[1:2]), float("nan") if near_hint is None else float(near_hint), B.stream())
         else:
             _launch(a)
-        sm_starts = _exclusive_cumsum(sm_cnts, meta[0:1])
+        packed_info = _cumsum_packed(sm_cnts, meta[0:1])
         n_sm, n_overflow = (int(v) for v in meta.tolist())  # the one device->host read of the traversal
         t_starts = torch.empty(n_sm, dtype=torch.float32, device=dev)
         t_ends = torch.empty(n_sm, dtype=torch.float32, device=dev)
@@ -323,16 +335,16 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
         if n_sm > 0:
             if use_runs:
                 B.call("nfa_expand_runs", n_rays, float(step_size), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
-                       B.ptr(sm_starts), B.ptr(sm_cnts), B.ptr(t_starts), B.ptr(t_ends), None, B.ptr(ray_indices), B.stream())
+                       B.ptr(packed_info), B.ptr(t_starts), B.ptr(t_ends), None, B.ptr(ray_indices), B.stream())
             if not use_runs or n_overflow > 0:
                 a.mode = 1
                 a.terminate_planes = None
+                sm_starts = packed_info[:, 0].contiguous()
                 a.sm_starts = B.ptr(sm_starts)
                 a.sm_t_starts, a.sm_t_ends, a.sm_ray_indices = B.ptr(t_starts), B.ptr(t_ends), B.ptr(ray_indices)
                 if use_runs:  # only the rays whose runs did not fit (their counts already honour mask and limit)
                     a.ray_filter, a.ray_filter_min = B.ptr(run_cnts), MAX_RUNS
                 _launch(a)
-        packed_info = torch.stack([sm_starts, sm_cnts], dim=-1)
     info = tag_trusted(packed_info, n_sm)
     tag_ray_indices(ray_indices, n_rays, info)
     out = (ray_indices, t_starts, t_ends, packed_info)
