@@ -23,6 +23,25 @@ from ..volrend import _visibility_native
 from .base import AbstractEstimator
 
 
+class TraversalHandle:
+    """Result of :meth:`OccGridEstimator.prefetch_traversal`: (ray_indices, t_starts, t_ends, packed_info) produced on
+    a side stream plus the event that marks their completion."""
+
+    def __init__(self, tensors, event, key):
+        self._tensors, self._event, self.key = tensors, event, key
+
+    def consume(self, stream):
+        assert self._tensors is not None, "a TraversalHandle can be consumed once"
+        stream.wait_event(self._event)
+        tensors, self._tensors = self._tensors, None
+        for t in tensors:  # allocated on the side stream, used on `stream` from now on
+            t.record_stream(stream)
+        seg = getattr(tensors[3], "_nfa_seg", None)
+        if seg is not None and seg[2].tiles is not None:
+            seg[2].tiles.record_stream(stream)
+        return tensors
+
+
 class OccGridEstimator(AbstractEstimator):
     """Occupancy grid transmittance estimator for spatial skipping ("Instant-NGP" style).
 
@@ -63,6 +82,7 @@ class OccGridEstimator(AbstractEstimator):
                              persistent=False)
         self.register_buffer("grid_indices", torch.arange(self.cells_per_lvl), persistent=False)
         self._occs_mean_cache = None
+        self._prefetch_stream = None
 
     # ------------------------------------------------------------------ hot path
     def _planes(self, rays_o: Tensor, near_plane: float, far_plane: float):
@@ -83,6 +103,55 @@ class OccGridEstimator(AbstractEstimator):
             self._occs_mean_cache = (key, float(self.occs.mean().item()))
         return self._occs_mean_cache[1]
 
+    def _traverse(self, rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified, cone_angle):
+        near_planes, far_planes = self._planes(rays_o, near_plane, far_plane)
+        if t_min is not None:
+            near_planes = torch.clamp(near_planes, min=t_min)
+        if t_max is not None:
+            far_planes = torch.clamp(far_planes, max=t_max)
+        if stratified:
+            near_planes = near_planes + torch.rand_like(near_planes) * render_step_size
+        return _traverse_samples(rays_o, rays_d, self.binaries, self.aabbs, near_planes, far_planes, render_step_size,
+                                 cone_angle, near_hint=near_plane)
+
+    @torch.no_grad()
+    def prefetch_traversal(
+        self,
+        rays_o: Tensor,
+        rays_d: Tensor,
+        near_plane: float = 0.0,
+        far_plane: float = 1e10,
+        t_min: Optional[Tensor] = None,
+        t_max: Optional[Tensor] = None,
+        render_step_size: float = 1e-3,
+        stratified: bool = False,
+        cone_angle: float = 0.0,
+        wait_for_inputs: bool = True,
+    ) -> "TraversalHandle":
+        """Run the geometric half of :meth:`sampling` (grid traversal; no density callback) for a batch of rays on
+        a side stream and return a handle for ``sampling(..., traversal=handle)``.
+
+        The walk through the grid is bound by instruction issue, the rendering passes by HBM bandwidth: issued on two
+        streams they overlap, so the traversal of the NEXT batch can run under the rendering / backward of the
+        current one (pipeline objects that carry sizes across calls).  The result is exactly what
+        ``sampling`` would compute itself (same kernels) as long as the occupancy grid is not modified in between.
+        ``wait_for_inputs=False`` skips the dependency on the current stream's pending work -- only when the inputs
+        are already resident (otherwise the side stream would wait for the very work it is meant to overlap with).
+        """
+        if self._prefetch_stream is None:
+            self._prefetch_stream = torch.cuda.Stream(device=rays_o.device)
+        side = self._prefetch_stream
+        if wait_for_inputs:
+            side.wait_stream(torch.cuda.current_stream(rays_o.device))
+        with torch.cuda.stream(side):
+            out = self._traverse(rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified,
+                                 cone_angle)
+            event = torch.cuda.Event()
+            event.record(side)
+        key = (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], float(near_plane), float(far_plane),
+               float(render_step_size), float(cone_angle), self.binaries.data_ptr(), self.binaries._version)
+        return TraversalHandle(out, event, key)
+
     @torch.no_grad()
     def sampling(
         self,
@@ -99,6 +168,7 @@ class OccGridEstimator(AbstractEstimator):
         alpha_thre: float = 0.0,
         stratified: bool = False,
         cone_angle: float = 0.0,
+        traversal: Optional["TraversalHandle"] = None,
     ) -> Tuple[Tensor, Tensor, Tensor]:
         """Sampling with spatial skipping; not differentiable.
 
@@ -107,17 +177,15 @@ class OccGridEstimator(AbstractEstimator):
         ``alpha_fn`` take ``(t_starts, t_ends, ray_indices)`` and return densities / opacities
         ``(N,)``; when given (and a threshold is active) invisible samples are dropped.
         """
-        near_planes, far_planes = self._planes(rays_o, near_plane, far_plane)
-        if t_min is not None:
-            near_planes = torch.clamp(near_planes, min=t_min)
-        if t_max is not None:
-            far_planes = torch.clamp(far_planes, max=t_max)
-        if stratified:
-            near_planes = near_planes + torch.rand_like(near_planes) * render_step_size
-
-        ray_indices, t_starts, t_ends, packed_info = _traverse_samples(
-            rays_o, rays_d, self.binaries, self.aabbs, near_planes, far_planes, render_step_size, cone_angle,
-            near_hint=near_plane)
+        if traversal is not None:
+            key = (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], float(near_plane), float(far_plane),
+                   float(render_step_size), float(cone_angle), self.binaries.data_ptr(), self.binaries._version)
+            if traversal.key != key:
+                raise ValueError("nerfacc_amd: the prefetched traversal was made for other rays / planes / step / grid")
+            ray_indices, t_starts, t_ends, packed_info = traversal.consume(torch.cuda.current_stream(rays_o.device))
+        else:
+            ray_indices, t_starts, t_ends, packed_info = self._traverse(
+                rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified, cone_angle)
 
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None or alpha_fn is not None):
             alpha_thre = min(alpha_thre, self._occs_mean())

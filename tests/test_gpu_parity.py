@@ -681,6 +681,30 @@ def test_bench_geometry_bit_exact_vs_oracle(dev, oracle):
     _cmp_traversal(res, oracle.traverse_grids(o, d, b, ab, step_size=step))
 
 
+def test_prefetched_traversal_is_the_same_sampling(dev):
+    """sampling(traversal=handle) == sampling(): the handle holds the traversal made on the side stream by the same
+    kernels; a handle made for other rays is rejected."""
+    import bench
+    b = bench.make_grid(64, "shell10")
+    o, d = bench.make_rays(48 * 48, "image", rank=1)
+    est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=64).to(dev)
+    est.binaries = T(b, dev)
+    est.occs = T(b.reshape(-1).astype(np.float32), dev)
+    ro, rd = T(o, dev), T(d, dev)
+    sig = lambda ts, te, ri: 6.0 + 3.0 * torch.sin(9.0 * (ts + te))
+    kw = dict(sigma_fn=sig, render_step_size=0.004, early_stop_eps=1e-2, near_plane=0.1)
+    ref = est.sampling(ro, rd, **kw)
+    for _ in range(3):
+        h = est.prefetch_traversal(ro, rd, near_plane=0.1, render_step_size=0.004)
+        got = est.sampling(ro, rd, traversal=h, **kw)
+        assert all(torch.equal(a, b_) for a, b_ in zip(ref, got)) and ref[0].numel() > 10000
+    h = est.prefetch_traversal(ro, rd, near_plane=0.1, render_step_size=0.004)
+    with pytest.raises(ValueError):
+        est.sampling(ro, rd, traversal=h, **dict(kw, near_plane=0.2))
+    with pytest.raises(AssertionError):
+        got = est.sampling(ro, rd, traversal=h, **kw); est.sampling(ro, rd, traversal=h, **kw)
+
+
 # ----------------------------------------------------------------------------- full-size properties (BASELINE cfg 2)
 def test_full_size_properties(dev):
     """1024x1024 rays through a 128^3 grid at ~10% occupancy: size-independent invariants."""
