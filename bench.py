@@ -461,7 +461,7 @@ def main():
             try:
                 prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_hbm_traffic.json"))[-1]
                 pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
-                sym = {"nfa_traverse_runs": "runs_kernel", "nfa_expand_runs": "expand_runs_kernel",
+                sym = {"nfa_traverse_runs": "nfa::runs_kernel", "nfa_expand_runs": "expand_runs_kernel",
                        "nfa_render_from_density_fwd": "DensityFwdOp", "nfa_render_from_density_bwd": "DensityBwdOp",
                        "nfa_render_accumulate_fwd": "RenderAccumOp", "nfa_render_accumulate_bwd": "RenderAccumBwdOp",
                        "nfa_render_fused_fwd": "RenderFusedFwdOp", "nfa_render_fused_bwd": "RenderFusedBwdOp",

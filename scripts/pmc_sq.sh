@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing"
+CMD="python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-pipelined"
 rocprofv3 -L > $OUT/avail.txt 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/sq1 -- $CMD > $OUT/sq1.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d $OUT/sq2 -- $CMD > $OUT/sq2.log 2>&1
