@@ -185,6 +185,16 @@ __device__ __forceinline__ void push_closed(RunState &st, float *ev_thr, int typ
     st.ev_cnt++;
 }
 
+// min of four finite-or-inf floats as two instructions (fminf's IEEE canonicalisation of signalling NaNs costs
+// three more per cell; the DDA's distances are never NaN: d == 0 axes carry this_tmax)
+__device__ __forceinline__ float min4_f32(float a, float b, float c, float d)
+{
+    float m;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+    asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(d));
+    return m;
+}
+
 template <bool COARSE_LDS>
 __device__ __forceinline__ void runs_span(const nfa_traverse_args &a, const RunsParams &p, const uint32_t *coarse_lds,
                                           float *ev_thr, int64_t tid, const float o[3], const float d[3],
@@ -254,7 +264,7 @@ __device__ __forceinline__ void runs_span(const nfa_traverse_args &a, const Runs
             st.ev_occ |= (changed ? (uint32_t)(st.open_type & 1) : 0u) << st.ev_cnt;
             st.ev_cnt += changed ? 1 : 0;
             st.open_type = type;
-            st.open_thr = fminf(fminf(tdist[0], fminf(tdist[1], tdist[2])), this_tmax);  // t_traverse, non-decreasing
+            st.open_thr = min4_f32(tdist[0], tdist[1], tdist[2], this_tmax);  // t_traverse, non-decreasing
             // single_traversal (include/utils_grid.cuh:116-142), branch-free
             const bool s0 = (tdist[0] < tdist[1]) && (tdist[0] < tdist[2]);
             const bool s1 = !s0 && (tdist[1] < tdist[2]);
@@ -262,9 +272,8 @@ __device__ __forceinline__ void runs_span(const nfa_traverse_args &a, const Runs
             cur[0] += s0 ? step[0] : 0; tdist[0] += s0 ? delta[0] : 0.0f;
             cur[1] += s1 ? step[1] : 0; tdist[1] += s1 ? delta[1] : 0.0f;
             cur[2] += s2 ? step[2] : 0; tdist[2] += s2 ? delta[2] : 0.0f;
-            const int32_t c_sel = s0 ? cur[0] : (s1 ? cur[1] : cur[2]);
-            const int32_t o_sel = s0 ? overflow[0] : (s1 ? overflow[1] : overflow[2]);
-            span_done = (c_sel == o_sel) || (--cells_left <= 0);
+            const bool hit = (s0 && cur[0] == overflow[0]) || (s1 && cur[1] == overflow[1]) || (s2 && cur[2] == overflow[2]);
+            span_done = hit || (--cells_left <= 0);
             if (span_done || st.ev_cnt == EV_MAX) break;
         }
         if (!span_done) process_events(st, ev_thr, dt, limit, p, tid);
