@@ -10,10 +10,16 @@
 //     ray is scanned start-to-end by exactly one wave: no cross-workgroup carry, no atomics,
 //     deterministic results, load balance independent of the ray-length distribution;
 //   * a wave walks its element range in 256-element steps, 16 B per lane per array (coalesced
-//     1 KiB wave loads/stores), does the segmented scan in registers with wave shuffles
-//     (64-lane Hillis-Steele on (value, ray-id) pairs) and carries the open ray across steps;
+//     1 KiB wave loads/stores); everything that is uniform over the wave (tile bounds, step base,
+//     loop control) lives in scalar registers;
 //   * segment heads are scattered into a 1 KiB per-wave LDS line from a register-cached window
-//     of packed_info rows (16 B/ray read once); waves never synchronise with each other.
+//     of packed_info rows (16 B/ray read once); the ray id of every element is resolved ONCE per
+//     step (lane-local + 6 DPP steps: row_shr 1/2/4/8, row_bcast 15/31), value scans reuse that
+//     structure (one DPP add + one select per step and channel) and carry the open ray across
+//     steps; waves never synchronise with each other;
+//   * a step may run a second scan stage whose inputs are the first stage's results (per-ray
+//     totals of w*rgb after the transmittance scan) and a pre-scan hook that sees the ray id
+//     (gradient of a per-ray reduction), which is how `rendering()` becomes one pass each way.
 // The op-specific arithmetic (exp, alpha, weights, gradients, masks, compaction, per-ray sums)
 // is fused into the same pass through small functor structs.
 //

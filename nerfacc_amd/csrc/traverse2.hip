@@ -1,4 +1,4 @@
-// traverse2.hip -- run-length traversal for the sampler (constant step, cone_angle == 0).
+// traverse2.hip -- run-length traversal (constant step, cone_angle == 0): the sampler's and the API's fast path.
 //
 // The reference walks every ray twice with the same divergent DDA kernel (count pass, fill pass;
 // cuda/csrc/grid.cu:405-471), one 1-byte scattered grid load per cell and per-thread strided
@@ -11,17 +11,18 @@
 //                 current word is cached in registers, so most cells cost no memory access.
 //                 The walk does no marching: it records one typed threshold per run of cells of
 //                 one kind (a handful per ray, in LDS).  A second, lock-step phase marches through
-//                 those thresholds with the exact O(#binades) jumps of march.h -- skipping and
+//                 those thresholds with march.h's Stepper (remembered stable increment per binade,
+//                 verified jump counts, tabulated approach from a common near plane) -- skipping and
 //                 sample emission are the same code path, emission being "count the steps" -- so
 //                 there is no per-sample loop and no per-cell divergence.  Instead of samples the
-//                 pass emits RUNS: (t_first, n) for n consecutive samples with one exact fp32
-//                 increment -- typically 2-10 per ray (8 B each).
-//   expand pass   after the device-side cumsum of the sample counts, every output element is
-//                 computed independently: t_start = t_first + k*inc, t_end = t_first + (k+1)*inc
-//                 (exact: multiples of one ulp inside a binade), ray index from the run.  A wave
-//                 stages the runs of 32 rays in LDS and streams its contiguous output range with
-//                 16 B-per-lane stores: the 16 B/sample of the sampler's output are written once,
-//                 fully coalesced.
+//                 pass emits RUN RECORDS: n consecutive samples with one exact fp32 increment,
+//                 typically 2-10 per ray (8 B each, slot-major).
+//   expand passes after the device-side cumsum of the counts, every output element is computed
+//                 independently: t = fma(k, inc, t_first) (exact: every sample of a run is t_first + k*inc).
+//                 A wave stages the records of 32 rays in LDS; per 256-output chunk the run starts are
+//                 scattered into an LDS line and a "most recent entry" DPP scan tells every output its
+//                 run; 16 B-per-lane stores.  expand_runs: (t_starts, t_ends, ray_indices) or the API's
+//                 sample centres; expand_intervals: the API's edge stream with is_left / is_right.
 // Results are bit-identical to the reference's serial accumulation (oracle/nerfacc_oracle.c).
 #include "common.hip.h"
 #include "march.h"
