@@ -48,17 +48,36 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t subseque
     return (float)out[offset & 3] * 2.3283064365386963e-10f + 1.1641532182693481e-10f;
 }
 
+__device__ __forceinline__ int upper_bound_lds(const float *data, int start, int end, float val)
+{
+    while (start < end) {
+        const int mid = start + ((end - start) >> 1);
+        if (!(data[mid] > val)) start = mid + 1;
+        else end = mid;
+    }
+    return start;
+}
+
+constexpr int IS_STAGE_MAX = 512;  // CDF entries a wave may stage in LDS (x 2 arrays x 4 waves = 16 KiB per workgroup)
+
 // L lanes per ray (power of two <= 64); 64 / L rays per wave.
+// STAGED (batched input whose rays fit): the wave's rays are consecutive rows of one contiguous block, which is
+// copied to LDS with coalesced loads; the S binary searches of a ray then run on LDS (7 dependent ~64-cycle reads
+// instead of 7 dependent global loads per sample).
+template <bool STAGED>
 __global__ __launch_bounds__(256) void importance_sampling_kernel(
     const float *__restrict__ in_vals, const float *__restrict__ cdfs, const int64_t *__restrict__ in_packed,
     int64_t n_rays, int64_t n_edges_per_ray, int64_t S, int L, int stratified, uint64_t seed, uint64_t offset,
     float *__restrict__ out_iv, float *__restrict__ out_sm)
 {
+    __shared__ float s_cdf[4][STAGED ? IS_STAGE_MAX : 1];
+    __shared__ float s_val[4][STAGED ? IS_STAGE_MAX : 1];
     const int lane = lane_id();
     const int gl = lane & (L - 1);            // lane within the ray's group
     const int rays_per_wave = 64 / L;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    float *lc = s_cdf[threadIdx.x >> 6], *lv = s_val[threadIdx.x >> 6];
     for (int64_t r0 = wave * rays_per_wave; r0 < n_rays; r0 += n_waves * rays_per_wave) {
         const int64_t ray = r0 + lane / L;
         const bool ray_ok = ray < n_rays;
@@ -67,27 +86,42 @@ __global__ __launch_bounds__(256) void importance_sampling_kernel(
             if (in_packed) { base = in_packed[2 * ray]; last = base + in_packed[2 * ray + 1] - 1; }
             else { base = ray * n_edges_per_ray; last = base + n_edges_per_ray - 1; }
         }
+        int lbase = 0;  // the ray's first entry in LDS
+        if (STAGED) {
+            const int64_t blk0 = r0 * n_edges_per_ray;
+            const int64_t n_here = min((int64_t)rays_per_wave, n_rays - r0) * n_edges_per_ray;
+            __builtin_amdgcn_wave_barrier();
+            for (int f = lane; f < n_here; f += 64) { lc[f] = cdfs[blk0 + f]; lv[f] = in_vals[blk0 + f]; }
+            __builtin_amdgcn_wave_barrier();
+            lbase = (lane / L) * (int)n_edges_per_ray;
+        }
+        const int llast = lbase + (int)n_edges_per_ray - 1;
         float u_floor = 0.f, u_step = 0.f, bias = 0.5f, t_min = 0.f, t_max = 0.f;
         if (ray_ok) {
-            u_floor = cdfs[base];
-            const float u_ceil = cdfs[last];
+            u_floor = STAGED ? lc[lbase] : cdfs[base];
+            const float u_ceil = STAGED ? lc[llast] : cdfs[last];
             u_step = (u_ceil - u_floor) / S;
             if (stratified) bias = philox_uniform(seed, (uint64_t)ray, offset);
-            t_min = in_vals[base];
-            t_max = in_vals[last];
+            t_min = STAGED ? lv[lbase] : in_vals[base];
+            t_max = STAGED ? lv[llast] : in_vals[last];
         }
         float t_carry = 0.f;  // last sample of the previous block of L samples
-        float t_first = 0.f;
         for (int64_t s0 = 0; s0 < S; s0 += L) {
             const int64_t sid = s0 + gl;
             const bool ok = ray_ok && sid < S;
             float t = 0.f;
             if (ok) {  // pdf.cu:133-166
                 const float u = u_floor + (sid + bias) * u_step;
-                const int64_t p = upper_bound_f(cdfs, base, last, u);
-                const int64_t p0 = clamp64(p - 1, base, last), p1 = clamp64(p, base, last);
-                const float u_lower = cdfs[p0], u_upper = cdfs[p1];
-                const float t_lower = in_vals[p0], t_upper = in_vals[p1];
+                float u_lower, u_upper, t_lower, t_upper;
+                if (STAGED) {
+                    const int p = upper_bound_lds(lc, lbase, llast, u);
+                    const int p0 = min(max(p - 1, lbase), llast), p1 = min(max(p, lbase), llast);
+                    u_lower = lc[p0]; u_upper = lc[p1]; t_lower = lv[p0]; t_upper = lv[p1];
+                } else {
+                    const int64_t p = upper_bound_f(cdfs, base, last, u);
+                    const int64_t p0 = clamp64(p - 1, base, last), p1 = clamp64(p, base, last);
+                    u_lower = cdfs[p0]; u_upper = cdfs[p1]; t_lower = in_vals[p0]; t_upper = in_vals[p1];
+                }
                 if (u_upper - u_lower < 1e-10f) t = (t_lower + t_upper) * 0.5f;
                 else {
                     const float scaling = (t_upper - t_lower) / (u_upper - u_lower);
@@ -99,8 +133,6 @@ __global__ __launch_bounds__(256) void importance_sampling_kernel(
             float t_prev = __shfl_up(t, 1, L);
             if (gl == 0) t_prev = t_carry;
             const float t_next = __shfl_down(t, 1, L);
-            if (s0 == 0) t_first = __shfl(t, 0, L);
-            (void)t_first;
             if (ok) {
                 float *edge = out_iv + ray * (S + 1);
                 if (sid == 0) {
@@ -119,15 +151,39 @@ __global__ __launch_bounds__(256) void importance_sampling_kernel(
     }
 }
 
+// STAGED (query and key both batched, the keys of the rays a wave touches fit): a wave's 64 consecutive queries
+// belong to a few consecutive rays whose key rows are one contiguous block; it is copied to LDS and searched there.
+template <bool STAGED>
 __global__ __launch_bounds__(256) void searchsorted_kernel(
     const float *__restrict__ q_vals, const int64_t *__restrict__ q_packed, const int64_t *__restrict__ q_ray_indices,
     int64_t q_n_rays, int64_t q_per_ray, int64_t q_total, const float *__restrict__ k_vals,
     const int64_t *__restrict__ k_packed, int64_t k_per_ray, int64_t *__restrict__ ids_left,
     int64_t *__restrict__ ids_right)
 {
+    __shared__ float s_key[4][STAGED ? IS_STAGE_MAX : 1];
     const bool q_batched = q_packed == nullptr;
-    for (int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tid < q_total;
-         tid += (int64_t)blockDim.x * gridDim.x) {
+    const int lane = lane_id();
+    float *lk = s_key[threadIdx.x >> 6];
+    for (int64_t tid0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; tid0 < q_total;
+         tid0 += (int64_t)blockDim.x * gridDim.x) {
+        const int64_t tid = tid0 + lane;
+        if (STAGED) {
+            const int64_t r_first = tid0 / q_per_ray;
+            const int64_t r_last = min(tid0 + 63, q_total - 1) / q_per_ray;
+            const int64_t blk0 = r_first * k_per_ray, n_here = (r_last - r_first + 1) * k_per_ray;
+            __builtin_amdgcn_wave_barrier();
+            for (int f = lane; f < n_here; f += 64) lk[f] = k_vals[blk0 + f];
+            __builtin_amdgcn_wave_barrier();
+            if (tid < q_total) {
+                const int64_t ray_id = tid / q_per_ray;
+                const int lbase = (int)((ray_id - r_first) * k_per_ray), llast = lbase + (int)k_per_ray - 1;
+                const int p = upper_bound_lds(lk, lbase, llast, q_vals[tid]);
+                ids_left[tid] = min(max(p - 1, lbase), llast) - lbase;
+                ids_right[tid] = min(max(p, lbase), llast) - lbase;
+            }
+            continue;
+        }
+        if (tid >= q_total) continue;
         int64_t ray_id;
         if (q_batched) ray_id = tid / q_per_ray;
         else if (q_ray_indices) ray_id = q_ray_indices[tid];
@@ -169,9 +225,15 @@ int nfa_importance_sampling(const float *in_vals, const float *cdfs, const int64
     const int64_t rays_per_wave = 64 / L;
     const int64_t n_waves = ceil_div64(n_rays, rays_per_wave);
     const unsigned grid = grid_1d(n_waves * 64, 256, 1 << 16);
-    hipLaunchKernelGGL(importance_sampling_kernel, dim3(grid), dim3(256), 0, as_stream(stream), in_vals, cdfs,
-                       in_packed_info, n_rays, n_edges_per_ray, n_samples, L, stratified, seed, offset, out_intervals,
-                       out_samples);
+    const bool staged = !in_packed_info && rays_per_wave * n_edges_per_ray <= IS_STAGE_MAX;
+    if (staged)
+        hipLaunchKernelGGL(importance_sampling_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), in_vals, cdfs,
+                           in_packed_info, n_rays, n_edges_per_ray, n_samples, L, stratified, seed, offset, out_intervals,
+                           out_samples);
+    else
+        hipLaunchKernelGGL(importance_sampling_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), in_vals, cdfs,
+                           in_packed_info, n_rays, n_edges_per_ray, n_samples, L, stratified, seed, offset, out_intervals,
+                           out_samples);
     NFA_CHECK_LAUNCH("importance_sampling");
     return NFA_OK;
 }
@@ -185,9 +247,16 @@ int nfa_searchsorted(const float *q_vals, const int64_t *q_packed_info, const in
     NFA_REQUIRE(q_vals && k_vals && ids_left && ids_right, "searchsorted: null pointer");
     NFA_REQUIRE(q_packed_info || q_per_ray >= 1, "searchsorted: batched query needs q_per_ray");
     NFA_REQUIRE(k_packed_info || k_per_ray >= 1, "searchsorted: batched key needs k_per_ray");
-    hipLaunchKernelGGL(searchsorted_kernel, dim3(grid_1d(q_total, 256)), dim3(256), 0, as_stream(stream), q_vals,
-                       q_packed_info, q_ray_indices, q_n_rays, q_per_ray, q_total, k_vals, k_packed_info, k_per_ray,
-                       ids_left, ids_right);
+    // rays touched by 64 consecutive queries: at most 63 / q_per_ray + 2
+    const bool staged = !q_packed_info && !k_packed_info && (63 / q_per_ray + 2) * k_per_ray <= IS_STAGE_MAX;
+    if (staged)
+        hipLaunchKernelGGL(searchsorted_kernel<true>, dim3(grid_1d(q_total, 256)), dim3(256), 0, as_stream(stream), q_vals,
+                           q_packed_info, q_ray_indices, q_n_rays, q_per_ray, q_total, k_vals, k_packed_info, k_per_ray,
+                           ids_left, ids_right);
+    else
+        hipLaunchKernelGGL(searchsorted_kernel<false>, dim3(grid_1d(q_total, 256)), dim3(256), 0, as_stream(stream), q_vals,
+                           q_packed_info, q_ray_indices, q_n_rays, q_per_ray, q_total, k_vals, k_packed_info, k_per_ray,
+                           ids_left, ids_right);
     NFA_CHECK_LAUNCH("searchsorted");
     return NFA_OK;
 }
