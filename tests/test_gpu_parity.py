@@ -705,6 +705,69 @@ def test_prefetched_traversal_is_the_same_sampling(dev):
         got = est.sampling(ro, rd, traversal=h, **kw); est.sampling(ro, rd, traversal=h, **kw)
 
 
+def test_traversal_fuzz_bit_exact(dev, oracle):
+    """Randomised configurations against the oracle, bit for bit: resolutions (also not multiples of 4), 1-3
+    levels, occupancies from 2 % to 90 % (90 % random cells = dozens of runs per ray: the overflow path), steps
+    from a fraction of a cell to several cells, rays from inside and outside with zero direction components,
+    per-ray near / far planes, sample budgets; API traverse_grids (intervals + samples), the sampler's direct
+    path and the test-mode (mask + limit) path."""
+    rng = np.random.default_rng(2024)
+    n_cases = 24
+    for case in range(n_cases):
+        res = [int(rng.choice([8, 16, 24, 30, 50])) for _ in range(3)] if case % 3 else [int(rng.choice([16, 32]))] * 3
+        levels = int(rng.integers(1, 4))
+        occ = float(rng.choice([0.02, 0.1, 0.5, 0.9]))
+        n_rays = int(rng.integers(200, 1500))
+        b = rng.random((levels, *res)) < occ
+        if case % 5 == 0:
+            b[:] = False
+            b[:, res[0] // 4: res[0] // 2] = True               # a slab: long continuous runs
+        if case % 7 == 3:                                         # checkerboard: > 32 runs per ray (overflow rays)
+            res = [48, 48, 48]
+            ii = np.indices(res).sum(0)
+            b = np.broadcast_to((ii % 2 == 0), (levels, *res)).copy()
+        o = (rng.random((n_rays, 3)) * 3 - 1.5).astype(np.float32)
+        if case % 2:
+            o *= 0.3                                              # inside the level-0 box
+        d = rng.standard_normal((n_rays, 3)).astype(np.float32)
+        d[rng.random(n_rays) < 0.1, int(rng.integers(0, 3))] = 0.0    # axis-parallel components
+        d /= np.maximum(np.linalg.norm(d, axis=-1, keepdims=True), 1e-6)
+        step = float(rng.choice([2e-3, 7e-3, 0.03, 0.11])) * (2.0 / min(res)) * 8
+        est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=res, levels=levels).to(dev)
+        ab = est.aabbs.cpu().numpy()
+        near = (rng.random(n_rays) * 0.5).astype(np.float32) if case % 4 == 1 else None
+        far = (near + 0.5 + rng.random(n_rays) * 3).astype(np.float32) if near is not None else None
+        kw = dict(step_size=step)
+        if near is not None:
+            kw.update(near_planes=near, far_planes=far)
+        if case % 6 == 2:
+            kw.update(traverse_steps_limit=int(rng.integers(3, 40)))
+        tkw = {k: (T(v, dev) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+        res_api = na.traverse_grids(T(o, dev), T(d, dev), T(b, dev), T(ab, dev), **tkw)
+        ref = oracle.traverse_grids(o, d, b, ab, **kw)
+        _cmp_traversal(res_api, ref)
+        # sampler path (t_starts / t_ends of the same samples)
+        nearp = T(near if near is not None else np.zeros(n_rays, np.float32), dev)
+        farp = T(far if far is not None else np.full(n_rays, 1e10, np.float32), dev)
+        mask = (rng.random(n_rays) < 0.7) if case % 6 == 2 else None
+        ri, ts, te, pi = na.grid._traverse_samples(
+            T(o, dev), T(d, dev), T(b, dev), T(ab, dev), nearp, farp, step, 0.0,
+            rays_mask=None if mask is None else T(mask, dev), traverse_steps_limit=kw.get("traverse_steps_limit"),
+            near_hint=0.0 if near is None else None)
+        if mask is None:
+            riv, rsm, _ = oracle.traverse_grids(o, d, b, ab, near_planes=nearp.cpu().numpy(), far_planes=farp.cpu().numpy(),
+                                                **{k: v for k, v in kw.items() if k not in ("near_planes", "far_planes")})
+            L, Rr = riv["vals"][riv["is_left"]], riv["vals"][riv["is_right"]]
+            assert (ri.cpu().numpy() == rsm["ray_indices"]).all() and (ts.cpu().numpy() == L).all() and (te.cpu().numpy() == Rr).all(), case
+        else:
+            riv, rsm, _ = oracle.traverse_grids(o, d, b, ab, near_planes=nearp.cpu().numpy(), far_planes=farp.cpu().numpy(),
+                                                step_size=step, traverse_steps_limit=kw["traverse_steps_limit"],
+                                                over_allocate=True, rays_mask=mask)
+            L, Rr = riv["vals"][riv["is_left"]], riv["vals"][riv["is_right"]]
+            keep = rsm["is_valid"]
+            assert (ri.cpu().numpy() == rsm["ray_indices"][keep]).all() and (ts.cpu().numpy() == L).all() and (te.cpu().numpy() == Rr).all(), case
+
+
 # ----------------------------------------------------------------------------- full-size properties (BASELINE cfg 2)
 def test_full_size_properties(dev):
     """1024x1024 rays through a 128^3 grid at ~10% occupancy: size-independent invariants."""
