@@ -786,7 +786,7 @@ struct VisibilityOp {
         for (int j = 0; j < 4; ++j) {
             pf[j] = prefix ? r.pf.v[j] : 1.0f;
             const float sv = sel(r.s, j, valid, 0.0f);
-            if (DENSITY) { x0[j] = valid[j] ? sv * (r.b.v[j] - r.a.v[j]) : 0.0f; a4[j] = 1.0f - expf(-x0[j]); }
+            if (DENSITY) { x0[j] = valid[j] ? sv * (r.b.v[j] - r.a.v[j]) : 0.0f; a4[j] = (thre > 0.0f) ? 1.0f - expf(-x0[j]) : 1.0f; }  // alpha only when it is tested
             else { a4[j] = sv; x0[j] = 1.0f - sv; }
         }
     }
