@@ -265,6 +265,16 @@ int nfa_render_fused_bwd(const float *t_starts, const float *t_ends, const float
                          int64_t n_rays, int64_t n_elems, float *grad_sigmas, float *grad_rgbs,
                          nfa_stream_t stream);
 
+/* One iteration of the test-mode marching loop (ref: examples/utils.py:370-405) in one pass: weights from
+ * densities with prefix_trans = 1 - opacities[ray], samples with alpha < alpha_thre dropped (alpha_thre <= 0:
+ * none), and colors[r,3] / opacities[r] / depths[r] accumulated in place (+=).  Deterministic (a ray is owned by
+ * one wave); replaces render_weight_from_density + boolean masks + 3 accumulate_along_rays_ launches.
+ * *n_visible (may be NULL) += number of samples that passed the threshold (the loop's running sample count). */
+int nfa_render_step_accumulate(const float *t_starts, const float *t_ends, const float *sigmas, const float *rgbs,
+                               const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles, int64_t n_rays,
+                               int64_t n_elems, float alpha_thre, float *colors, float *opacities, float *depths,
+                               int64_t *n_visible, nfa_stream_t stream);
+
 /* ------------------------------------------------------------------ pdf */
 
 /* ref: cuda/csrc/pdf.cu:359-421 (int overload): S samples + S+1 edges per ray, batched outputs.

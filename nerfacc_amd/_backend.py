@@ -72,6 +72,7 @@ _SIGS = {
     "nfa_render_accumulate_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],
     "nfa_render_fused_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "nfa_render_fused_bwd": [_vp] * 13 + [_i64, _i64, _i64, _vp, _vp, _vp],
+    "nfa_render_step_accumulate": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _vp, _vp],
     "nfa_importance_sampling": [_vp, _vp, _vp, _i64, _i64, _i64, _int, _u64, _u64, _vp, _vp, _vp],
     "nfa_searchsorted": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp],
     "nfa_cumsum_scratch_bytes": [_i64],

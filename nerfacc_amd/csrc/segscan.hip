@@ -1194,6 +1194,69 @@ struct RenderFusedFwdOp : OpBase1 {
     }
 };
 
+// ---- one iteration of the test-mode marching loop (ref: examples/utils.py:370-405) in one pass: weights with
+//      prefix_trans = 1 - opacity[ray] (the ray id is known before the scan), samples with alpha < alpha_thre dropped,
+//      and rgb / opacity / depth accumulated IN PLACE into the per-ray image buffers.  Nothing per sample is written.
+//      A ray is owned by one wave, which reads its old opacity for all the ray's samples before it adds the total.
+template <bool VEC>
+struct RenderStepOp : OpBase1 {
+    static constexpr int NCHB = 5;
+    static constexpr bool NEEDS_RID = true;
+    struct Raw { F4 a, b, s; float c[12]; };
+    const float *ts, *te, *sig, *rgb;
+    float thre;
+    float *colors, *opac, *depth;  // [R,3], [R], [R] in/out
+    unsigned long long *n_visible;  // += samples that pass the alpha threshold (the loop's sample count), or null
+    float xs[4], mid[4], pf[4], rw[4], c[12];
+    bool keep[4];
+    __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
+    {
+        ld4<VEC>(ts, q, r.a);
+        ld4<VEC>(te, q, r.b);
+        ld4<VEC>(sig, q, r.s);
+        load_rgb12(rgb, VEC, q, r.c);
+    }
+    __device__ __forceinline__ void load(const Raw &r, const Pos &pos)
+    {
+        const bool *valid = pos.valid;
+        fix_rgb12(rgb, VEC, pos, r.c, c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xs[j] = valid[j] ? r.s.v[j] * (r.b.v[j] - r.a.v[j]) : 0.0f;
+            mid[j] = (r.a.v[j] + r.b.v[j]) / 2.0f;
+        }
+    }
+    __device__ __forceinline__ void pre(int j, int64_t, bool valid, int rid) { pf[j] = valid ? 1.0f - opac[rid] : 1.0f; }
+    __device__ __forceinline__ void store_pre(const Pos &) const {}
+    __device__ __forceinline__ float x(int j, int) const { return xs[j]; }
+    __device__ __forceinline__ void emit(int j, int64_t, bool valid, bool is_head, int, int, const float *, const float prev[1])
+    {
+        const float S = is_head ? 0.0f : prev[0];
+        const float T = expf(-S) * pf[j];
+        const float a = 1.0f - expf(-xs[j]);
+        keep[j] = valid && !(thre > 0.0f && !(a >= thre));
+        rw[j] = keep[j] ? T * a : 0.0f;
+    }
+    __device__ __forceinline__ float xb(int j, int ch) const
+    {
+        return ch < 3 ? rw[j] * c[3 * j + ch] : (ch == 3 ? rw[j] : rw[j] * mid[j]);
+    }
+    __device__ __forceinline__ void ray_done_b(int rid, int ch, float t) const
+    {
+        if (ch < 3) colors[3 * (int64_t)rid + ch] += t;
+        else if (ch == 3) opac[rid] += t;
+        else depth[rid] += t;
+    }
+    __device__ __forceinline__ void store(const Pos &) const
+    {
+        if (n_visible) {
+            const int c = __builtin_popcountll(__ballot(keep[0])) + __builtin_popcountll(__ballot(keep[1])) +
+                          __builtin_popcountll(__ballot(keep[2])) + __builtin_popcountll(__ballot(keep[3]));
+            if (c > 0 && lane_id() == 0) atomicAdd(n_visible, (unsigned long long)c);
+        }
+    }
+};
+
 // ---- its backward in one reverse pass: the gradient of the three accumulations w.r.t. w is formed
 //      from the per-ray output gradients (needs the ray id before the scan: NEEDS_RID), added to the
 //      gradients arriving at extras' weights / trans / alphas, and pushed through the transmittance
@@ -1722,6 +1785,27 @@ int nfa_render_fused_bwd(const float *t_starts, const float *t_ends, const float
     else     { if (extra) NFA_FB(false, true); else NFA_FB(false, false); }
 #undef NFA_FB
     NFA_CHECK_LAUNCH("render_fused_bwd");
+    return NFA_OK;
+}
+
+int nfa_render_step_accumulate(const float *t_starts, const float *t_ends, const float *sigmas, const float *rgbs,
+                               const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles, int64_t n_rays,
+                               int64_t n_elems, float alpha_thre, float *colors, float *opacities, float *depths,
+                               int64_t *n_visible, nfa_stream_t stream)
+{
+    SEG_COMMON_CHECKS("render_step_accumulate");
+    if (n_elems == 0) return NFA_OK;
+    NFA_REQUIRE(t_starts && t_ends && sigmas && rgbs && colors && opacities && depths, "render_step_accumulate: null pointer");
+    hipStream_t s = as_stream(stream);
+    const bool vec = all_aligned16(t_starts, t_ends, sigmas, rgbs);
+#define NFA_RS(V)                                                                                          \
+    do { RenderStepOp<V> op; op.ts = t_starts; op.te = t_ends; op.sig = sigmas; op.rgb = rgbs; op.thre = alpha_thre; \
+         op.colors = colors; op.opac = opacities; op.depth = depths;                                         \
+         op.n_visible = reinterpret_cast<unsigned long long *>(n_visible);                                   \
+         launch_seg<1>(op, packed_info, tiles, n_rays, n_tiles, s); } while (0)
+    if (vec) NFA_RS(true); else NFA_RS(false);
+#undef NFA_RS
+    NFA_CHECK_LAUNCH("render_step_accumulate");
     return NFA_OK;
 }
 

@@ -24,9 +24,19 @@ from typing import Callable, Optional, Tuple
 import torch
 from torch import Tensor
 
+from . import _backend as B
 from .estimators.occ_grid import OccGridEstimator
 from .grid import _traverse_samples, ray_aabb_intersect
 from .volrend import accumulate_along_rays_, render_weight_from_density
+
+
+def _render_step_native(seg, t_starts, t_ends, sigmas, rgbs, alpha_thre, rgb, opacity, depth, n_visible) -> None:
+    dev = B.require_device(t_starts, t_ends, sigmas, rgbs, rgb, opacity, depth)
+    assert rgb.is_contiguous() and opacity.is_contiguous() and depth.is_contiguous()
+    with torch.cuda.device(dev):
+        B.call("nfa_render_step_accumulate", B.ptr(t_starts), B.ptr(t_ends), B.ptr(sigmas), B.ptr(rgbs),
+               B.ptr(seg.packed_info), B.ptr(seg.tiles), seg.n_tiles, seg.n_rays, sigmas.numel(), float(alpha_thre),
+               B.ptr(rgb), B.ptr(opacity), B.ptr(depth), B.ptr(n_visible), B.stream())
 
 
 @torch.no_grad()
@@ -66,7 +76,7 @@ def render_rays_test_mode(
         t_mins, t_maxs, hits = ray_aabb_intersect(rays_o, rays_d, estimator.aabbs)
         t_sorted, t_indices = torch.sort(torch.cat([t_mins, t_maxs], -1), -1)
     opc_thre = 1 - early_stop_eps
-    rgbs = None
+    n_visible = None  # device counter of the samples that pass alpha_thre on the fused path
 
     while iter_samples < max_samples:
         n_alive = int(ray_mask.sum().item())
@@ -80,23 +90,39 @@ def render_rays_test_mode(
             cone_angle, rays_mask=ray_mask, traverse_steps_limit=n_samples, t_sorted=t_sorted, t_indices=t_indices,
             hits=hits, return_terminate=True, near_hint=near_plane if iter_samples == n_samples else None)
 
+        n_counted = 0
         if ray_indices.numel() > 0:
             rgbs, sigmas = rgb_sigma_fn(t_starts, t_ends, ray_indices)
-            weights, _, alphas = render_weight_from_density(
-                t_starts, t_ends, sigmas, packed_info=packed_info, n_rays=num_rays,
-                prefix_trans=1 - opacity[ray_indices].squeeze(-1))
-            if alpha_thre > 0:
-                vis_mask = alphas >= alpha_thre
-                ray_indices, rgbs, weights, t_starts, t_ends = (
-                    ray_indices[vis_mask], rgbs[vis_mask], weights[vis_mask], t_starts[vis_mask], t_ends[vis_mask])
-            accumulate_along_rays_(weights, values=rgbs, ray_indices=ray_indices, outputs=rgb)
-            accumulate_along_rays_(weights, values=None, ray_indices=ray_indices, outputs=opacity)
-            accumulate_along_rays_(weights, values=(t_starts + t_ends)[..., None] / 2.0, ray_indices=ray_indices,
-                                   outputs=depth)
+            seg = getattr(packed_info, "_nfa_seg", None)
+            if (seg is not None and seg[2].contiguous and rgbs.dtype == sigmas.dtype == torch.float32
+                    and rgbs.dim() == 2 and rgbs.shape[-1] == 3):
+                # weights with prefix_trans = 1 - opacity[ray], alpha_thre masking and the three in-place
+                # accumulations (:370-405) as one pass of the segmented engine
+                if alpha_thre > 0 and n_visible is None:
+                    n_visible = torch.zeros(1, dtype=torch.int64, device=device)
+                _render_step_native(seg[2], t_starts, t_ends, sigmas.contiguous(), rgbs.contiguous(), alpha_thre,
+                                    rgb, opacity, depth, n_visible if alpha_thre > 0 else None)
+                n_counted = 0 if alpha_thre > 0 else ray_indices.shape[0]
+            else:
+                weights, _, alphas = render_weight_from_density(
+                    t_starts, t_ends, sigmas, packed_info=packed_info, n_rays=num_rays,
+                    prefix_trans=1 - opacity[ray_indices].squeeze(-1))
+                if alpha_thre > 0:
+                    vis_mask = alphas >= alpha_thre
+                    ri_v, rgbs, weights, ts_v, te_v = (ray_indices[vis_mask], rgbs[vis_mask], weights[vis_mask],
+                                                       t_starts[vis_mask], t_ends[vis_mask])
+                else:
+                    ri_v, ts_v, te_v = ray_indices, t_starts, t_ends
+                accumulate_along_rays_(weights, values=rgbs, ray_indices=ri_v, outputs=rgb)
+                accumulate_along_rays_(weights, values=None, ray_indices=ri_v, outputs=opacity)
+                accumulate_along_rays_(weights, values=(ts_v + te_v)[..., None] / 2.0, ray_indices=ri_v, outputs=depth)
+                n_counted = ri_v.shape[0]
         near_planes = termination_planes
         ray_mask = torch.logical_and(opacity.view(-1) <= opc_thre, packed_info[:, 1] == n_samples)
-        total_samples += ray_indices.shape[0]
+        total_samples += n_counted  # samples that entered the accumulation (:416)
 
+    if n_visible is not None:
+        total_samples += int(n_visible.item())
     if render_bkgd is not None:
         rgb = rgb + render_bkgd * (1.0 - opacity)
     eps = torch.finfo(rgb.dtype).eps
