@@ -502,13 +502,18 @@ static void launch_seg(const Op &op, const int64_t *packed_info, const int64_t *
 {
     const longlong2 *tiles = reinterpret_cast<const longlong2 *>(tiles_raw);
     const unsigned grid = (unsigned)ceil_div64(n_tiles, SEG_WAVES_PER_BLOCK);
-    static const bool pipe = getenv("NFA_SEG_PIPELINE") ? atoi(getenv("NFA_SEG_PIPELINE")) != 0 : false;  // measured: no gain, more VGPRs
-    if (pipe)
+    // The one-step-ahead software prefetch (PIPE) measured slower than the extra occupancy its registers cost on
+    // every op; it is compiled only with -DNFA_SEG_ENABLE_PIPE=1 (then NFA_SEG_PIPELINE=1 selects it at run time).
+#if defined(NFA_SEG_ENABLE_PIPE) && NFA_SEG_ENABLE_PIPE
+    static const bool pipe = getenv("NFA_SEG_PIPELINE") ? atoi(getenv("NFA_SEG_PIPELINE")) != 0 : false;
+    if (pipe) {
         hipLaunchKernelGGL((seg_kernel<DIR, true, Op>), dim3(grid), dim3(64 * SEG_WAVES_PER_BLOCK), 0, s, op, packed_info, tiles,
                            n_rays, n_tiles);
-    else
-        hipLaunchKernelGGL((seg_kernel<DIR, false, Op>), dim3(grid), dim3(64 * SEG_WAVES_PER_BLOCK), 0, s, op, packed_info, tiles,
-                           n_rays, n_tiles);
+        return;
+    }
+#endif
+    hipLaunchKernelGGL((seg_kernel<DIR, false, Op>), dim3(grid), dim3(64 * SEG_WAVES_PER_BLOCK), 0, s, op, packed_info, tiles,
+                       n_rays, n_tiles);
 }
 
 // ------------------------------------------------------------------------------------------

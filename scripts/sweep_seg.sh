@@ -1,6 +1,6 @@
 #!/bin/bash
 # scratch: sweep tile size / prefetch for the segmented engine on the bench workload
-for pipe in 1 0; do for tile in 512 1024 2048 4096; do
+for pipe in 0; do for tile in 512 1024 2048 4096; do  # pipe=1 needs a build with -DNFA_SEG_ENABLE_PIPE=1
   echo "== pipeline=$pipe tile=$tile"
   NFA_SEG_PIPELINE=$pipe NFA_SEG_TILE=$tile python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
