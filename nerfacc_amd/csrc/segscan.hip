@@ -32,7 +32,12 @@
 namespace nfa {
 
 constexpr int SEG_CHUNK = 256;  // elements per wave step (4 per lane)
-constexpr int SEG_WAVES_PER_BLOCK = 4;
+#ifndef NFA_SEG_WAVES_PER_BLOCK
+#define NFA_SEG_WAVES_PER_BLOCK 1
+#endif
+// waves never cooperate, so the workgroup size is only a dispatch granularity; measured on cfg 2 (fused bwd / fwd /
+// visibility, us): 1 wave 333 / 271 / 135, 2 waves 335 / 273 / 137, 4 waves 343 / 275 / 138, 8 waves 369 / 288 / 144
+constexpr int SEG_WAVES_PER_BLOCK = NFA_SEG_WAVES_PER_BLOCK;
 
 // ------------------------------------------------------------------------------------------
 // tile ownership table
