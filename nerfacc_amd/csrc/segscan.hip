@@ -33,10 +33,11 @@ namespace nfa {
 
 constexpr int SEG_CHUNK = 256;  // elements per wave step (4 per lane)
 #ifndef NFA_SEG_WAVES_PER_BLOCK
-#define NFA_SEG_WAVES_PER_BLOCK 1
+#define NFA_SEG_WAVES_PER_BLOCK 4
 #endif
 // waves never cooperate, so the workgroup size is only a dispatch granularity; measured on cfg 2 (fused bwd / fwd /
-// visibility, us): 1 wave 333 / 271 / 135, 2 waves 335 / 273 / 137, 4 waves 343 / 275 / 138, 8 waves 369 / 288 / 144
+// visibility, us): 1 wave 333 / 271 / 135, 2 waves 335 / 273 / 137, 4 waves 343 / 275 / 138, 8 waves 369 / 288 / 144 --
+// but the whole step (and the pipelined loop) is not faster with 1 than with 4, so 4 stays
 constexpr int SEG_WAVES_PER_BLOCK = NFA_SEG_WAVES_PER_BLOCK;
 
 // ------------------------------------------------------------------------------------------

@@ -31,6 +31,10 @@ namespace nfa {
 
 constexpr int EXP_RPW = 32;        // rays per wave batch in the expansion
 constexpr int EXP_QMAX = 1024;     // runs staged per batch (EXP_RPW * max_runs)
+#ifndef NFA_EXP_WPB
+#define NFA_EXP_WPB 2  /* measured on cfg 2: 1 wave 176 us, 2 waves 160 us, 4 waves 175 us */
+#endif
+constexpr int EXP_WPB = NFA_EXP_WPB;  // waves per workgroup of the expansion kernels (they never cooperate)
 constexpr int COARSE_LDS_WORDS = 8192;  // 32 KiB: up to 64^3 bricks (256^3 cells); next to the 32 KiB event lists
 
 // ------------------------------------------------------------------------------------------
@@ -376,21 +380,21 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
 // produced chunk by chunk (256 per step, 16 B per lane and array) with a scatter + "most recent entry"
 // scan that tells every output its run.
 template <bool MIDS /* write the API's sample centres instead of (t_starts, t_ends) */>
-__global__ __launch_bounds__(256) void expand_runs_kernel(int64_t n_rays, float dt, const int32_t *__restrict__ run_cnts,
+__global__ __launch_bounds__(64 * EXP_WPB) void expand_runs_kernel(int64_t n_rays, float dt, const int32_t *__restrict__ run_cnts,
                                                           const unsigned long long *__restrict__ runs, int32_t max_runs,
                                                           const longlong2 *__restrict__ packed_info,
                                                           float *__restrict__ t_starts, float *__restrict__ t_ends,
                                                           float *__restrict__ t_mids, int64_t *__restrict__ ray_indices, int vec)
 {
-    __shared__ uint32_t s_pos[4][EXP_QMAX];
-    __shared__ float s_t0[4][EXP_QMAX];
-    __shared__ __attribute__((aligned(16))) int32_t s_own[4][256];  // entry that starts at each output of the current chunk
+    __shared__ uint32_t s_pos[EXP_WPB][EXP_QMAX];
+    __shared__ float s_t0[EXP_WPB][EXP_QMAX];
+    __shared__ __attribute__((aligned(16))) int32_t s_own[EXP_WPB][256];  // entry that starts at each output of the current chunk
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     uint32_t *pos = s_pos[wave];
     float *t0s = s_t0[wave];
     int32_t *slot = s_own[wave];
     const int64_t n_batches = ceil_div64(n_rays, EXP_RPW);
-    for (int64_t batch = (int64_t)blockIdx.x * 4 + wave; batch < n_batches; batch += (int64_t)gridDim.x * 4) {
+    for (int64_t batch = (int64_t)blockIdx.x * EXP_WPB + wave; batch < n_batches; batch += (int64_t)gridDim.x * EXP_WPB) {
         const int64_t r0 = batch * EXP_RPW;
         const int64_t ray = r0 + lane;
         const bool own = lane < EXP_RPW && ray < n_rays;
@@ -549,23 +553,23 @@ __global__ __launch_bounds__(256) void expand_runs_kernel(int64_t n_rays, float 
 // then the end t_first + m * inc of each of its samples.  is_right is false exactly at chain starts, is_left
 // is false exactly before a chain start (or the end of the ray's edges).  Same batch / chunk structure as
 // expand_runs_kernel; one lane per ray stages that ray's records (it needs the running count of chain starts).
-__global__ __launch_bounds__(256) void expand_intervals_kernel(int64_t n_rays, float dt, const int32_t *__restrict__ run_cnts,
+__global__ __launch_bounds__(64 * EXP_WPB) void expand_intervals_kernel(int64_t n_rays, float dt, const int32_t *__restrict__ run_cnts,
                                                                const unsigned long long *__restrict__ runs, int32_t max_runs,
                                                                const longlong2 *__restrict__ iv_packed_info,
                                                                float *__restrict__ vals, int64_t *__restrict__ ray_indices,
                                                                uint8_t *__restrict__ is_left, uint8_t *__restrict__ is_right, int vec)
 {
-    __shared__ uint32_t s_pos[4][EXP_QMAX];
-    __shared__ float s_t0[4][EXP_QMAX];
-    __shared__ uint8_t s_cont[4][EXP_QMAX];
-    __shared__ __attribute__((aligned(16))) int32_t s_own[4][256 + 4];  // + look-ahead slot for the chunk's last edge
+    __shared__ uint32_t s_pos[EXP_WPB][EXP_QMAX];
+    __shared__ float s_t0[EXP_WPB][EXP_QMAX];
+    __shared__ uint8_t s_cont[EXP_WPB][EXP_QMAX];
+    __shared__ __attribute__((aligned(16))) int32_t s_own[EXP_WPB][256 + 4];  // + look-ahead slot for the chunk's last edge
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     uint32_t *pos = s_pos[wave];
     float *t0s = s_t0[wave];
     uint8_t *conts = s_cont[wave];
     int32_t *slot = s_own[wave];
     const int64_t n_batches = ceil_div64(n_rays, EXP_RPW);
-    for (int64_t batch = (int64_t)blockIdx.x * 4 + wave; batch < n_batches; batch += (int64_t)gridDim.x * 4) {
+    for (int64_t batch = (int64_t)blockIdx.x * EXP_WPB + wave; batch < n_batches; batch += (int64_t)gridDim.x * EXP_WPB) {
         const int64_t r0 = batch * EXP_RPW;
         const int64_t ray = r0 + lane;
         const bool mine = lane < EXP_RPW && ray < n_rays;
@@ -797,13 +801,13 @@ int nfa_expand_runs(int64_t n_rays, float step_size, const int32_t *run_cnts, co
     NFA_REQUIRE(step_size > 0.0f, "expand_runs: step_size must be > 0");
     const int vec = ((reinterpret_cast<uintptr_t>(t_starts) | reinterpret_cast<uintptr_t>(t_ends) |
                       reinterpret_cast<uintptr_t>(t_mids) | reinterpret_cast<uintptr_t>(ray_indices)) & 15) == 0;
-    const unsigned grid = grid_1d(ceil_div64(n_rays, EXP_RPW) * 64, 256, 1 << 20);
+    const unsigned grid = grid_1d(ceil_div64(n_rays, EXP_RPW) * 64, 64 * EXP_WPB, 1 << 22);
     if (t_mids)
-        hipLaunchKernelGGL(expand_runs_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), n_rays, step_size, run_cnts,
+        hipLaunchKernelGGL(expand_runs_kernel<true>, dim3(grid), dim3(64 * EXP_WPB), 0, as_stream(stream), n_rays, step_size, run_cnts,
                            reinterpret_cast<const unsigned long long *>(runs), max_runs,
                            reinterpret_cast<const longlong2 *>(packed_info), t_starts, t_ends, t_mids, ray_indices, vec);
     else
-        hipLaunchKernelGGL(expand_runs_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), n_rays, step_size, run_cnts,
+        hipLaunchKernelGGL(expand_runs_kernel<false>, dim3(grid), dim3(64 * EXP_WPB), 0, as_stream(stream), n_rays, step_size, run_cnts,
                            reinterpret_cast<const unsigned long long *>(runs), max_runs,
                            reinterpret_cast<const longlong2 *>(packed_info), t_starts, t_ends, t_mids, ray_indices, vec);
     NFA_CHECK_LAUNCH("expand_runs");
@@ -822,8 +826,8 @@ int nfa_expand_intervals(int64_t n_rays, float step_size, const int32_t *run_cnt
     NFA_REQUIRE(step_size > 0.0f, "expand_intervals: step_size must be > 0");
     const int vec = ((reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(ray_indices)) & 15) == 0 &&
                     ((reinterpret_cast<uintptr_t>(is_left) | reinterpret_cast<uintptr_t>(is_right)) & 3) == 0;
-    const unsigned grid = grid_1d(ceil_div64(n_rays, EXP_RPW) * 64, 256, 1 << 20);
-    hipLaunchKernelGGL(expand_intervals_kernel, dim3(grid), dim3(256), 0, as_stream(stream), n_rays, step_size, run_cnts,
+    const unsigned grid = grid_1d(ceil_div64(n_rays, EXP_RPW) * 64, 64 * EXP_WPB, 1 << 22);
+    hipLaunchKernelGGL(expand_intervals_kernel, dim3(grid), dim3(64 * EXP_WPB), 0, as_stream(stream), n_rays, step_size, run_cnts,
                        reinterpret_cast<const unsigned long long *>(runs), max_runs,
                        reinterpret_cast<const longlong2 *>(iv_packed_info), vals, ray_indices, is_left, is_right, vec);
     NFA_CHECK_LAUNCH("expand_intervals");
