@@ -139,7 +139,9 @@ class OccGridEstimator(AbstractEstimator):
         are already resident (otherwise the side stream would wait for the very work it is meant to overlap with).
         """
         if self._prefetch_stream is None:
-            self._prefetch_stream = torch.cuda.Stream(device=rays_o.device)
+            # a high-priority stream: it comes from a different pool than ordinary streams, which makes it far less
+            # likely to share a hardware queue with the stream it is supposed to overlap with
+            self._prefetch_stream = torch.cuda.Stream(device=rays_o.device, priority=-1)
         side = self._prefetch_stream
         if wait_for_inputs:
             side.wait_stream(torch.cuda.current_stream(rays_o.device))
