@@ -129,6 +129,21 @@ NFA_HD uint32_t stepper_advance(Stepper &s, float &t, float dt, float half, floa
 {
     const uint32_t bt = f32_bits(t);
     const uint32_t e = bt >> 23;  // sign must be 0 for a jump: e in [1, 254]
+    if (!(s.aligned && e == s.q_binade) && e >= 1u && e < 254u && max_steps > 1u) {
+        // The stable increment of this binade without observing it: dt = (k + f) ulp exactly (ulp is a power of two),
+        // and every in-binade step adds RN(k + f) ulps whatever t is -- unless f == 1/2 (ties-to-even depends on t's
+        // parity for the first step; that case keeps the observation protocol below).
+        const float r = ldexpf(dt, 150 - (int)e);  // dt / ulp(t), exact (a power-of-two scaling) when finite
+        if (r >= 0.5f && r < 8388608.0f) {
+            const float k = floorf(r), f = r - k;  // exact: r < 2^23 has at least one fractional bit
+            if (f != 0.5f) {
+                s.q_stable = (uint32_t)k + (f > 0.5f ? 1u : 0u);
+                s.q_binade = e;
+                s.aligned = true;
+                s.obs_q = s.q_stable; s.obs_binade = e;
+            }
+        }
+    }
     if (s.aligned && e == s.q_binade && max_steps > 1u) {
         const uint32_t q = s.q_stable;
         const uint32_t room = (bt | 0x7FFFFFu) - bt;                 // bit patterns left in the binade (Bb - 1 - bt)
