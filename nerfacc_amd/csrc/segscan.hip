@@ -31,6 +31,9 @@
 
 namespace nfa {
 
+#ifndef NFA_SEG_OCC_HINTS
+#define NFA_SEG_OCC_HINTS 0  /* A/B on one box: 5-6 waves instead of 4-5 for the fused passes is within run-to-run noise */
+#endif
 constexpr int SEG_CHUNK = 256;  // elements per wave step (4 per lane)
 #ifndef NFA_SEG_WAVES_PER_BLOCK
 #define NFA_SEG_WAVES_PER_BLOCK 4
@@ -491,7 +494,7 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
 }
 
 template <int DIR, bool PIPE, class Op>
-__global__ __launch_bounds__(64 * SEG_WAVES_PER_BLOCK) void seg_kernel(Op op, const int64_t *__restrict__ packed_info,
+__global__ __launch_bounds__(64 * SEG_WAVES_PER_BLOCK, Op::MIN_WAVES_PER_EU) void seg_kernel(Op op, const int64_t *__restrict__ packed_info,
                                                                        const longlong2 *__restrict__ tiles,
                                                                        int64_t n_rays, int64_t n_tiles)
 {
@@ -531,6 +534,7 @@ struct OpBase1 {  // one additive channel
     static constexpr int NCHB = 0;
     static constexpr bool NEEDS_RID = false;
     static constexpr bool TOTALS = false;
+    static constexpr int MIN_WAVES_PER_EU = 1;  // occupancy floor asked of the register allocator (1 = none)
     __device__ __forceinline__ float identity(int) const { return 0.0f; }
     __device__ __forceinline__ float comb(int, float a, float b) const { return a + b; }
     __device__ __forceinline__ void ray_done(int, const float *) const {}
@@ -544,6 +548,7 @@ struct ScanOp {
     static constexpr int NCHB = 0;
     static constexpr bool NEEDS_RID = false;
     static constexpr bool TOTALS = false;
+    static constexpr int MIN_WAVES_PER_EU = 1;  // occupancy floor asked of the register allocator (1 = none)
     struct Raw { F4 x; };
     const float *in;
     float *out;
@@ -646,6 +651,7 @@ struct AlphaFwdOp {
     static constexpr int NCHB = 0;
     static constexpr bool NEEDS_RID = false;
     static constexpr bool TOTALS = false;
+    static constexpr int MIN_WAVES_PER_EU = 1;  // occupancy floor asked of the register allocator (1 = none)
     struct Raw { F4 a, pf; };
     const float *al, *prefix;
     float *w, *tr;
@@ -772,6 +778,7 @@ struct VisibilityOp {
     static constexpr int NCHB = COUNT ? 1 : 0;
     static constexpr bool NEEDS_RID = false;
     static constexpr bool TOTALS = false;
+    static constexpr int MIN_WAVES_PER_EU = 1;  // occupancy floor asked of the register allocator (1 = none)
     struct Raw { F4 s, pf, a, b; };
     const float *ts, *te, *val, *prefix;
     float eps, thre;
@@ -893,6 +900,7 @@ struct AccumOp {
     static constexpr int NCHB = 0;
     static constexpr bool NEEDS_RID = false;
     static constexpr bool TOTALS = true;
+    static constexpr int MIN_WAVES_PER_EU = 1;
     struct Raw { F4 w; float v[4][C]; };
     const float *w, *vals;  // vals may be null (C == 1): accumulate w
     int32_t D, d0;
@@ -1034,6 +1042,7 @@ struct RenderAccumOp {
     static constexpr int NCHB = 0;
     static constexpr bool NEEDS_RID = false;
     static constexpr bool TOTALS = true;
+    static constexpr int MIN_WAVES_PER_EU = 1;
     struct Raw { F4 w, a, b; float c[12]; };
     const float *w, *rgb, *ts, *te;
     float *colors, *opac, *depth;
@@ -1145,6 +1154,7 @@ struct RenderAccumBwdOp : OpBase1 {
 template <bool VEC>
 struct RenderFusedFwdOp : OpBase1 {
     static constexpr int NCHB = 5;
+    static constexpr int MIN_WAVES_PER_EU = NFA_SEG_OCC_HINTS ? 6 : 1;  // 81 VGPRs without the hint: one over the 6-wave budget
     struct Raw { F4 a, b, s; float c[12]; };
     const float *ts, *te, *sig, *rgb;
     float *w, *tr, *al, *colors, *opac, *depth;
@@ -1275,6 +1285,7 @@ struct RenderStepOp : OpBase1 {
 template <bool VEC, bool EXTRA /* gradients arrive at weights / trans / alphas too */>
 struct RenderFusedBwdOp : OpBase1 {
     static constexpr bool NEEDS_RID = true;
+    static constexpr int MIN_WAVES_PER_EU = (NFA_SEG_OCC_HINTS && !EXTRA) ? 5 : 1;  // 98 VGPRs without the hint: two over the 5-wave budget
     struct Raw { F4 a, b, T, A, gw, gt, ga; float c[12]; };
     const float *ts, *te, *rgb, *tr, *al, *gc, *go, *gd, *gw, *gt, *ga;
     float *gsig, *grgb;
