@@ -190,36 +190,20 @@ __device__ __forceinline__ void push_closed(RunState &st, float *ev_thr, int typ
     st.ev_cnt++;
 }
 
-// min of four finite-or-inf floats as two instructions (fminf's IEEE canonicalisation of signalling NaNs costs
-// three more per cell; the DDA's distances are never NaN: d == 0 axes carry this_tmax)
-__device__ __forceinline__ float min4_f32(float a, float b, float c, float d)
-{
-    float m;
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
-    asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(d));
-    return m;
-}
+// DDA state of the span being walked (setup_traversal, include/utils_grid.cuh:58-114)
+struct SpanDDA {
+    float tdist[3], delta[3], this_tmax;
+    int32_t step[3], cur[3], overflow[3];
+    int32_t lvl_brick_base, cells_left;
+};
 
-template <bool COARSE_LDS>
-__device__ __forceinline__ void runs_span(const nfa_traverse_args &a, const RunsParams &p, const uint32_t *coarse_lds,
-                                          float *ev_thr, int64_t tid, const float o[3], const float d[3],
-                                          const float inv[3], int32_t level, float this_tmin, float this_tmax,
-                                          RunState &st)
+__device__ __forceinline__ void span_setup(const nfa_traverse_args &a, const RunsParams &p, const float o[3], const float d[3],
+                                           const float inv[3], int32_t level, float this_tmin, float this_tmax, SpanDDA &sp)
 {
     const float eps = 1e-6f;
-    const float dt = a.step_size;
-    const int32_t limit = a.traverse_steps_limit;
-    // span start: the (conditional) skip to this_tmin becomes the open entry; the first cell closes it.
-    if (st.ev_cnt >= EV_MAX - 1) process_events(st, ev_thr, dt, limit, p, tid);
-    if (st.open_type != EV_NONE) push_closed(st, ev_thr, st.open_type, st.open_thr);
-    st.open_type = EV_SPAN;
-    st.open_thr = this_tmin;
-
     const float *bmin = a.aabbs + 6 * level, *bmax = bmin + 3;
-    float tdist[3], delta[3];
-    int32_t step[3], cur[3], overflow[3];
 #pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {  // setup_traversal, include/utils_grid.cuh:58-114
+    for (int ax = 0; ax < 3; ++ax) {
         const float resf = (float)a.res[ax];
         const float extent = bmax[ax] - bmin[ax];
         const float voxel = extent / resf;
@@ -232,59 +216,30 @@ __device__ __forceinline__ void runs_span(const nfa_traverse_args &a, const Runs
         const int32_t start_index = c + (d[ax] > 0.0f ? 1 : 0);
         const float tmax_ax = ((bmin[ax] + (((float)start_index * voxel) - ray_start)) * inv[ax]) + this_tmin;
         const float step_f = (d[ax] == 0.0f) ? 0.0f : (d[ax] > 0.0f ? 1.0f : -1.0f);
-        tdist[ax] = (d[ax] == 0.0f) ? this_tmax : tmax_ax;
-        step[ax] = (int32_t)step_f;
+        sp.tdist[ax] = (d[ax] == 0.0f) ? this_tmax : tmax_ax;
+        sp.step[ax] = (int32_t)step_f;
         const float delta_tmp = voxel * inv[ax] * step_f;
-        delta[ax] = (d[ax] == 0.0f) ? this_tmax : delta_tmp;
-        cur[ax] = c;
-        overflow[ax] = f + step[ax];
+        sp.delta[ax] = (d[ax] == 0.0f) ? this_tmax : delta_tmp;
+        sp.cur[ax] = c;
+        sp.overflow[ax] = f + sp.step[ax];
     }
-    const int32_t lvl_brick_base = level * p.bx * p.by * p.bz;
-    int32_t cells_left = a.res[0] + a.res[1] + a.res[2] + 3;
-
-    // Phase 1: the reference's cell loop (grid.cu:184-272) reduced to the DDA and one event per run of
-    // cells of one kind.  Straight-line predicated code, 32-bit integer ops only: the only branches are the
-    // brick reload and the loop exit (span end, or list full -> consume it and resume).  The open entry's
-    // threshold is written to slot ev_cnt on EVERY cell; the slot becomes a closed entry when the kind
-    // changes (ev_cnt advances) and is overwritten otherwise.
-    // The first cell always closes the EV_SPAN entry opened above: its kind bit is set here.
-    st.ev_span |= 1u << st.ev_cnt;
-    float *ev_col = ev_thr + threadIdx.x;
-    bool span_done = false;
-    while (!span_done) {
-        for (;;) {
-            const int32_t bid = lvl_brick_base + (int32_t)__umul24(__umul24(cur[0] >> 2, p.by) + (cur[1] >> 2), p.bz) + (cur[2] >> 2);
-            if (bid != st.brick_id) {
-                st.brick_id = bid;
-                const uint32_t cw = COARSE_LDS ? coarse_lds[bid >> 5] : p.coarse[bid >> 5];
-                const unsigned long long w = ((cw >> (bid & 31)) & 1u) ? p.bricks[bid] : 0ull;
-                st.brick_lo = (uint32_t)w; st.brick_hi = (uint32_t)(w >> 32);
-            }
-            // bit ((x&3)<<4 | (y&3)<<2 | (z&3)) of the 64-bit brick word, on 32-bit halves
-            const uint32_t half_w = (cur[0] & 2) ? st.brick_hi : st.brick_lo;
-            const int sh = ((cur[0] & 1) << 4) | ((cur[1] & 3) << 2) | (cur[2] & 3);
-            const int type = (int)((half_w >> sh) & 1u);  // EV_EMPTY / EV_OCC
-            const bool changed = type != st.open_type;
-            ev_col[st.ev_cnt * 256] = st.open_thr;
-            st.ev_occ |= (changed ? (uint32_t)(st.open_type & 1) : 0u) << st.ev_cnt;
-            st.ev_cnt += changed ? 1 : 0;
-            st.open_type = type;
-            st.open_thr = min4_f32(tdist[0], tdist[1], tdist[2], this_tmax);  // t_traverse, non-decreasing
-            // single_traversal (include/utils_grid.cuh:116-142), branch-free
-            const bool s0 = (tdist[0] < tdist[1]) && (tdist[0] < tdist[2]);
-            const bool s1 = !s0 && (tdist[1] < tdist[2]);
-            const bool s2 = !s0 && !s1;
-            cur[0] += s0 ? step[0] : 0; tdist[0] += s0 ? delta[0] : 0.0f;
-            cur[1] += s1 ? step[1] : 0; tdist[1] += s1 ? delta[1] : 0.0f;
-            cur[2] += s2 ? step[2] : 0; tdist[2] += s2 ? delta[2] : 0.0f;
-            const bool hit = (s0 && cur[0] == overflow[0]) || (s1 && cur[1] == overflow[1]) || (s2 && cur[2] == overflow[2]);
-            span_done = hit || (--cells_left <= 0);
-            if (span_done || st.ev_cnt == EV_MAX) break;
-        }
-        if (!span_done) process_events(st, ev_thr, dt, limit, p, tid);
-    }
+    sp.this_tmax = this_tmax;
+    sp.lvl_brick_base = level * p.bx * p.by * p.bz;
+    sp.cells_left = a.res[0] + a.res[1] + a.res[2] + 3;
 }
 
+// min of four finite-or-inf floats as two instructions (fminf's IEEE canonicalisation of signalling NaNs costs
+// three more per cell; the DDA's distances are never NaN: d == 0 axes carry this_tmax)
+__device__ __forceinline__ float min4_f32(float a, float b, float c, float d)
+{
+    float m;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+    asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(d));
+    return m;
+}
+
+// One ray = a loop of (phase 1: walk cells, opening the next span when one ends, until the event list is full or
+// the ray has no span left) + (phase 2: consume the list).  There is exactly ONE copy of each phase in the code.
 template <bool FUSED, bool COARSE_LDS>
 __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, const RunsParams p)
 {
@@ -295,6 +250,9 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
         for (int i = threadIdx.x; i < p.n_coarse_words; i += blockDim.x) coarse_lds[i] = p.coarse[i];
         __syncthreads();
     }
+    float *ev_col = ev_thr + threadIdx.x;
+    const float dt = a.step_size;
+    const int32_t limit = a.traverse_steps_limit;
     for (int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tid < a.n_rays;
          tid += (int64_t)blockDim.x * gridDim.x) {
         if (a.mode == 2 && a.rays_mask != nullptr && !a.rays_mask[tid]) {
@@ -313,6 +271,10 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
         st.n_samples = 0; st.n_runs = 0; st.n_chains = 0; st.open = false; st.run_cont = false; st.run_t0 = 0.f; st.run_inc = 0.f;
         st.run_n = 0; st.brick_id = -1; st.brick_lo = st.brick_hi = 0u;
         st.ev_cnt = 0; st.ev_occ = 0u; st.ev_span = 0u; st.open_type = EV_NONE; st.open_thr = 0.f;
+
+        // the ray's spans: one (slab test here) or the event walk over the sorted intersections (grid.cu:125-150)
+        float f_tmin = 0.f, f_tmax = 0.f;
+        bool f_pending = false;
         if (FUSED) {
             float tmin, tmax, lo, hi;
             bool hit = true;
@@ -330,36 +292,104 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
                 }
                 if (tmax <= 0) hit = false;
             }
-            if (hit) {
-                const float this_tmin = fmaxf(tmin, near_plane), this_tmax = fminf(tmax, far_plane);
-                if (this_tmin < this_tmax)
-                    runs_span<COARSE_LDS>(a, p, coarse_lds, ev_thr, tid, o, d, inv, 0, this_tmin, this_tmax, st);
-            }
-        } else {
-            const int32_t G = a.n_grids;
-            const uint8_t *hits = a.hits + tid * G;
-            const float *ts = a.t_sorted + tid * 2 * G;
-            const int64_t *ti = a.t_indices + tid * 2 * G;
-            for (int32_t i = 0; i < 2 * G - 1; ++i) {  // grid.cu:125-150
-                const int64_t idx = ti[i];
-                int32_t level = (int32_t)(idx % G);
-                if (!hits[level]) continue;
-                if (!(idx < G)) {
-                    const int64_t nidx = ti[i + 1];
-                    if (nidx < G) continue;
-                    level = (int32_t)(nidx % G);
-                    if (!hits[level]) continue;
+            f_tmin = fmaxf(tmin, near_plane); f_tmax = fminf(tmax, far_plane);
+            f_pending = hit && f_tmin < f_tmax;
+        }
+        const int32_t G = a.n_grids;
+        int32_t next_i = 0;  // next entry of the event walk (non-fused)
+
+        SpanDDA sp;
+        sp.this_tmax = 0.f; sp.lvl_brick_base = 0; sp.cells_left = 0;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) { sp.tdist[ax] = sp.delta[ax] = 0.f; sp.step[ax] = sp.cur[ax] = sp.overflow[ax] = 0; }
+        bool in_span = false;
+
+        for (;;) {
+            // ---------------- phase 1: the reference's cell loop (grid.cu:184-272) reduced to the DDA and one event
+            // per run of cells of one kind, straight-line predicated code, 32-bit integer ops only.  The open entry's
+            // threshold is written to slot ev_cnt on EVERY cell; the slot becomes a closed entry when the kind changes.
+            bool finished = false;
+            for (;;) {
+                if (!in_span) {
+                    if (st.ev_cnt >= EV_MAX - 1) break;  // a span start needs two entries: flush first
+                    float this_tmin = 0.f, this_tmax = 0.f;
+                    int32_t level = 0;
+                    bool found = false;
+                    if (FUSED) {
+                        found = f_pending; f_pending = false;
+                        this_tmin = f_tmin; this_tmax = f_tmax;
+                    } else {
+                        const uint8_t *hits = a.hits + tid * G;
+                        const float *ts = a.t_sorted + tid * 2 * G;
+                        const int64_t *ti = a.t_indices + tid * 2 * G;
+                        while (!found && next_i < 2 * G - 1) {
+                            const int32_t i = next_i++;
+                            const int64_t idx = ti[i];
+                            level = (int32_t)(idx % G);
+                            if (!hits[level]) continue;
+                            if (!(idx < G)) {
+                                const int64_t nidx = ti[i + 1];
+                                if (nidx < G) continue;
+                                level = (int32_t)(nidx % G);
+                                if (!hits[level]) continue;
+                            }
+                            this_tmin = fmaxf(ts[i], near_plane); this_tmax = fminf(ts[i + 1], far_plane);
+                            if (this_tmin >= this_tmax) continue;
+                            found = true;
+                        }
+                    }
+                    if (!found) { finished = true; break; }
+                    // span start: the (conditional) skip to this_tmin becomes the open entry; the first cell closes it
+                    if (st.open_type != EV_NONE) push_closed(st, ev_thr, st.open_type, st.open_thr);
+                    st.open_type = EV_SPAN;
+                    st.open_thr = this_tmin;
+                    span_setup(a, p, o, d, inv, level, this_tmin, this_tmax, sp);
+                    st.ev_span |= 1u << st.ev_cnt;  // the first cell always closes the EV_SPAN entry: its kind bit
+                    in_span = true;
                 }
-                const float this_tmin = fmaxf(ts[i], near_plane), this_tmax = fminf(ts[i + 1], far_plane);
-                if (this_tmin >= this_tmax) continue;
-                runs_span<COARSE_LDS>(a, p, coarse_lds, ev_thr, tid, o, d, inv, level, this_tmin, this_tmax, st);
+                bool span_done = false;
+                for (;;) {
+                    const int32_t bid = sp.lvl_brick_base +
+                                        (int32_t)__umul24(__umul24(sp.cur[0] >> 2, p.by) + (sp.cur[1] >> 2), p.bz) + (sp.cur[2] >> 2);
+                    if (bid != st.brick_id) {
+                        st.brick_id = bid;
+                        const uint32_t cw = COARSE_LDS ? coarse_lds[bid >> 5] : p.coarse[bid >> 5];
+                        const unsigned long long w = ((cw >> (bid & 31)) & 1u) ? p.bricks[bid] : 0ull;
+                        st.brick_lo = (uint32_t)w; st.brick_hi = (uint32_t)(w >> 32);
+                    }
+                    // bit ((x&3)<<4 | (y&3)<<2 | (z&3)) of the 64-bit brick word, on 32-bit halves
+                    const uint32_t half_w = (sp.cur[0] & 2) ? st.brick_hi : st.brick_lo;
+                    const int sh = ((sp.cur[0] & 1) << 4) | ((sp.cur[1] & 3) << 2) | (sp.cur[2] & 3);
+                    const int type = (int)((half_w >> sh) & 1u);  // EV_EMPTY / EV_OCC
+                    const bool changed = type != st.open_type;
+                    ev_col[st.ev_cnt * 256] = st.open_thr;
+                    st.ev_occ |= (changed ? (uint32_t)(st.open_type & 1) : 0u) << st.ev_cnt;
+                    st.ev_cnt += changed ? 1 : 0;
+                    st.open_type = type;
+                    st.open_thr = min4_f32(sp.tdist[0], sp.tdist[1], sp.tdist[2], sp.this_tmax);  // t_traverse, non-decreasing
+                    // single_traversal (include/utils_grid.cuh:116-142), branch-free
+                    const bool s0 = (sp.tdist[0] < sp.tdist[1]) && (sp.tdist[0] < sp.tdist[2]);
+                    const bool s1 = !s0 && (sp.tdist[1] < sp.tdist[2]);
+                    const bool s2 = !s0 && !s1;
+                    sp.cur[0] += s0 ? sp.step[0] : 0; sp.tdist[0] += s0 ? sp.delta[0] : 0.0f;
+                    sp.cur[1] += s1 ? sp.step[1] : 0; sp.tdist[1] += s1 ? sp.delta[1] : 0.0f;
+                    sp.cur[2] += s2 ? sp.step[2] : 0; sp.tdist[2] += s2 ? sp.delta[2] : 0.0f;
+                    const bool hit_end = (s0 && sp.cur[0] == sp.overflow[0]) || (s1 && sp.cur[1] == sp.overflow[1]) ||
+                                         (s2 && sp.cur[2] == sp.overflow[2]);
+                    span_done = hit_end || (--sp.cells_left <= 0);
+                    if (span_done || st.ev_cnt == EV_MAX) break;
+                }
+                if (span_done) in_span = false;
+                if (st.ev_cnt == EV_MAX) break;
             }
+            if (finished && st.open_type != EV_NONE) {
+                if (st.ev_cnt == EV_MAX) finished = false;  // no slot for the last open entry: flush and come back
+                else { push_closed(st, ev_thr, st.open_type, st.open_thr); st.open_type = EV_NONE; }
+            }
+            // ---------------- phase 2
+            process_events(st, ev_thr, dt, limit, p, tid);
+            if (finished) break;
         }
-        if (st.open_type != EV_NONE) {
-            if (st.ev_cnt == EV_MAX) process_events(st, ev_thr, a.step_size, a.traverse_steps_limit, p, tid);
-            push_closed(st, ev_thr, st.open_type, st.open_thr);
-        }
-        process_events(st, ev_thr, a.step_size, a.traverse_steps_limit, p, tid);
         close_run(st, p, tid);
         if (a.terminate_planes) a.terminate_planes[tid] = st.t_last;
         a.sm_cnts[tid] = st.n_samples;
