@@ -121,6 +121,23 @@ NFA_HD void stepper_init(Stepper &s) { s.q_stable = 0; s.q_binade = 0; s.obs_q =
 // after t has been assigned a value that is not the result of a step
 NFA_HD void stepper_reset(Stepper &s) { s.aligned = false; s.obs_binade = 0; }
 
+// The stable increment of binade e (biased exponent of a positive normal t) without observing it: dt = (k + f) ulp
+// exactly (ulp is a power of two), and every in-binade step adds RN(k + f) ulps whatever t is -- unless f == 1/2
+// (ties-to-even depends on t's parity for the first step; that case keeps the observation protocol).
+NFA_HD bool stepper_align(Stepper &s, uint32_t e, float dt)
+{
+    if (!(e >= 1u && e < 254u)) return false;
+    const float r = ldexpf(dt, 150 - (int)e);  // dt / ulp(t), exact (a power-of-two scaling) when finite
+    if (!(r >= 0.5f && r < 8388608.0f)) return false;
+    const float k = floorf(r), f = r - k;      // exact: r < 2^23 has at least one fractional bit
+    if (f == 0.5f) return false;
+    s.q_stable = (uint32_t)k + (f > 0.5f ? 1u : 0u);
+    s.q_binade = e;
+    s.aligned = true;
+    s.obs_q = s.q_stable; s.obs_binade = e;
+    return true;
+}
+
 // Precondition: t + half < thr (the serial loop would take a step).  Takes n >= 1 steps exactly as the serial
 // loop `while (t + half < thr) t += dt` would (never past the point where the condition turns false, never
 // more than max_steps >= 1), all with the same exact increment *inc, and returns n; returns 0 (t unchanged)
@@ -129,21 +146,7 @@ NFA_HD uint32_t stepper_advance(Stepper &s, float &t, float dt, float half, floa
 {
     const uint32_t bt = f32_bits(t);
     const uint32_t e = bt >> 23;  // sign must be 0 for a jump: e in [1, 254]
-    if (!(s.aligned && e == s.q_binade) && e >= 1u && e < 254u && max_steps > 1u) {
-        // The stable increment of this binade without observing it: dt = (k + f) ulp exactly (ulp is a power of two),
-        // and every in-binade step adds RN(k + f) ulps whatever t is -- unless f == 1/2 (ties-to-even depends on t's
-        // parity for the first step; that case keeps the observation protocol below).
-        const float r = ldexpf(dt, 150 - (int)e);  // dt / ulp(t), exact (a power-of-two scaling) when finite
-        if (r >= 0.5f && r < 8388608.0f) {
-            const float k = floorf(r), f = r - k;  // exact: r < 2^23 has at least one fractional bit
-            if (f != 0.5f) {
-                s.q_stable = (uint32_t)k + (f > 0.5f ? 1u : 0u);
-                s.q_binade = e;
-                s.aligned = true;
-                s.obs_q = s.q_stable; s.obs_binade = e;
-            }
-        }
-    }
+    if (!(s.aligned && e == s.q_binade) && max_steps > 1u) stepper_align(s, e, dt);
     if (s.aligned && e == s.q_binade && max_steps > 1u) {
         const uint32_t q = s.q_stable;
         const uint32_t room = (bt | 0x7FFFFFu) - bt;                 // bit patterns left in the binade (Bb - 1 - bt)
@@ -256,6 +259,68 @@ NFA_HD void approach_table_apply(const ApproachTable &tb, Stepper &s, float &t, 
             return;
         }
     }
+}
+
+// The whole march of one event in one shot, straight-line code for the cases that make up > 99.9 % of the events of a
+// ray: t inside a binade whose stable increment is known (or computable), the threshold reached inside this binade
+// or inside the next one (one binade boundary crossed).  On success (true) t has advanced by the steps listed in
+// segs[0..*n_seg) -- n steps from t0 with exact increment inc each -- and the loop condition is known to be FALSE at
+// the new t; on false NOTHING has changed and the general loop has to do the event (exact ties, a sample budget,
+// denormal / huge t, thresholds sitting exactly at a binade end, estimates that were no upper bound).
+// Same principle as the jump of stepper_advance: fp32 estimates, then the condition is evaluated on the actual floats.
+struct StepSeg { float t0, inc; uint32_t n; };
+
+NFA_HD bool stepper_run_event(Stepper &s, float &t, float dt, float half, float thr, StepSeg segs[3], int *n_seg)
+{
+    Stepper ls = s;
+    float lt = t;
+    int ns = 0;
+    bool done = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int stage = 0; stage < 2 && !done; ++stage) {
+        const uint32_t bt = f32_bits(lt), e = bt >> 23;
+        if (!(ls.aligned && e == ls.q_binade) && !stepper_align(ls, e, dt)) return false;
+        if (!(lt + half < thr)) { done = true; break; }
+        const uint32_t q = ls.q_stable, room = (bt | 0x7FFFFFu) - bt;
+        if (q <= room) {
+            const float step_val = bits_f32(bt + q) - lt;
+            const float est = ((thr - half) - lt) * NFA_RCP(step_val);
+            const uint32_t n0 = est < 4194304.0f ? (uint32_t)fmaxf(est, 0.0f) + 2u : 0x400002u;
+            if ((float)n0 * (float)q < (float)room) {
+                // threshold inside this binade: largest m in [1, n0] with cond(m - 1); cond(0) holds
+                uint32_t m = n0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+                for (int i = 0; i < 4; ++i)
+                    if (m > 1u && !(bits_f32(bt + (m - 1u) * q) + half < thr)) m--;
+                if (m > 1u && !(bits_f32(bt + (m - 1u) * q) + half < thr)) return false;  // four probes were not enough
+                if (m == n0) return false;  // the estimate was no upper bound
+                segs[ns].t0 = lt; segs[ns].inc = step_val; segs[ns].n = m; ns++;
+                lt = bits_f32(bt + m * q);  // cond(m - 1) true, cond(m) false (that probe failed)
+                done = true;
+                break;
+            }
+            // threshold at or beyond the binade's end: all the steps that stay inside it
+            uint32_t n_b = (uint32_t)((float)room / (float)q);  // both < 2^24: off by at most one
+            if (n_b * q > room) n_b--;
+            if (!(bits_f32(bt + (n_b - 1u) * q) + half < thr)) return false;  // it sits right at the end: general loop
+            segs[ns].t0 = lt; segs[ns].inc = step_val; segs[ns].n = n_b; ns++;
+            lt = bits_f32(bt + n_b * q);
+        }
+        if (stage == 1) return false;  // a second binade end inside one event
+        if (!(lt + half < thr)) { done = true; break; }
+        const float tn = lt + dt;      // the step across the boundary (its increment is its own)
+        if (tn == lt || (f32_bits(tn) >> 23) == e) return false;
+        segs[ns].t0 = lt; segs[ns].inc = tn - lt; segs[ns].n = 1u; ns++;
+        ls.aligned = false; ls.obs_binade = 0;
+        lt = tn;
+    }
+    if (!done) return false;
+    s = ls; t = lt; *n_seg = ns;
+    return true;
 }
 
 // fast_forward_serial through the stepper (one-shot state): used by tests and by the serial traversal

@@ -124,6 +124,20 @@ __device__ __forceinline__ void close_run(RunState &st, const RunsParams &p, int
     st.open = false;
 }
 
+// n samples t, t + inc, ... (exact sums) join the ray's run list
+__device__ __forceinline__ void emit_steps(RunState &st, float t, float inc, uint32_t n, const RunsParams &p, int64_t tid)
+{
+    if (st.open && st.continuous && inc == st.run_inc) {
+        st.run_n += (int32_t)n;
+    } else {
+        close_run(st, p, tid);
+        st.open = true; st.run_t0 = t; st.run_inc = inc; st.run_n = (int32_t)n; st.run_cont = st.continuous;
+        st.n_chains += st.continuous ? 0 : 1;
+    }
+    st.n_samples += (int32_t)n;
+    st.continuous = true;
+}
+
 // Advance t_last while the step's mid-point is before `thr`; with `emit` every step is a sample
 // and is appended to the ray's run list.  march.h's Stepper does the arithmetic: one exact jump per
 // binade (the stable increment is remembered across the marches of a ray), plus the sample budget of
@@ -149,17 +163,7 @@ __device__ __forceinline__ void march(RunState &st, float thr, float dt, float h
             if (!emit) { st.t_last = thr; stepper_reset(st.stp); }
             return;
         }
-        if (emit) {  // n samples t, t + inc, ... (exact sums)
-            if (st.open && st.continuous && inc == st.run_inc) {
-                st.run_n += (int32_t)n;
-            } else {
-                close_run(st, p, tid);
-                st.open = true; st.run_t0 = t; st.run_inc = inc; st.run_n = (int32_t)n; st.run_cont = st.continuous;
-                st.n_chains += st.continuous ? 0 : 1;
-            }
-            st.n_samples += (int32_t)n;
-            st.continuous = true;
-        }
+        if (emit) emit_steps(st, t, inc, n, p, tid);
         st.t_last = tn;
     }
 }
@@ -175,7 +179,24 @@ __device__ __forceinline__ void process_events(RunState &st, const float *ev_thr
         const float thr = ev_thr[k * 256 + threadIdx.x];
         if (limit > 0 && st.n_samples >= limit) break;  // grid.cu:184: nothing moves once the limit is hit
         if (type == EV_SPAN && st.continuous) continue;
-        march(st, thr, dt, half, type == EV_OCC, limit, p, tid);
+        // common case in one shot (aligned inside the binade, threshold well before its end, no sample budget);
+        // everything else -- and the rare under-estimate -- goes through the general loop
+        bool handled = false;
+        if (limit <= 0 && !st.at_near) {
+            float t = st.t_last;
+            StepSeg segs[3];
+            int n_seg = 0;
+            if (stepper_run_event(st.stp, t, dt, half, thr, segs, &n_seg)) {
+                if (type == EV_OCC) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        if (i < n_seg) emit_steps(st, segs[i].t0, segs[i].inc, segs[i].n, p, tid);
+                }
+                st.t_last = t;
+                handled = true;
+            }
+        }
+        if (!handled) march(st, thr, dt, half, type == EV_OCC, limit, p, tid);
         if (type == EV_EMPTY) st.continuous = false;
     }
     st.ev_cnt = 0;

@@ -42,7 +42,7 @@ extern "C" int approach_calls(float t0, float dt, float thr, int use_table, floa
 // the step's mid-point is before thr; budget of `limit` samples).  Serial reference vs Stepper + run records
 // expanded with one fused multiply-add per value (what expand_runs_kernel does).
 // Returns the number of samples; out_* hold (ts, te) of both versions; t_last[2] the final positions.
-extern "C" long ray_events(float t0, float dt, const float* thr, const int* emit, long n_ev, int limit, int use_table, long cap,
+extern "C" long ray_events(float t0, float dt, const float* thr, const int* emit, long n_ev, int limit, int use_table, int lean, long cap,
                            float* ts_a, float* te_a, float* ts_b, float* te_b, float* t_last, long* n_b_out, long* n_jumps) {
     const float half = dt * 0.5f;
     // ---- serial
@@ -73,6 +73,22 @@ extern "C" long ray_events(float t0, float dt, const float* thr, const int* emit
         bool open = false, continuous = false, at_near = true;
         for (long k = 0; k < n_ev; ++k) {
             if (limit > 0 && nb >= limit) break;
+            if (lean && limit <= 0 && !at_near) {   // the one-shot path of process_events (traverse2.hip)
+                float tt = t; nfa::StepSeg segs[3]; int n_seg = 0;
+                if (nfa::stepper_run_event(s, tt, dt, half, thr[k], segs, &n_seg)) {
+                    for (int i = 0; i < n_seg; ++i) {
+                        if (emit[k]) {
+                            if (open && continuous && segs[i].inc == runs.back().inc) runs.back().n += segs[i].n;
+                            else { runs.push_back({segs[i].t0, segs[i].inc, (long)segs[i].n}); open = true; }
+                            nb += segs[i].n; continuous = true;
+                        }
+                        if (segs[i].n > 1) jumps++;
+                    }
+                    t = tt;
+                    if (!emit[k]) continuous = false;
+                    continue;
+                }
+            }
             if (at_near) { at_near = false; if (!emit[k]) nfa::approach_table_apply(tb, s, t, half, thr[k]); }
             for (;;) {
                 if (!(t + half < thr[k])) break;
@@ -212,7 +228,7 @@ def test_stepper_matches_serial(tmp_path):
             thr += np.float32(rng.random() * 6)      # grid far from the near plane: the approach table's case
             emit[0] = 0
         na = lib.ray_events(C.c_float(float(t0)), C.c_float(float(dtv)), thr.ctypes.data_as(C.c_void_p),
-                            emit.ctypes.data_as(C.c_void_p), C.c_long(n_ev), C.c_int(limit), C.c_int(case % 3), C.c_long(cap),
+                            emit.ctypes.data_as(C.c_void_p), C.c_long(n_ev), C.c_int(limit), C.c_int(case % 3), C.c_int((case // 3) % 2), C.c_long(cap),
                             *[b.ctypes.data_as(C.c_void_p) for b in bufs], tl.ctypes.data_as(C.c_void_p),
                             C.byref(nb), C.byref(nj))
         assert na == nb.value, (case, na, nb.value)
