@@ -264,62 +264,68 @@ NFA_HD void approach_table_apply(const ApproachTable &tb, Stepper &s, float &t, 
 // The whole march of one event in one shot, straight-line code for the cases that make up > 99.9 % of the events of a
 // ray: t inside a binade whose stable increment is known (or computable), the threshold reached inside this binade
 // or inside the next one (one binade boundary crossed).  On success (true) t has advanced by the steps listed in
-// segs[0..*n_seg) -- n steps from t0 with exact increment inc each -- and the loop condition is known to be FALSE at
+// seg0 / seg1 / seg2 -- n (possibly 0) steps from t0 with exact increment inc each -- and the loop condition is known to be FALSE at
 // the new t; on false NOTHING has changed and the general loop has to do the event (exact ties, a sample budget,
 // denormal / huge t, thresholds sitting exactly at a binade end, estimates that were no upper bound).
 // Same principle as the jump of stepper_advance: fp32 estimates, then the condition is evaluated on the actual floats.
 struct StepSeg { float t0, inc; uint32_t n; };
 
-NFA_HD bool stepper_run_event(Stepper &s, float &t, float dt, float half, float thr, StepSeg segs[3], int *n_seg)
+// One binade of stepper_run_event.  Returns 0: the event is finished (condition false at lt), 1: lt stands on the last
+// point of the binade and the condition still holds, 2: give up (the general loop does the event).
+NFA_HD int stepper_event_stage(Stepper &ls, float &lt, float dt, float half, float thr, StepSeg &seg)
 {
+    const uint32_t bt = f32_bits(lt), e = bt >> 23;
+    if (!(ls.aligned && e == ls.q_binade) && !stepper_align(ls, e, dt)) return 2;
+    if (!(lt + half < thr)) return 0;
+    const uint32_t q = ls.q_stable, room = (bt | 0x7FFFFFu) - bt;
+    if (q > room) return 1;
+    const float step_val = bits_f32(bt + q) - lt;
+    const float est = ((thr - half) - lt) * NFA_RCP(step_val);
+    const uint32_t n0 = est < 4194304.0f ? (uint32_t)fmaxf(est, 0.0f) + 2u : 0x400002u;
+    if ((float)n0 * (float)q < (float)room) {
+        // threshold inside this binade: largest m in [1, n0] with cond(m - 1); cond(0) holds
+        uint32_t m = n0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int i = 0; i < 4; ++i)
+            if (m > 1u && !(bits_f32(bt + (m - 1u) * q) + half < thr)) m--;
+        if (m > 1u && !(bits_f32(bt + (m - 1u) * q) + half < thr)) return 2;  // four probes were not enough
+        if (m == n0) return 2;  // the estimate was no upper bound
+        seg.t0 = lt; seg.inc = step_val; seg.n = m;
+        lt = bits_f32(bt + m * q);  // cond(m - 1) true, cond(m) false (that probe failed)
+        return 0;
+    }
+    // threshold at or beyond the binade's end: all the steps that stay inside it
+    uint32_t n_b = (uint32_t)((float)room / (float)q);  // both < 2^24: off by at most one
+    if (n_b * q > room) n_b--;
+    if (!(bits_f32(bt + (n_b - 1u) * q) + half < thr)) return 2;  // it sits right at the end: general loop
+    seg.t0 = lt; seg.inc = step_val; seg.n = n_b;
+    lt = bits_f32(bt + n_b * q);
+    return (lt + half < thr) ? 1 : 0;
+}
+
+NFA_HD bool stepper_run_event(Stepper &s, float &t, float dt, float half, float thr, StepSeg &seg0, StepSeg &seg1, StepSeg &seg2)
+{
+    // seg0: steps inside the first binade, seg1: the step across its end, seg2: steps inside the next binade (n == 0: none)
     Stepper ls = s;
     float lt = t;
-    int ns = 0;
-    bool done = false;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int stage = 0; stage < 2 && !done; ++stage) {
-        const uint32_t bt = f32_bits(lt), e = bt >> 23;
-        if (!(ls.aligned && e == ls.q_binade) && !stepper_align(ls, e, dt)) return false;
-        if (!(lt + half < thr)) { done = true; break; }
-        const uint32_t q = ls.q_stable, room = (bt | 0x7FFFFFu) - bt;
-        if (q <= room) {
-            const float step_val = bits_f32(bt + q) - lt;
-            const float est = ((thr - half) - lt) * NFA_RCP(step_val);
-            const uint32_t n0 = est < 4194304.0f ? (uint32_t)fmaxf(est, 0.0f) + 2u : 0x400002u;
-            if ((float)n0 * (float)q < (float)room) {
-                // threshold inside this binade: largest m in [1, n0] with cond(m - 1); cond(0) holds
-                uint32_t m = n0;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-                for (int i = 0; i < 4; ++i)
-                    if (m > 1u && !(bits_f32(bt + (m - 1u) * q) + half < thr)) m--;
-                if (m > 1u && !(bits_f32(bt + (m - 1u) * q) + half < thr)) return false;  // four probes were not enough
-                if (m == n0) return false;  // the estimate was no upper bound
-                segs[ns].t0 = lt; segs[ns].inc = step_val; segs[ns].n = m; ns++;
-                lt = bits_f32(bt + m * q);  // cond(m - 1) true, cond(m) false (that probe failed)
-                done = true;
-                break;
-            }
-            // threshold at or beyond the binade's end: all the steps that stay inside it
-            uint32_t n_b = (uint32_t)((float)room / (float)q);  // both < 2^24: off by at most one
-            if (n_b * q > room) n_b--;
-            if (!(bits_f32(bt + (n_b - 1u) * q) + half < thr)) return false;  // it sits right at the end: general loop
-            segs[ns].t0 = lt; segs[ns].inc = step_val; segs[ns].n = n_b; ns++;
-            lt = bits_f32(bt + n_b * q);
-        }
-        if (stage == 1) return false;  // a second binade end inside one event
-        if (!(lt + half < thr)) { done = true; break; }
-        const float tn = lt + dt;      // the step across the boundary (its increment is its own)
+    seg0.n = seg1.n = seg2.n = 0u;
+    seg0.t0 = seg1.t0 = seg2.t0 = 0.0f;
+    seg0.inc = seg1.inc = seg2.inc = 0.0f;
+    int r = stepper_event_stage(ls, lt, dt, half, thr, seg0);
+    if (r == 2) return false;
+    if (r == 1) {
+        const uint32_t e = f32_bits(lt) >> 23;
+        const float tn = lt + dt;  // the step across the boundary (its increment is its own)
         if (tn == lt || (f32_bits(tn) >> 23) == e) return false;
-        segs[ns].t0 = lt; segs[ns].inc = tn - lt; segs[ns].n = 1u; ns++;
+        seg1.t0 = lt; seg1.inc = tn - lt; seg1.n = 1u;
         ls.aligned = false; ls.obs_binade = 0;
         lt = tn;
+        r = stepper_event_stage(ls, lt, dt, half, thr, seg2);
+        if (r != 0) return false;  // a second binade end inside one event, or give up
     }
-    if (!done) return false;
-    s = ls; t = lt; *n_seg = ns;
+    s = ls; t = lt;
     return true;
 }
 

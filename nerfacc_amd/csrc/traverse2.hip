@@ -184,13 +184,12 @@ __device__ __forceinline__ void process_events(RunState &st, const float *ev_thr
         bool handled = false;
         if (limit <= 0 && !st.at_near) {
             float t = st.t_last;
-            StepSeg segs[3];
-            int n_seg = 0;
-            if (stepper_run_event(st.stp, t, dt, half, thr, segs, &n_seg)) {
+            StepSeg g0, g1, g2;
+            if (stepper_run_event(st.stp, t, dt, half, thr, g0, g1, g2)) {
                 if (type == EV_OCC) {
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-                        if (i < n_seg) emit_steps(st, segs[i].t0, segs[i].inc, segs[i].n, p, tid);
+                    if (g0.n > 0u) emit_steps(st, g0.t0, g0.inc, g0.n, p, tid);
+                    if (g1.n > 0u) emit_steps(st, g1.t0, g1.inc, g1.n, p, tid);
+                    if (g2.n > 0u) emit_steps(st, g2.t0, g2.inc, g2.n, p, tid);
                 }
                 st.t_last = t;
                 handled = true;

@@ -74,9 +74,10 @@ extern "C" long ray_events(float t0, float dt, const float* thr, const int* emit
         for (long k = 0; k < n_ev; ++k) {
             if (limit > 0 && nb >= limit) break;
             if (lean && limit <= 0 && !at_near) {   // the one-shot path of process_events (traverse2.hip)
-                float tt = t; nfa::StepSeg segs[3]; int n_seg = 0;
-                if (nfa::stepper_run_event(s, tt, dt, half, thr[k], segs, &n_seg)) {
-                    for (int i = 0; i < n_seg; ++i) {
+                float tt = t; nfa::StepSeg segs[3];
+                if (nfa::stepper_run_event(s, tt, dt, half, thr[k], segs[0], segs[1], segs[2])) {
+                    for (int i = 0; i < 3; ++i) {
+                        if (segs[i].n == 0) continue;
                         if (emit[k]) {
                             if (open && continuous && segs[i].inc == runs.back().inc) runs.back().n += segs[i].n;
                             else { runs.push_back({segs[i].t0, segs[i].inc, (long)segs[i].n}); open = true; }
