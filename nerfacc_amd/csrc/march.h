@@ -297,8 +297,9 @@ NFA_HD int stepper_event_stage(Stepper &ls, float &lt, float dt, float half, flo
         return 0;
     }
     // threshold at or beyond the binade's end: all the steps that stay inside it
-    uint32_t n_b = (uint32_t)((float)room / (float)q);  // both < 2^24: off by at most one
-    if (n_b * q > room) n_b--;
+    uint32_t n_b = (uint32_t)((float)room * NFA_RCP((float)q));  // floor(room / q), estimated with a 1-ulp reciprocal and corrected
+    while (n_b * q > room) n_b--;             // (at most two corrections either way: relative error of the
+    while ((n_b + 1u) * q <= room) n_b++;     //  estimate < 3e-7, quotient < 2^23)
     if (!(bits_f32(bt + (n_b - 1u) * q) + half < thr)) return 2;  // it sits right at the end: general loop
     seg.t0 = lt; seg.inc = step_val; seg.n = n_b;
     lt = bits_f32(bt + n_b * q);
