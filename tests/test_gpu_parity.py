@@ -5,6 +5,8 @@ reference's own tests -- against torch on equal-length chunks.
 Bars (BASELINE.json north_star): bit-exact for ray_indices / packed_info / masks / sample
 positions; <= 1e-5 (relative to magnitude) for fp32 weights, transmittance, colours.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -305,7 +307,7 @@ def test_rendering_fused_pass_is_bit_identical_to_two_passes(dev, oracle):
     """The one-pass rendering (stage-A transmittance scan + stage-B accumulation scan, and the reverse pass
     that needs the ray id before its scan) against the two-pass composition, many tiles, ragged + empty rays,
     with gradients arriving at colours / opacity / depth AND at extras' weights / trans / alphas."""
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(int(os.environ.get("NFA_FUZZ_SEED", "11")))
     cnts = rng.integers(0, 90, size=5000)
     cnts[rng.integers(0, 5000, size=40)] = 0
     cnts[17], cnts[4000] = 3001, 1500
@@ -711,8 +713,8 @@ def test_traversal_fuzz_bit_exact(dev, oracle):
     from a fraction of a cell to several cells, rays from inside and outside with zero direction components,
     per-ray near / far planes, sample budgets; API traverse_grids (intervals + samples), the sampler's direct
     path and the test-mode (mask + limit) path."""
-    rng = np.random.default_rng(2024)
-    n_cases = 24
+    rng = np.random.default_rng(int(os.environ.get("NFA_FUZZ_SEED", "2024")))   # NFA_FUZZ_SEED: soak runs with other seeds
+    n_cases = int(os.environ.get("NFA_FUZZ_CASES", "24"))
     for case in range(n_cases):
         res = [int(rng.choice([8, 16, 24, 30, 50])) for _ in range(3)] if case % 3 else [int(rng.choice([16, 32]))] * 3
         levels = int(rng.integers(1, 4))
