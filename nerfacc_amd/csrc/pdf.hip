@@ -205,6 +205,79 @@ __global__ __launch_bounds__(256) void searchsorted_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Interlevel ("proposal") loss of Mip-NeRF 360 for batched rays, forward and backward, one kernel each
+// (ref: estimators/prop_net.py:232-256 = searchsorted + two gathers + five elementwise ops, and their autograd
+// backward = two scatter_adds + ~10 elementwise ops):
+//     l_j = max(w_j - wo_j, 0)^2 / (w_j + eps),  w_j = cq[j+1] - cq[j],  wo_j = ck[right_j] - ck[left_j],
+//     left_j = clamp(upper_bound(kv, qv[j]) - 1), right_j = clamp(upper_bound(kv, qv[j+1]))
+// L lanes per ray (power of two), key rows staged in LDS; the backward accumulates a ray's key-CDF gradient row
+// in LDS (only the ray's own lane group touches it) and writes it once.
+constexpr int PL_STAGE_MAX = 1024;  // key entries (vals + cdfs [+ grad row]) a wave may stage
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void pdf_loss_kernel(const float *__restrict__ q_vals, const float *__restrict__ q_cdfs,
+                                                       const float *__restrict__ k_vals, const float *__restrict__ k_cdfs,
+                                                       int64_t n_rays, int Q1, int K1, int L, float eps,
+                                                       float *__restrict__ loss, const float *__restrict__ g_loss,
+                                                       float *__restrict__ g_k_cdfs, float *__restrict__ g_q_cdfs)
+{
+    __shared__ float s_kv[4][PL_STAGE_MAX];
+    __shared__ float s_kc[4][PL_STAGE_MAX];
+    __shared__ float s_g[4][BWD ? PL_STAGE_MAX : 1];
+    __shared__ float s_gq[4][BWD ? PL_STAGE_MAX : 1];
+    const int lane = lane_id(), gl = lane & (L - 1), rpw = 64 / L, Q = Q1 - 1;
+    float *kv = s_kv[threadIdx.x >> 6], *kc = s_kc[threadIdx.x >> 6], *gk = s_g[threadIdx.x >> 6], *gq = s_gq[threadIdx.x >> 6];
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r0 = wave * rpw; r0 < n_rays; r0 += n_waves * rpw) {
+        const int n_here = (int)min((int64_t)rpw, n_rays - r0);
+        __builtin_amdgcn_wave_barrier();
+        for (int f = lane; f < n_here * K1; f += 64) {
+            kv[f] = k_vals[r0 * K1 + f]; kc[f] = k_cdfs[r0 * K1 + f];
+            if (BWD) gk[f] = 0.0f;
+        }
+        if (BWD && g_q_cdfs) for (int f = lane; f < n_here * Q1; f += 64) gq[f] = 0.0f;
+        __builtin_amdgcn_wave_barrier();
+        const int slot = lane / L;
+        const int64_t ray = r0 + slot;
+        if (ray < n_rays) {
+            const int kb = slot * K1, kl = kb + K1 - 1;
+            const float *qv = q_vals + ray * Q1, *qc = q_cdfs + ray * Q1;
+            for (int j = gl; j < Q; j += L) {
+                const int pl = upper_bound_lds(kv, kb, kl, qv[j]);
+                const int pr = upper_bound_lds(kv, kb, kl, qv[j + 1]);
+                const int left = min(max(pl - 1, kb), kl), right = min(max(pr, kb), kl);
+                const float w = qc[j + 1] - qc[j];
+                const float wo = kc[right] - kc[left];
+                const float d = fmaxf(w - wo, 0.0f);
+                if (!BWD) {
+                    loss[ray * Q + j] = (d * d) / (w + eps);
+                } else {
+                    const float g = g_loss[ray * Q + j];
+                    // d l / d wo = -2 d / (w + eps);  d l / d w = 2 d / (w + eps) - d^2 / (w + eps)^2   (d > 0)
+                    const float inv = 1.0f / (w + eps);
+                    const float gwo = -2.0f * d * inv * g;
+                    if (d > 0.0f) {
+                        atomicAdd(&gk[right], gwo);
+                        atomicAdd(&gk[left], -gwo);
+                        if (g_q_cdfs) {
+                            const float gw = (2.0f * d * inv - d * d * inv * inv) * g;
+                            atomicAdd(&gq[slot * Q1 + j + 1], gw);
+                            atomicAdd(&gq[slot * Q1 + j], -gw);
+                        }
+                    }
+                }
+            }
+        }
+        if (BWD) {
+            __builtin_amdgcn_wave_barrier();
+            for (int f = lane; f < n_here * K1; f += 64) g_k_cdfs[r0 * K1 + f] = gk[f];
+            if (g_q_cdfs) for (int f = lane; f < n_here * Q1; f += 64) g_q_cdfs[r0 * Q1 + f] = gq[f];
+        }
+    }
+}
+
 }  // namespace nfa
 
 using namespace nfa;
@@ -258,6 +331,45 @@ int nfa_searchsorted(const float *q_vals, const int64_t *q_packed_info, const in
                            q_packed_info, q_ray_indices, q_n_rays, q_per_ray, q_total, k_vals, k_packed_info, k_per_ray,
                            ids_left, ids_right);
     NFA_CHECK_LAUNCH("searchsorted");
+    return NFA_OK;
+}
+
+static int pdf_loss_lanes(int Q, int K1, int Q1)
+{
+    int L = 2;
+    while (L < 64 && L < Q) L <<= 1;
+    while (L < 64 && (64 / L) * (K1 > Q1 ? K1 : Q1) > PL_STAGE_MAX) L <<= 1;  // fewer rays per wave until the rows fit
+    return L;
+}
+
+int nfa_pdf_loss_fwd(const float *q_vals, const float *q_cdfs, const float *k_vals, const float *k_cdfs, int64_t n_rays,
+                     int32_t n_query_edges, int32_t n_key_edges, float eps, float *loss, nfa_stream_t stream)
+{
+    NFA_REQUIRE(n_rays >= 0 && n_query_edges >= 2 && n_key_edges >= 1, "pdf_loss_fwd: bad sizes");
+    NFA_REQUIRE(n_key_edges <= PL_STAGE_MAX && n_query_edges <= PL_STAGE_MAX, "pdf_loss_fwd: rows longer than 1024 edges are not supported");
+    if (n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(q_vals && q_cdfs && k_vals && k_cdfs && loss, "pdf_loss_fwd: null pointer");
+    const int L = pdf_loss_lanes(n_query_edges - 1, n_key_edges, n_query_edges);
+    const unsigned grid = grid_1d(ceil_div64(n_rays, 64 / L) * 64, 256, 1 << 16);
+    hipLaunchKernelGGL(pdf_loss_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), q_vals, q_cdfs, k_vals, k_cdfs,
+                       n_rays, (int)n_query_edges, (int)n_key_edges, L, eps, loss, nullptr, nullptr, nullptr);
+    NFA_CHECK_LAUNCH("pdf_loss_fwd");
+    return NFA_OK;
+}
+
+int nfa_pdf_loss_bwd(const float *q_vals, const float *q_cdfs, const float *k_vals, const float *k_cdfs, int64_t n_rays,
+                     int32_t n_query_edges, int32_t n_key_edges, float eps, const float *g_loss, float *g_k_cdfs,
+                     float *g_q_cdfs, nfa_stream_t stream)
+{
+    NFA_REQUIRE(n_rays >= 0 && n_query_edges >= 2 && n_key_edges >= 1, "pdf_loss_bwd: bad sizes");
+    NFA_REQUIRE(n_key_edges <= PL_STAGE_MAX && n_query_edges <= PL_STAGE_MAX, "pdf_loss_bwd: rows longer than 1024 edges are not supported");
+    if (n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(q_vals && q_cdfs && k_vals && k_cdfs && g_loss && g_k_cdfs, "pdf_loss_bwd: null pointer");
+    const int L = pdf_loss_lanes(n_query_edges - 1, n_key_edges, n_query_edges);
+    const unsigned grid = grid_1d(ceil_div64(n_rays, 64 / L) * 64, 256, 1 << 16);
+    hipLaunchKernelGGL(pdf_loss_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), q_vals, q_cdfs, k_vals, k_cdfs,
+                       n_rays, (int)n_query_edges, (int)n_key_edges, L, eps, nullptr, g_loss, g_k_cdfs, g_q_cdfs);
+    NFA_CHECK_LAUNCH("pdf_loss_bwd");
     return NFA_OK;
 }
 

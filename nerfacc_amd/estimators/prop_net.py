@@ -15,7 +15,9 @@ except ImportError:  # pragma: no cover
 
 import torch
 from torch import Tensor
+from torch.autograd.function import once_differentiable
 
+from .. import _backend as B
 from ..data_specs import RayIntervals
 from ..pdf import importance_sampling, searchsorted
 from ..volrend import render_transmittance_from_density
@@ -137,9 +139,49 @@ def _transform_stot(transform_type: Literal["uniform", "lindisp"], s_vals: Tenso
     raise ValueError(f"Unknown transform_type: {transform_type}")
 
 
+class _PdfLossBatched(torch.autograd.Function):
+    """The batched branch of :func:`_pdf_loss` as one native pass forward and one backward (the reference composes
+    searchsorted, two gathers and five elementwise ops, and autograd adds two scatter_adds and ~10 more)."""
+
+    @staticmethod
+    def forward(ctx, q_vals, q_cdfs, k_vals, k_cdfs, eps: float):
+        ctx.set_materialize_grads(False)
+        qv, qc, kv, kc = (t.contiguous() for t in (q_vals, q_cdfs, k_vals, k_cdfs))
+        dev = B.require_device(qv, qc, kv, kc)
+        Q1, K1 = qv.shape[-1], kv.shape[-1]
+        n_rays = qv.numel() // Q1
+        loss = torch.empty(qv.shape[:-1] + (Q1 - 1,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            B.call("nfa_pdf_loss_fwd", B.ptr(qv), B.ptr(qc), B.ptr(kv), B.ptr(kc), n_rays, Q1, K1, float(eps), B.ptr(loss),
+                   B.stream())
+        ctx.save_for_backward(qv, qc, kv, kc)
+        ctx.eps = float(eps)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_loss):
+        qv, qc, kv, kc = ctx.saved_tensors
+        if g_loss is None or not (ctx.needs_input_grad[1] or ctx.needs_input_grad[3]):
+            return None, None, None, None, None
+        Q1, K1 = qv.shape[-1], kv.shape[-1]
+        n_rays = qv.numel() // Q1
+        g_kc = torch.empty_like(kc)
+        g_qc = torch.empty_like(qc) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(qv.device):
+            B.call("nfa_pdf_loss_bwd", B.ptr(qv), B.ptr(qc), B.ptr(kv), B.ptr(kc), n_rays, Q1, K1, ctx.eps,
+                   B.ptr(g_loss.contiguous()), B.ptr(g_kc), B.ptr(g_qc), B.stream())
+        return None, g_qc, None, (g_kc if ctx.needs_input_grad[3] else None), None
+
+
 def _pdf_loss(segments_query: RayIntervals, cdfs_query: Tensor, segments_key: RayIntervals, cdfs_key: Tensor,
               eps: float = 1e-7) -> Tensor:
     """Mip-NeRF-360 interlevel loss ``clip(w - w_outer, 0)^2 / (w + eps)`` (ref :232-256)."""
+    qv, kv = segments_query.vals, segments_key.vals
+    if (qv.dim() > 1 and kv.dim() > 1 and qv.is_cuda and all(t.dtype == torch.float32 for t in (qv, kv, cdfs_query, cdfs_key))
+            and qv.shape[:-1] == kv.shape[:-1] and cdfs_query.shape == qv.shape and cdfs_key.shape == kv.shape
+            and 2 <= qv.shape[-1] <= 1024 and kv.shape[-1] <= 1024):
+        return _PdfLossBatched.apply(qv, cdfs_query, kv, cdfs_key, eps)
     ids_left, ids_right = searchsorted(segments_key, segments_query)
     if segments_query.vals.dim() > 1:
         w = cdfs_query[..., 1:] - cdfs_query[..., :-1]

@@ -770,6 +770,39 @@ def test_traversal_fuzz_bit_exact(dev, oracle):
             assert (ri.cpu().numpy() == rsm["ray_indices"][keep]).all() and (ts.cpu().numpy() == L).all() and (te.cpu().numpy() == Rr).all(), case
 
 
+def test_pdf_loss_fused_matches_composition(dev):
+    """The batched interlevel loss as one native pass each way against the reference's composition (searchsorted +
+    gathers + elementwise, prop_net.py:232-256) evaluated with torch autograd: values and both gradients."""
+    from nerfacc_amd.data_specs import RayIntervals
+    from nerfacc_amd.estimators.prop_net import _pdf_loss
+    from nerfacc_amd.pdf import searchsorted
+    rng = np.random.default_rng(5)
+    for R, Q1, K1 in ((513, 17, 65), (40, 65, 65), (7, 3, 2), (300, 129, 33)):
+        def mk(n):
+            v = np.sort(rng.uniform(0, 1, (R, n)).astype(np.float32), -1)
+            c = np.sort(rng.uniform(0, 1, (R, n)).astype(np.float32), -1)
+            return torch.from_numpy(v).to(dev), torch.from_numpy(c).to(dev)
+        qv, qc0 = mk(Q1); kv, kc0 = mk(K1)
+        g = torch.from_numpy(rng.normal(size=(R, Q1 - 1)).astype(np.float32)).to(dev)
+        qc, kc = qc0.clone().requires_grad_(True), kc0.clone().requires_grad_(True)
+        loss = _pdf_loss(RayIntervals(vals=qv), qc, RayIntervals(vals=kv), kc)
+        (loss * g).sum().backward()
+        # the composition
+        qc2, kc2 = qc0.clone().requires_grad_(True), kc0.clone().requires_grad_(True)
+        il, ir = searchsorted(RayIntervals(vals=kv), RayIntervals(vals=qv))
+        w = qc2[..., 1:] - qc2[..., :-1]
+        wo = kc2.gather(-1, ir[..., 1:]) - kc2.gather(-1, il[..., :-1])
+        ref = torch.clip(w - wo, min=0) ** 2 / (w + 1e-7)
+        (ref * g).sum().backward()
+        assert_close(loss, ref, atol=1e-6, rtol=1e-5)
+        assert_close(kc.grad, kc2.grad, atol=2e-5, rtol=1e-4)
+        assert_close(qc.grad, qc2.grad, atol=2e-4, rtol=1e-3)   # d/dw has a 1/(w+eps)^2 term: large values
+    # key gradient only (the estimator detaches the query CDF)
+    kc = kc0.clone().requires_grad_(True)
+    _pdf_loss(RayIntervals(vals=qv), qc0, RayIntervals(vals=kv), kc).sum().backward()
+    assert kc.grad is not None and torch.isfinite(kc.grad).all()
+
+
 # ----------------------------------------------------------------------------- full-size properties (BASELINE cfg 2)
 def test_full_size_properties(dev):
     """1024x1024 rays through a 128^3 grid at ~10% occupancy: size-independent invariants."""
