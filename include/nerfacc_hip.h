@@ -294,13 +294,14 @@ int nfa_searchsorted(const float *q_vals, const int64_t *q_packed_info, const in
 /* Interlevel (proposal) loss for batched rays (ref: estimators/prop_net.py:232-256): loss[r,j] =
  * max(w - w_outer, 0)^2 / (w + eps) with w = q_cdfs[r,j+1] - q_cdfs[r,j] and w_outer the key CDF mass between the
  * key edges that enclose query interval j (the reference's searchsorted + gathers), j < n_query_edges - 1.
- * Backward: g_k_cdfs[r, n_key_edges] (required) and g_q_cdfs[r, n_query_edges] (optional), rows of <= 1024 edges. */
+ * key_ids[r,j] (optional) = left | right << 16, the key edge indices, kept for the backward pass.
+ * Backward: g_k_cdfs[r, n_key_edges] (required) and g_q_cdfs[r, n_query_edges] (optional); rows of <= 1024 edges. */
 int nfa_pdf_loss_fwd(const float *q_vals, const float *q_cdfs, const float *k_vals, const float *k_cdfs,
                      int64_t n_rays, int32_t n_query_edges, int32_t n_key_edges, float eps, float *loss,
-                     nfa_stream_t stream);
-int nfa_pdf_loss_bwd(const float *q_vals, const float *q_cdfs, const float *k_vals, const float *k_cdfs,
-                     int64_t n_rays, int32_t n_query_edges, int32_t n_key_edges, float eps, const float *g_loss,
-                     float *g_k_cdfs, float *g_q_cdfs, nfa_stream_t stream);
+                     uint32_t *key_ids, nfa_stream_t stream);
+int nfa_pdf_loss_bwd(const float *q_cdfs, const float *k_cdfs, const uint32_t *key_ids, int64_t n_rays,
+                     int32_t n_query_edges, int32_t n_key_edges, float eps, const float *g_loss, float *g_k_cdfs,
+                     float *g_q_cdfs, nfa_stream_t stream);
 
 #ifdef __cplusplus
 }

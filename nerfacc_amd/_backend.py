@@ -46,8 +46,8 @@ _SIGS = {
     "nfa_exclusive_cumsum_i64": [_vp, _i64, _vp, _vp, _vp, _vp],
     "nfa_exclusive_cumsum_pairs_i64": [_vp, _i64, _vp, _vp, _vp, _vp],
     "nfa_pack_info": [_vp, _i64, _i64, _vp, _vp, _vp, _vp],
-    "nfa_pdf_loss_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp],
-    "nfa_pdf_loss_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _vp, _vp],
+    "nfa_pdf_loss_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _vp],
+    "nfa_pdf_loss_bwd": [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _vp, _vp],
     "nfa_pack_bits": [_vp, _i64, _vp, _vp],
     "nfa_ray_aabb_intersect": [_vp, _vp, _i64, _vp, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
     "nfa_traverse_grids": [C.POINTER(TraverseArgs), _vp],

@@ -215,29 +215,21 @@ __global__ __launch_bounds__(256) void searchsorted_kernel(
 // in LDS (only the ray's own lane group touches it) and writes it once.
 constexpr int PL_STAGE_MAX = 1024;  // key entries (vals + cdfs [+ grad row]) a wave may stage
 
-template <bool BWD>
-__global__ __launch_bounds__(256) void pdf_loss_kernel(const float *__restrict__ q_vals, const float *__restrict__ q_cdfs,
-                                                       const float *__restrict__ k_vals, const float *__restrict__ k_cdfs,
-                                                       int64_t n_rays, int Q1, int K1, int L, float eps,
-                                                       float *__restrict__ loss, const float *__restrict__ g_loss,
-                                                       float *__restrict__ g_k_cdfs, float *__restrict__ g_q_cdfs)
+__global__ __launch_bounds__(256) void pdf_loss_fwd_kernel(const float *__restrict__ q_vals, const float *__restrict__ q_cdfs,
+                                                           const float *__restrict__ k_vals, const float *__restrict__ k_cdfs,
+                                                           int64_t n_rays, int Q1, int K1, int L, float eps,
+                                                           float *__restrict__ loss, uint32_t *__restrict__ ids /* left | right << 16, or null */)
 {
     __shared__ float s_kv[4][PL_STAGE_MAX];
     __shared__ float s_kc[4][PL_STAGE_MAX];
-    __shared__ float s_g[4][BWD ? PL_STAGE_MAX : 1];
-    __shared__ float s_gq[4][BWD ? PL_STAGE_MAX : 1];
     const int lane = lane_id(), gl = lane & (L - 1), rpw = 64 / L, Q = Q1 - 1;
-    float *kv = s_kv[threadIdx.x >> 6], *kc = s_kc[threadIdx.x >> 6], *gk = s_g[threadIdx.x >> 6], *gq = s_gq[threadIdx.x >> 6];
+    float *kv = s_kv[threadIdx.x >> 6], *kc = s_kc[threadIdx.x >> 6];
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t r0 = wave * rpw; r0 < n_rays; r0 += n_waves * rpw) {
         const int n_here = (int)min((int64_t)rpw, n_rays - r0);
         __builtin_amdgcn_wave_barrier();
-        for (int f = lane; f < n_here * K1; f += 64) {
-            kv[f] = k_vals[r0 * K1 + f]; kc[f] = k_cdfs[r0 * K1 + f];
-            if (BWD) gk[f] = 0.0f;
-        }
-        if (BWD && g_q_cdfs) for (int f = lane; f < n_here * Q1; f += 64) gq[f] = 0.0f;
+        for (int f = lane; f < n_here * K1; f += 64) { kv[f] = k_vals[r0 * K1 + f]; kc[f] = k_cdfs[r0 * K1 + f]; }
         __builtin_amdgcn_wave_barrier();
         const int slot = lane / L;
         const int64_t ray = r0 + slot;
@@ -251,30 +243,59 @@ __global__ __launch_bounds__(256) void pdf_loss_kernel(const float *__restrict__
                 const float w = qc[j + 1] - qc[j];
                 const float wo = kc[right] - kc[left];
                 const float d = fmaxf(w - wo, 0.0f);
-                if (!BWD) {
-                    loss[ray * Q + j] = (d * d) / (w + eps);
-                } else {
-                    const float g = g_loss[ray * Q + j];
-                    // d l / d wo = -2 d / (w + eps);  d l / d w = 2 d / (w + eps) - d^2 / (w + eps)^2   (d > 0)
-                    const float inv = 1.0f / (w + eps);
+                loss[ray * Q + j] = (d * d) / (w + eps);
+                if (ids) ids[ray * Q + j] = (uint32_t)(left - kb) | ((uint32_t)(right - kb) << 16);
+            }
+        }
+    }
+}
+
+// Backward from the key indices saved by the forward pass: no searches, no key rows; a ray's key-CDF gradient row is
+// accumulated in LDS by the ray's own lane group and written once.
+__global__ __launch_bounds__(256) void pdf_loss_bwd_kernel(const float *__restrict__ q_cdfs, const float *__restrict__ k_cdfs,
+                                                           const uint32_t *__restrict__ ids, int64_t n_rays, int Q1, int K1,
+                                                           int L, float eps, const float *__restrict__ g_loss,
+                                                           float *__restrict__ g_k_cdfs, float *__restrict__ g_q_cdfs)
+{
+    __shared__ float s_g[4][PL_STAGE_MAX];
+    __shared__ float s_gq[4][PL_STAGE_MAX];
+    const int lane = lane_id(), gl = lane & (L - 1), rpw = 64 / L, Q = Q1 - 1;
+    float *gk = s_g[threadIdx.x >> 6], *gq = s_gq[threadIdx.x >> 6];
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r0 = wave * rpw; r0 < n_rays; r0 += n_waves * rpw) {
+        const int n_here = (int)min((int64_t)rpw, n_rays - r0);
+        __builtin_amdgcn_wave_barrier();
+        for (int f = lane; f < n_here * K1; f += 64) gk[f] = 0.0f;
+        if (g_q_cdfs) for (int f = lane; f < n_here * Q1; f += 64) gq[f] = 0.0f;
+        __builtin_amdgcn_wave_barrier();
+        const int slot = lane / L;
+        const int64_t ray = r0 + slot;
+        if (ray < n_rays) {
+            const int kb = slot * K1;
+            const float *qc = q_cdfs + ray * Q1, *kc = k_cdfs + ray * K1;
+            for (int j = gl; j < Q; j += L) {
+                const uint32_t id = ids[ray * Q + j];
+                const int left = (int)(id & 0xFFFFu), right = (int)(id >> 16);
+                const float w = qc[j + 1] - qc[j];
+                const float d = fmaxf(w - (kc[right] - kc[left]), 0.0f);
+                if (d > 0.0f) {
+                    // d l / d wo = -2 d / (w + eps);  d l / d w = 2 d / (w + eps) - d^2 / (w + eps)^2
+                    const float g = g_loss[ray * Q + j], inv = 1.0f / (w + eps);
                     const float gwo = -2.0f * d * inv * g;
-                    if (d > 0.0f) {
-                        atomicAdd(&gk[right], gwo);
-                        atomicAdd(&gk[left], -gwo);
-                        if (g_q_cdfs) {
-                            const float gw = (2.0f * d * inv - d * d * inv * inv) * g;
-                            atomicAdd(&gq[slot * Q1 + j + 1], gw);
-                            atomicAdd(&gq[slot * Q1 + j], -gw);
-                        }
+                    atomicAdd(&gk[kb + right], gwo);
+                    atomicAdd(&gk[kb + left], -gwo);
+                    if (g_q_cdfs) {
+                        const float gw = (2.0f * d * inv - d * d * inv * inv) * g;
+                        atomicAdd(&gq[slot * Q1 + j + 1], gw);
+                        atomicAdd(&gq[slot * Q1 + j], -gw);
                     }
                 }
             }
         }
-        if (BWD) {
-            __builtin_amdgcn_wave_barrier();
-            for (int f = lane; f < n_here * K1; f += 64) g_k_cdfs[r0 * K1 + f] = gk[f];
-            if (g_q_cdfs) for (int f = lane; f < n_here * Q1; f += 64) g_q_cdfs[r0 * Q1 + f] = gq[f];
-        }
+        __builtin_amdgcn_wave_barrier();
+        for (int f = lane; f < n_here * K1; f += 64) g_k_cdfs[r0 * K1 + f] = gk[f];
+        if (g_q_cdfs) for (int f = lane; f < n_here * Q1; f += 64) g_q_cdfs[r0 * Q1 + f] = gq[f];
     }
 }
 
@@ -343,7 +364,7 @@ static int pdf_loss_lanes(int Q, int K1, int Q1)
 }
 
 int nfa_pdf_loss_fwd(const float *q_vals, const float *q_cdfs, const float *k_vals, const float *k_cdfs, int64_t n_rays,
-                     int32_t n_query_edges, int32_t n_key_edges, float eps, float *loss, nfa_stream_t stream)
+                     int32_t n_query_edges, int32_t n_key_edges, float eps, float *loss, uint32_t *key_ids, nfa_stream_t stream)
 {
     NFA_REQUIRE(n_rays >= 0 && n_query_edges >= 2 && n_key_edges >= 1, "pdf_loss_fwd: bad sizes");
     NFA_REQUIRE(n_key_edges <= PL_STAGE_MAX && n_query_edges <= PL_STAGE_MAX, "pdf_loss_fwd: rows longer than 1024 edges are not supported");
@@ -351,24 +372,24 @@ int nfa_pdf_loss_fwd(const float *q_vals, const float *q_cdfs, const float *k_va
     NFA_REQUIRE(q_vals && q_cdfs && k_vals && k_cdfs && loss, "pdf_loss_fwd: null pointer");
     const int L = pdf_loss_lanes(n_query_edges - 1, n_key_edges, n_query_edges);
     const unsigned grid = grid_1d(ceil_div64(n_rays, 64 / L) * 64, 256, 1 << 16);
-    hipLaunchKernelGGL(pdf_loss_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), q_vals, q_cdfs, k_vals, k_cdfs,
-                       n_rays, (int)n_query_edges, (int)n_key_edges, L, eps, loss, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(pdf_loss_fwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), q_vals, q_cdfs, k_vals, k_cdfs,
+                       n_rays, (int)n_query_edges, (int)n_key_edges, L, eps, loss, key_ids);
     NFA_CHECK_LAUNCH("pdf_loss_fwd");
     return NFA_OK;
 }
 
-int nfa_pdf_loss_bwd(const float *q_vals, const float *q_cdfs, const float *k_vals, const float *k_cdfs, int64_t n_rays,
+int nfa_pdf_loss_bwd(const float *q_cdfs, const float *k_cdfs, const uint32_t *key_ids, int64_t n_rays,
                      int32_t n_query_edges, int32_t n_key_edges, float eps, const float *g_loss, float *g_k_cdfs,
                      float *g_q_cdfs, nfa_stream_t stream)
 {
     NFA_REQUIRE(n_rays >= 0 && n_query_edges >= 2 && n_key_edges >= 1, "pdf_loss_bwd: bad sizes");
     NFA_REQUIRE(n_key_edges <= PL_STAGE_MAX && n_query_edges <= PL_STAGE_MAX, "pdf_loss_bwd: rows longer than 1024 edges are not supported");
     if (n_rays == 0) return NFA_OK;
-    NFA_REQUIRE(q_vals && q_cdfs && k_vals && k_cdfs && g_loss && g_k_cdfs, "pdf_loss_bwd: null pointer");
+    NFA_REQUIRE(q_cdfs && k_cdfs && key_ids && g_loss && g_k_cdfs, "pdf_loss_bwd: null pointer");
     const int L = pdf_loss_lanes(n_query_edges - 1, n_key_edges, n_query_edges);
     const unsigned grid = grid_1d(ceil_div64(n_rays, 64 / L) * 64, 256, 1 << 16);
-    hipLaunchKernelGGL(pdf_loss_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), q_vals, q_cdfs, k_vals, k_cdfs,
-                       n_rays, (int)n_query_edges, (int)n_key_edges, L, eps, nullptr, g_loss, g_k_cdfs, g_q_cdfs);
+    hipLaunchKernelGGL(pdf_loss_bwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), q_cdfs, k_cdfs, key_ids, n_rays,
+                       (int)n_query_edges, (int)n_key_edges, L, eps, g_loss, g_k_cdfs, g_q_cdfs);
     NFA_CHECK_LAUNCH("pdf_loss_bwd");
     return NFA_OK;
 }

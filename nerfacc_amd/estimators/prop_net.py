@@ -151,25 +151,28 @@ class _PdfLossBatched(torch.autograd.Function):
         Q1, K1 = qv.shape[-1], kv.shape[-1]
         n_rays = qv.numel() // Q1
         loss = torch.empty(qv.shape[:-1] + (Q1 - 1,), dtype=torch.float32, device=dev)
+        need_bwd = any(ctx.needs_input_grad)
+        ids = torch.empty(loss.shape, dtype=torch.int32, device=dev) if need_bwd else None  # key edges, for the backward
         with torch.cuda.device(dev):
             B.call("nfa_pdf_loss_fwd", B.ptr(qv), B.ptr(qc), B.ptr(kv), B.ptr(kc), n_rays, Q1, K1, float(eps), B.ptr(loss),
-                   B.stream())
-        ctx.save_for_backward(qv, qc, kv, kc)
-        ctx.eps = float(eps)
+                   B.ptr(ids), B.stream())
+        if need_bwd:
+            ctx.save_for_backward(qc, kc, ids)
+        ctx.eps, ctx.K1 = float(eps), K1
         return loss
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g_loss):
-        qv, qc, kv, kc = ctx.saved_tensors
         if g_loss is None or not (ctx.needs_input_grad[1] or ctx.needs_input_grad[3]):
             return None, None, None, None, None
-        Q1, K1 = qv.shape[-1], kv.shape[-1]
-        n_rays = qv.numel() // Q1
+        qc, kc, ids = ctx.saved_tensors
+        Q1, K1 = qc.shape[-1], kc.shape[-1]
+        n_rays = qc.numel() // Q1
         g_kc = torch.empty_like(kc)
         g_qc = torch.empty_like(qc) if ctx.needs_input_grad[1] else None
-        with torch.cuda.device(qv.device):
-            B.call("nfa_pdf_loss_bwd", B.ptr(qv), B.ptr(qc), B.ptr(kv), B.ptr(kc), n_rays, Q1, K1, ctx.eps,
+        with torch.cuda.device(qc.device):
+            B.call("nfa_pdf_loss_bwd", B.ptr(qc), B.ptr(kc), B.ptr(ids), n_rays, Q1, K1, ctx.eps,
                    B.ptr(g_loss.contiguous()), B.ptr(g_kc), B.ptr(g_qc), B.stream())
         return None, g_qc, None, (g_kc if ctx.needs_input_grad[3] else None), None
 
