@@ -141,7 +141,10 @@ class OccGridEstimator(AbstractEstimator):
         if self._prefetch_stream is None:
             # a high-priority stream: it comes from a different pool than ordinary streams, which makes it far less
             # likely to share a hardware queue with the stream it is supposed to overlap with
-            self._prefetch_stream = torch.cuda.Stream(device=rays_o.device, priority=-1)
+            try:
+                self._prefetch_stream = torch.cuda.Stream(device=rays_o.device, priority=-1)
+            except Exception:  # pragma: no cover - priorities unsupported
+                self._prefetch_stream = torch.cuda.Stream(device=rays_o.device)
         side = self._prefetch_stream
         if wait_for_inputs:
             side.wait_stream(torch.cuda.current_stream(rays_o.device))
