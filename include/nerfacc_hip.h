@@ -109,7 +109,7 @@ typedef struct nfa_traverse_args {
     int64_t *iv_starts; int64_t *iv_cnts;
     /* samples */
     float *sm_vals; int64_t *sm_ray_indices; uint8_t *sm_is_valid;
-    float *sm_t_starts; float *sm_t_ends;       /* sample-only fast path */
+    float *sm_t_starts; float *sm_t_ends;       /* sample-only fast path (sm_ray_indices may be NULL: see nfa_fill_ray_indices) */
     int64_t *sm_starts; int64_t *sm_cnts;
     float *terminate_planes;    /* [n_rays] or NULL */
     /* optional ray filter (mode 1): only rays with ray_filter[r] > ray_filter_min are processed */
@@ -147,6 +147,12 @@ int nfa_traverse_runs(const nfa_traverse_args *args, const uint64_t *bricks, con
 int nfa_expand_runs(int64_t n_rays, float step_size, const int32_t *run_cnts, const uint64_t *runs,
                     int32_t max_runs, const int64_t *packed_info /*[n_rays,2] {start, count}*/, float *t_starts,
                     float *t_ends, float *t_mids, int64_t *ray_indices, nfa_stream_t stream);
+/* ray_indices[k] = r for every k in [packed_info[r].start, packed_info[r].start + packed_info[r].count): the inverse of
+ * nfa_pack_info for contiguous, ray-ordered segments (what the traversal produces), written as coalesced 32-byte
+ * stores.  Used after nfa_traverse_grids' direct fill pass with sm_ray_indices == NULL, so that the per-ray serial
+ * kernel does not scatter 8-byte indices (ref: grid.cu:247 writes them from the marching loop). */
+int nfa_fill_ray_indices(int64_t n_rays, const int64_t *packed_info /*[n_rays,2]*/, int64_t *ray_indices,
+                         nfa_stream_t stream);
 /* The interval stream of the API's traverse_grids from the same run records (ref: grid.cu:219-262; edge
  * values, ray_indices, is_left, is_right); iv_cnts as written by nfa_traverse_runs when args->iv_cnts is set
  * (edges = samples + one leading edge per chain of continuous samples), iv_packed_info its {start, count} rows. */
@@ -285,6 +291,15 @@ int nfa_importance_sampling(const float *in_vals, const float *cdfs, const int64
                             int stratified, uint64_t seed, uint64_t offset,
                             float *out_intervals /*[n_rays,S+1]*/, float *out_samples /*[n_rays,S] or NULL*/,
                             nfa_stream_t stream);
+/* The same resampling with the s -> t mapping of PropNetEstimator.sampling fused in (ref: estimators/prop_net.py:215-229):
+ * besides the s-space intervals, the S+1 edges mapped to metric distance are written as contiguous rows
+ * t_starts[n_rays,S] / t_ends[n_rays,S].  transform 1 = uniform: t = s*t_b + (1-s)*t_a with (t_a, t_b) = (t_min, t_max);
+ * 2 = lindisp: t = 1 / (s*t_b + (1-s)*t_a) with (t_a, t_b) = (1/t_min, 1/t_max).  Same fp32 operation order as the
+ * reference's tensor expression. */
+int nfa_importance_sampling_t(const float *in_vals, const float *cdfs, const int64_t *in_packed_info, int64_t n_rays,
+                              int64_t n_edges_per_ray, int64_t n_samples, int stratified, uint64_t seed,
+                              uint64_t offset, float *out_intervals, float *out_samples, int transform, float t_a,
+                              float t_b, float *out_t_starts, float *out_t_ends, nfa_stream_t stream);
 /* ref: cuda/csrc/pdf.cu:245-286,426-456. Batched query => ray-relative ids. */
 int nfa_searchsorted(const float *q_vals, const int64_t *q_packed_info, const int64_t *q_ray_indices,
                      int64_t q_n_rays, int64_t q_per_ray, int64_t q_total,

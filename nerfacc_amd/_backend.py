@@ -55,6 +55,7 @@ _SIGS = {
     "nfa_pack_bricks": [_vp, _i32, C.POINTER(_i32), _vp, _vp, _vp],
     "nfa_traverse_runs": [C.POINTER(TraverseArgs), _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp],
     "nfa_expand_runs": [_i64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "nfa_fill_ray_indices": [_i64, _vp, _vp, _vp],
     "nfa_expand_intervals": [_i64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "nfa_seg_plan": [_i64, C.POINTER(_i64), C.POINTER(_i64)],
     "nfa_seg_build_tiles": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
@@ -76,6 +77,7 @@ _SIGS = {
     "nfa_render_fused_bwd": [_vp] * 13 + [_i64, _i64, _i64, _vp, _vp, _vp],
     "nfa_render_step_accumulate": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _vp, _vp],
     "nfa_importance_sampling": [_vp, _vp, _vp, _i64, _i64, _i64, _int, _u64, _u64, _vp, _vp, _vp],
+    "nfa_importance_sampling_t": [_vp, _vp, _vp, _i64, _i64, _i64, _int, _u64, _u64, _vp, _vp, _int, _f32, _f32, _vp, _vp, _vp],
     "nfa_searchsorted": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp],
     "nfa_cumsum_scratch_bytes": [_i64],
     "nfa_last_error": [],

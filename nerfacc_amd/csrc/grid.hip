@@ -79,7 +79,7 @@ enum { EMIT_NONE = 0, EMIT_API = 1, EMIT_DIRECT = 2 };
 
 struct RayState {
     float t_last;
-    bool continuous;
+    int32_t continuous;     // 0 / 1 (an integer: a bool carried across the loops lives in scalar lane masks)
     int32_t n_intervals;
     int32_t n_samples;
     int32_t brick_id;       // brick cache (when the brick-packed grid is given)
@@ -124,79 +124,119 @@ __device__ __forceinline__ void traverse_span(const nfa_traverse_args &a, int64_
     }
     const int64_t level_base = (int64_t)level * a.res[0] * a.res[1] * a.res[2];
     int32_t cells_left = a.res[0] + a.res[1] + a.res[2] + 3;  // safety cap, never binding for a valid DDA
+    // 4x4x4 bricks: bit ((x&3)<<4 | (y&3)<<2 | (z&3)) of word ((x>>2)*by + (y>>2))*bz + (z>>2)
+    const int32_t by = (a.res[1] + 3) >> 2, bz = (a.res[2] + 3) >> 2, bx = (a.res[0] + 3) >> 2;
+    const int32_t brick_base = level * bx * by * bz;
 
-    while (limit <= 0 || st.n_samples < limit) {
+    // one sample [t_last, t_next) (grid.cu:219-258)
+    auto emit = [&](float t_next) {
+        if (HAS_IV) {
+            if (EMIT == EMIT_API) {
+                // Both mask bytes of every edge are written (the reference zero-fills the
+                // arrays first and only sets the true ones, data_spec.hpp:66-71).
+                const int64_t idx = iv_base + st.n_intervals;
+                if (!st.continuous) {
+                    a.iv_vals[idx] = st.t_last; a.iv_ray_indices[idx] = tid;
+                    a.iv_is_left[idx] = 1; a.iv_is_right[idx] = 0;
+                    a.iv_vals[idx + 1] = t_next; a.iv_ray_indices[idx + 1] = tid;
+                    a.iv_is_left[idx + 1] = 0; a.iv_is_right[idx + 1] = 1;
+                } else {
+                    a.iv_vals[idx] = t_next; a.iv_ray_indices[idx] = tid;
+                    a.iv_is_left[idx - 1] = 1; a.iv_is_left[idx] = 0; a.iv_is_right[idx] = 1;
+                }
+            }
+            st.n_intervals += st.continuous ? 1 : 2;
+        }
+        if (HAS_SM) {
+            const int64_t idx = sm_base + st.n_samples;
+            if (EMIT == EMIT_API) {
+                a.sm_vals[idx] = (t_next + st.t_last) * 0.5f;
+                a.sm_ray_indices[idx] = tid;
+                a.sm_is_valid[idx] = 1;
+            } else if (EMIT == EMIT_DIRECT) {
+                a.sm_t_starts[idx] = st.t_last;
+                a.sm_t_ends[idx] = t_next;
+                if (a.sm_ray_indices) a.sm_ray_indices[idx] = tid;
+            }
+        }
+        st.n_samples++;
+        st.continuous = 1;
+        st.t_last = t_next;
+    };
+
+    // The hot loop is written for the scalar unit as much as for the vector ALUs: with unrelated rays every `if`, `break`
+    // and bool that lives across a branch becomes a handful of 64-bit mask operations on the CU's single scalar pipe, and
+    // the first version of this loop issued more scalar than vector instructions (8.1 G vs 6.1 G per launch on cfg 5:
+    // the scalar pipe was the bottleneck).  Hence: one exit per loop, flags in integer registers, selects instead of
+    // branches, and the brick word of the NEXT cell requested before the current cell is marched (the DDA does not
+    // depend on the march), so that the load's latency overlaps the march.
+    auto brick_of = [&](void) {
+        return brick_base + (int32_t)__umul24(__umul24(cur[0] >> 2, by) + (cur[1] >> 2), bz) + (cur[2] >> 2);
+    };
+    const bool use_bricks = a.bricks != nullptr;
+    if (use_bricks) {
+        const int32_t bid = brick_of();
+        if (bid != st.brick_id) {
+            st.brick_id = bid;
+            const unsigned long long w = a.bricks[bid];  // (the 1-bit mask would be a second, dependent access)
+            st.brick_lo = (uint32_t)w; st.brick_hi = (uint32_t)(w >> 32);
+        }
+    }
+    if (limit > 0 && st.n_samples >= limit) return;
+    for (;;) {
         const float t_traverse = fminf(fminf(tdist[0], fminf(tdist[1], tdist[2])), this_tmax);
         bool occupied;
-        if (a.bricks) {  // 4x4x4 bricks: bit ((x&3)<<4 | (y&3)<<2 | (z&3)) of word ((x>>2)*by + (y>>2))*bz + (z>>2)
-            const int32_t by = (a.res[1] + 3) >> 2, bz = (a.res[2] + 3) >> 2, bx = (a.res[0] + 3) >> 2;
-            const int32_t bid = level * bx * by * bz + ((cur[0] >> 2) * by + (cur[1] >> 2)) * bz + (cur[2] >> 2);
-            if (bid != st.brick_id) {
-                st.brick_id = bid;
-                const unsigned long long w = ((a.coarse[bid >> 5] >> (bid & 31)) & 1u) ? a.bricks[bid] : 0ull;
-                st.brick_lo = (uint32_t)w; st.brick_hi = (uint32_t)(w >> 32);
-            }
+        if (use_bricks) {
             const uint32_t half_w = (cur[0] & 2) ? st.brick_hi : st.brick_lo;
             occupied = (half_w >> (((cur[0] & 1) << 4) | ((cur[1] & 3) << 2) | (cur[2] & 3))) & 1u;
         } else {
             occupied = a.binaries[level_base + (int64_t)(cur[0] * a.res[1] * a.res[2] + cur[1] * a.res[2] + cur[2])] != 0;
         }
-        if (!occupied) {
-            st.t_last = fast_forward(st.t_last, t_traverse, step_size, cone);
-            st.continuous = false;
+        // single_traversal, utils_grid.cuh:116-142 (branch-free)
+        const bool s0 = (tdist[0] < tdist[1]) && (tdist[0] < tdist[2]);
+        const bool s1 = !s0 && (tdist[1] < tdist[2]);
+        const bool s2 = !s0 && !s1;
+        cur[0] += s0 ? step[0] : 0; tdist[0] += s0 ? delta[0] : 0.0f;
+        cur[1] += s1 ? step[1] : 0; tdist[1] += s1 ? delta[1] : 0.0f;
+        cur[2] += s2 ? step[2] : 0; tdist[2] += s2 ? delta[2] : 0.0f;
+        const bool done = (s0 && cur[0] == overflow[0]) || (s1 && cur[1] == overflow[1]) || (s2 && cur[2] == overflow[2]);
+        unsigned long long w_next = 0ull;
+        const int32_t bid_next = use_bricks ? brick_of() : st.brick_id;
+        const bool fetch = use_bricks && !done && bid_next != st.brick_id;
+        if (fetch) w_next = a.bricks[bid_next];
+
+        if (step_size <= 0.0f) {  // one interval per occupied cell (grid.cu:155,198,212)
+            if (occupied) emit(t_traverse);
+            else { st.t_last = t_traverse; st.continuous = 0; }
         } else {
-            while (limit <= 0 || st.n_samples < limit) {
-                float t_next;
-                if (step_size <= 0.0f) {
-                    t_next = t_traverse;
+            // March to t_traverse.  An empty cell skips with the dt of its first step (grid.cu:193-206), an occupied
+            // one emits with dt recomputed per sample (grid.cu:207-262): one loop, so that a wave whose lanes sit in
+            // cells of both kinds runs it once.
+            float dt = calc_dt(st.t_last, cone, step_size);
+            // a skip of many steps (cell much larger than the step): closed form (march.h), same result as the loop
+            if (!occupied && t_traverse - st.t_last > 8.0f * dt) st.t_last = fast_forward_exact(st.t_last, t_traverse, dt);
+            for (;;) {
+                const float t_next = st.t_last + dt;
+                const bool budget = !(occupied && limit > 0 && st.n_samples >= limit);
+                if (!((st.t_last + dt * 0.5f < t_traverse) && (t_next != st.t_last) && budget)) break;
+                if (occupied) {
+                    emit(t_next);
+                    dt = calc_dt(t_next, cone, step_size);
                 } else {
-                    const float dt = calc_dt(st.t_last, cone, step_size);
-                    if (st.t_last + dt * 0.5f >= t_traverse) break;
-                    t_next = st.t_last + dt;
-                    if (t_next == st.t_last) break;  // no-progress guard (ours)
+                    st.t_last = t_next;
                 }
-                if (HAS_IV) {
-                    if (EMIT == EMIT_API) {
-                        // Both mask bytes of every edge are written (the reference zero-fills the
-                        // arrays first and only sets the true ones, data_spec.hpp:66-71).
-                        const int64_t idx = iv_base + st.n_intervals;
-                        if (!st.continuous) {
-                            a.iv_vals[idx] = st.t_last; a.iv_ray_indices[idx] = tid;
-                            a.iv_is_left[idx] = 1; a.iv_is_right[idx] = 0;
-                            a.iv_vals[idx + 1] = t_next; a.iv_ray_indices[idx + 1] = tid;
-                            a.iv_is_left[idx + 1] = 0; a.iv_is_right[idx + 1] = 1;
-                        } else {
-                            a.iv_vals[idx] = t_next; a.iv_ray_indices[idx] = tid;
-                            a.iv_is_left[idx - 1] = 1; a.iv_is_left[idx] = 0; a.iv_is_right[idx] = 1;
-                        }
-                    }
-                    st.n_intervals += st.continuous ? 1 : 2;
-                }
-                if (HAS_SM) {
-                    const int64_t idx = sm_base + st.n_samples;
-                    if (EMIT == EMIT_API) {
-                        a.sm_vals[idx] = (t_next + st.t_last) * 0.5f;
-                        a.sm_ray_indices[idx] = tid;
-                        a.sm_is_valid[idx] = 1;
-                    } else if (EMIT == EMIT_DIRECT) {
-                        a.sm_t_starts[idx] = st.t_last;
-                        a.sm_t_ends[idx] = t_next;
-                        a.sm_ray_indices[idx] = tid;
-                    }
-                }
-                st.n_samples++;
-                st.continuous = true;
-                st.t_last = t_next;
-                if (t_next >= t_traverse) break;
+            }
+            if (!occupied) {
+                // left the loop before the target without progress (ours: the reference would spin): jump there
+                if (st.t_last + dt * 0.5f < t_traverse) st.t_last = t_traverse;
+                st.continuous = 0;
             }
         }
-        // single_traversal, utils_grid.cuh:116-142
-        const int ax = (tdist[0] < tdist[1] && tdist[0] < tdist[2]) ? 0 : (tdist[1] < tdist[2] ? 1 : 2);
-        bool done;
-        if (ax == 0)      { cur[0] += step[0]; tdist[0] += delta[0]; done = cur[0] == overflow[0]; }
-        else if (ax == 1) { cur[1] += step[1]; tdist[1] += delta[1]; done = cur[1] == overflow[1]; }
-        else              { cur[2] += step[2]; tdist[2] += delta[2]; done = cur[2] == overflow[2]; }
-        if (done || --cells_left <= 0) break;
+        st.brick_id = fetch ? bid_next : st.brick_id;
+        st.brick_lo = fetch ? (uint32_t)w_next : st.brick_lo;
+        st.brick_hi = fetch ? (uint32_t)(w_next >> 32) : st.brick_hi;
+        --cells_left;
+        if (done || cells_left <= 0 || (limit > 0 && st.n_samples >= limit)) break;
     }
 }
 
@@ -205,6 +245,9 @@ __device__ __forceinline__ void traverse_span(const nfa_traverse_args &a, int64_
 // EMIT_DIRECT: (t_starts, t_ends, ray_indices) per sample (modes 1, 2)
 // FUSED      : single grid, intersection computed here (t_sorted/t_indices/hits are NULL)
 template <int EMIT, bool HAS_IV, bool HAS_SM, bool FUSED>
+#ifdef NFA_TRAVERSE_WAVES
+__attribute__((amdgpu_waves_per_eu(NFA_TRAVERSE_WAVES, 8)))
+#endif
 __global__ __launch_bounds__(256) void traverse_kernel(const nfa_traverse_args a)
 {
     for (int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tid < a.n_rays;
@@ -234,7 +277,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(const nfa_traverse_args a
 
         RayState st;
         st.t_last = near_plane;
-        st.continuous = false;
+        st.continuous = 0;
         st.n_intervals = 0;
         st.n_samples = 0;
         st.brick_id = -1; st.brick_lo = st.brick_hi = 0u;
@@ -537,8 +580,8 @@ int nfa_traverse_grids(const nfa_traverse_args *pa, nfa_stream_t stream)
                     "traverse_grids: interval outputs missing");
         NFA_REQUIRE(!has_sm || a.sm_starts, "traverse_grids: sample starts missing");
         if (direct) {
-            NFA_REQUIRE(!has_iv && has_sm && a.sm_t_ends && a.sm_ray_indices,
-                        "traverse_grids: direct emission needs sm_t_starts, sm_t_ends, sm_ray_indices and no intervals");
+            NFA_REQUIRE(!has_iv && has_sm && a.sm_t_ends,
+                        "traverse_grids: direct emission needs sm_t_starts, sm_t_ends and no intervals");
             launch_traverse<EMIT_DIRECT, false, true>(a, fused, s);
         } else {
             NFA_REQUIRE(!has_sm || (a.sm_vals && a.sm_ray_indices && a.sm_is_valid), "traverse_grids: sample outputs missing");

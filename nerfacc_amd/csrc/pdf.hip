@@ -68,8 +68,21 @@ template <bool STAGED>
 __global__ __launch_bounds__(256) void importance_sampling_kernel(
     const float *__restrict__ in_vals, const float *__restrict__ cdfs, const int64_t *__restrict__ in_packed,
     int64_t n_rays, int64_t n_edges_per_ray, int64_t S, int L, int stratified, uint64_t seed, uint64_t offset,
-    float *__restrict__ out_iv, float *__restrict__ out_sm)
+    float *__restrict__ out_iv, float *__restrict__ out_sm, int transform, float t_a, float t_b,
+    float *__restrict__ out_ts, float *__restrict__ out_te)
 {
+    // optional s -> t mapping of the S+1 edges (ref: estimators/prop_net.py:215-229), written as contiguous
+    // t_starts / t_ends rows: uniform t = s*t_b + (1-s)*t_a (t_a = t_min, t_b = t_max);
+    // lindisp t = 1 / (s*t_b + (1-s)*t_a) (t_a = 1/t_min, t_b = 1/t_max)
+    auto emit_edge = [&](int64_t ray, int64_t k, float e) {
+        out_iv[ray * (S + 1) + k] = e;
+        if (transform) {
+            const float lin = e * t_b + (1.0f - e) * t_a;
+            const float t = transform == 2 ? 1.0f / lin : lin;
+            if (k < S) out_ts[ray * S + k] = t;
+            if (k > 0) out_te[ray * S + k - 1] = t;
+        }
+    };
     __shared__ float s_cdf[4][STAGED ? IS_STAGE_MAX : 1];
     __shared__ float s_val[4][STAGED ? IS_STAGE_MAX : 1];
     const int lane = lane_id();
@@ -134,15 +147,14 @@ __global__ __launch_bounds__(256) void importance_sampling_kernel(
             if (gl == 0) t_prev = t_carry;
             const float t_next = __shfl_down(t, 1, L);
             if (ok) {
-                float *edge = out_iv + ray * (S + 1);
                 if (sid == 0) {
                     const float half_width = (t_next - t) * 0.5f;  // S >= 2 and L >= 2 guarantee lane 1 holds t_1
-                    edge[0] = fmaxf(t - half_width, t_min);
+                    emit_edge(ray, 0, fmaxf(t - half_width, t_min));
                 } else {
-                    edge[sid] = (t + t_prev) * 0.5f;
+                    emit_edge(ray, sid, (t + t_prev) * 0.5f);
                     if (sid == S - 1) {
                         const float half_width = (t - t_prev) * 0.5f;
-                        edge[sid + 1] = fminf(t + half_width, t_max);
+                        emit_edge(ray, sid + 1, fminf(t + half_width, t_max));
                     }
                 }
             }
@@ -305,15 +317,17 @@ using namespace nfa;
 
 extern "C" {
 
-int nfa_importance_sampling(const float *in_vals, const float *cdfs, const int64_t *in_packed_info, int64_t n_rays,
-                            int64_t n_edges_per_ray, int64_t n_samples, int stratified, uint64_t seed,
-                            uint64_t offset, float *out_intervals, float *out_samples, nfa_stream_t stream)
+static int launch_importance_sampling(const float *in_vals, const float *cdfs, const int64_t *in_packed_info, int64_t n_rays,
+                                      int64_t n_edges_per_ray, int64_t n_samples, int stratified, uint64_t seed,
+                                      uint64_t offset, float *out_intervals, float *out_samples, int transform, float t_a,
+                                      float t_b, float *out_ts, float *out_te, nfa_stream_t stream)
 {
     NFA_REQUIRE(n_rays >= 0, "importance_sampling: negative n_rays");
     NFA_REQUIRE(n_samples >= 2, "importance_sampling: n_intervals_per_ray must be >= 2 (the reference reads out of bounds for 1, pdf.cu:211)");
     if (n_rays == 0) return NFA_OK;
     NFA_REQUIRE(in_vals && cdfs && out_intervals, "importance_sampling: null pointer");
     NFA_REQUIRE(in_packed_info || n_edges_per_ray >= 1, "importance_sampling: need packed_info or n_edges_per_ray >= 1");
+    NFA_REQUIRE(transform == 0 || (out_ts && out_te), "importance_sampling: t_starts / t_ends missing");
     int L = 2;
     while (L < 64 && L < n_samples) L <<= 1;
     const int64_t rays_per_wave = 64 / L;
@@ -323,13 +337,31 @@ int nfa_importance_sampling(const float *in_vals, const float *cdfs, const int64
     if (staged)
         hipLaunchKernelGGL(importance_sampling_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), in_vals, cdfs,
                            in_packed_info, n_rays, n_edges_per_ray, n_samples, L, stratified, seed, offset, out_intervals,
-                           out_samples);
+                           out_samples, transform, t_a, t_b, out_ts, out_te);
     else
         hipLaunchKernelGGL(importance_sampling_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), in_vals, cdfs,
                            in_packed_info, n_rays, n_edges_per_ray, n_samples, L, stratified, seed, offset, out_intervals,
-                           out_samples);
+                           out_samples, transform, t_a, t_b, out_ts, out_te);
     NFA_CHECK_LAUNCH("importance_sampling");
     return NFA_OK;
+}
+
+int nfa_importance_sampling(const float *in_vals, const float *cdfs, const int64_t *in_packed_info, int64_t n_rays,
+                            int64_t n_edges_per_ray, int64_t n_samples, int stratified, uint64_t seed,
+                            uint64_t offset, float *out_intervals, float *out_samples, nfa_stream_t stream)
+{
+    return launch_importance_sampling(in_vals, cdfs, in_packed_info, n_rays, n_edges_per_ray, n_samples, stratified, seed,
+                                      offset, out_intervals, out_samples, 0, 0.f, 0.f, nullptr, nullptr, stream);
+}
+
+int nfa_importance_sampling_t(const float *in_vals, const float *cdfs, const int64_t *in_packed_info, int64_t n_rays,
+                              int64_t n_edges_per_ray, int64_t n_samples, int stratified, uint64_t seed, uint64_t offset,
+                              float *out_intervals, float *out_samples, int transform, float t_a, float t_b,
+                              float *out_t_starts, float *out_t_ends, nfa_stream_t stream)
+{
+    NFA_REQUIRE(transform == 1 || transform == 2, "importance_sampling_t: transform must be 1 (uniform) or 2 (lindisp)");
+    return launch_importance_sampling(in_vals, cdfs, in_packed_info, n_rays, n_edges_per_ray, n_samples, stratified, seed,
+                                      offset, out_intervals, out_samples, transform, t_a, t_b, out_t_starts, out_t_ends, stream);
 }
 
 int nfa_searchsorted(const float *q_vals, const int64_t *q_packed_info, const int64_t *q_ray_indices, int64_t q_n_rays,

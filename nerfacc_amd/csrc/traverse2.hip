@@ -429,7 +429,8 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
 // (t_first = NaN) so that its output range is skipped (the serial kernel fills it).  Outputs are then
 // produced chunk by chunk (256 per step, 16 B per lane and array) with a scatter + "most recent entry"
 // scan that tells every output its run.
-template <bool MIDS /* write the API's sample centres instead of (t_starts, t_ends) */>
+enum { EXP_STARTS_ENDS = 0, EXP_MIDS = 1 /* the API's sample centres */, EXP_RAY_INDICES = 2 /* ray_indices only, from packed_info alone */ };
+template <int MODE>
 __global__ __launch_bounds__(64 * EXP_WPB) void expand_runs_kernel(int64_t n_rays, float dt, const int32_t *__restrict__ run_cnts,
                                                           const unsigned long long *__restrict__ runs, int32_t max_runs,
                                                           const longlong2 *__restrict__ packed_info,
@@ -451,10 +452,10 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_runs_kernel(int64_t n_ray
         int32_t c = 0, c_real = 0;
         int64_t s = 0, n = 0;
         if (own) {
-            c_real = run_cnts[ray];
             const longlong2 row = packed_info[ray];
             s = row.x;
             n = row.y;
+            c_real = MODE == EXP_RAY_INDICES ? (n > 0 ? 1 : 0) : run_cnts[ray];  // (ray indices: the ray is one "run")
             c = (c_real > max_runs) ? 1 : c_real;  // overflowed ray: one sentinel entry
         }
         const int64_t W0 = __shfl(s, 0, 64);
@@ -469,6 +470,15 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_runs_kernel(int64_t n_ray
         const int32_t Q = __shfl(incl, EXP_RPW - 1, 64);
         // overflow flag per local ray as a wave-uniform mask
         const unsigned long long ovf_mask = __ballot(own && c_real > max_runs);
+        if (MODE == EXP_RAY_INDICES && W1 - W0 >= ((int64_t)1 << 27)) {
+            // the packed 27-bit positions below cannot address this window (rays of millions of samples): plain
+            // cooperative fill, still coalesced
+            for (int rl = 0; rl <= last_lane; ++rl) {
+                const int64_t s_r = __shfl(s, rl, 64), n_r = __shfl(n, rl, 64);
+                for (int64_t i = lane; i < n_r; i += 64) ray_indices[s_r + i] = r0 + rl;
+            }
+            continue;
+        }
         __builtin_amdgcn_wave_barrier();
         {   // staging: lane -> (ray rl, half); the two half-waves take alternate slots of every ray.  The loads of
             // different slots do not depend on each other (slot-major records: one 256 B line per slot and batch).
@@ -486,7 +496,7 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_runs_kernel(int64_t n_ray
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int32_t i = i0 + 2 * u + half;
-                    rec[u] = (i < c_rl && !ovf) ? col[(int64_t)i * n_rays] : 0ull;
+                    rec[u] = (MODE != EXP_RAY_INDICES && i < c_rl && !ovf) ? col[(int64_t)i * n_rays] : 0ull;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -567,14 +577,14 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_runs_kernel(int64_t n_ray
                     ri4[k] = r0 + (e >> 27);
                     valid[k] = true;
                 }
-                if (MIDS) {  // API form of the samples (ref grid.cu:244: vals = (t_next + t_last) * 0.5f)
+                if (MODE == EXP_MIDS) {  // API form of the samples (ref grid.cu:244: vals = (t_next + t_last) * 0.5f)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) ts4[k] = (te4[k] + ts4[k]) * 0.5f;
                 }
                 if (vec && valid[0] && valid[1] && valid[2] && valid[3]) {
-                    if (MIDS) {
+                    if (MODE == EXP_MIDS) {
                         *reinterpret_cast<float4 *>(t_mids + p0) = make_float4(ts4[0], ts4[1], ts4[2], ts4[3]);
-                    } else {
+                    } else if (MODE == EXP_STARTS_ENDS) {
                         *reinterpret_cast<float4 *>(t_starts + p0) = make_float4(ts4[0], ts4[1], ts4[2], ts4[3]);
                         *reinterpret_cast<float4 *>(t_ends + p0) = make_float4(te4[0], te4[1], te4[2], te4[3]);
                     }
@@ -585,8 +595,8 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_runs_kernel(int64_t n_ray
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (valid[k]) {
-                            if (MIDS) t_mids[p0 + k] = ts4[k];
-                            else { t_starts[p0 + k] = ts4[k]; t_ends[p0 + k] = te4[k]; }
+                            if (MODE == EXP_MIDS) t_mids[p0 + k] = ts4[k];
+                            else if (MODE == EXP_STARTS_ENDS) { t_starts[p0 + k] = ts4[k]; t_ends[p0 + k] = te4[k]; }
                             ray_indices[p0 + k] = ri4[k];
                         }
                 }
@@ -853,14 +863,28 @@ int nfa_expand_runs(int64_t n_rays, float step_size, const int32_t *run_cnts, co
                       reinterpret_cast<uintptr_t>(t_mids) | reinterpret_cast<uintptr_t>(ray_indices)) & 15) == 0;
     const unsigned grid = grid_1d(ceil_div64(n_rays, EXP_RPW) * 64, 64 * EXP_WPB, 1 << 22);
     if (t_mids)
-        hipLaunchKernelGGL(expand_runs_kernel<true>, dim3(grid), dim3(64 * EXP_WPB), 0, as_stream(stream), n_rays, step_size, run_cnts,
+        hipLaunchKernelGGL(expand_runs_kernel<EXP_MIDS>, dim3(grid), dim3(64 * EXP_WPB), 0, as_stream(stream), n_rays, step_size, run_cnts,
                            reinterpret_cast<const unsigned long long *>(runs), max_runs,
                            reinterpret_cast<const longlong2 *>(packed_info), t_starts, t_ends, t_mids, ray_indices, vec);
     else
-        hipLaunchKernelGGL(expand_runs_kernel<false>, dim3(grid), dim3(64 * EXP_WPB), 0, as_stream(stream), n_rays, step_size, run_cnts,
+        hipLaunchKernelGGL(expand_runs_kernel<EXP_STARTS_ENDS>, dim3(grid), dim3(64 * EXP_WPB), 0, as_stream(stream), n_rays, step_size, run_cnts,
                            reinterpret_cast<const unsigned long long *>(runs), max_runs,
                            reinterpret_cast<const longlong2 *>(packed_info), t_starts, t_ends, t_mids, ray_indices, vec);
     NFA_CHECK_LAUNCH("expand_runs");
+    return NFA_OK;
+}
+
+int nfa_fill_ray_indices(int64_t n_rays, const int64_t *packed_info, int64_t *ray_indices, nfa_stream_t stream)
+{
+    NFA_REQUIRE(n_rays >= 0, "fill_ray_indices: negative n_rays");
+    if (n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(packed_info && ray_indices, "fill_ray_indices: null pointer");
+    const int vec = (reinterpret_cast<uintptr_t>(ray_indices) & 15) == 0;
+    const unsigned grid = grid_1d(ceil_div64(n_rays, EXP_RPW) * 64, 64 * EXP_WPB, 1 << 22);
+    hipLaunchKernelGGL(expand_runs_kernel<EXP_RAY_INDICES>, dim3(grid), dim3(64 * EXP_WPB), 0, as_stream(stream), n_rays, 0.0f,
+                       nullptr, nullptr, 1, reinterpret_cast<const longlong2 *>(packed_info), nullptr, nullptr, nullptr,
+                       ray_indices, vec);
+    NFA_CHECK_LAUNCH("fill_ray_indices");
     return NFA_OK;
 }
 

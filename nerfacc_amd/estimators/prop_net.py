@@ -61,9 +61,8 @@ class PropNetEstimator(AbstractEstimator):
                           torch.ones((n_rays, 1), device=self.device)], dim=-1)
         intervals = RayIntervals(vals=cdfs)
         for level_fn, level_samples in zip(prop_sigma_fns, prop_samples):
-            intervals, _ = importance_sampling(intervals, cdfs, level_samples, stratified)
-            t_vals = _transform_stot(sampling_type, intervals.vals, near_plane, far_plane)
-            t_starts, t_ends = t_vals[..., :-1], t_vals[..., 1:]
+            intervals, t_starts, t_ends = _resample(intervals, cdfs, level_samples, stratified, sampling_type,
+                                                    near_plane, far_plane)
             with torch.set_grad_enabled(requires_grad):
                 sigmas = level_fn(t_starts, t_ends)
                 assert sigmas.shape == t_starts.shape
@@ -71,9 +70,8 @@ class PropNetEstimator(AbstractEstimator):
                 cdfs = 1.0 - torch.cat([trans, torch.zeros_like(trans[:, :1])], dim=-1)
                 if requires_grad:
                     self.prop_cache.append((intervals, cdfs))
-        intervals, _ = importance_sampling(intervals, cdfs, num_samples, stratified)
-        t_vals = _transform_stot(sampling_type, intervals.vals, near_plane, far_plane)
-        t_starts, t_ends = t_vals[..., :-1], t_vals[..., 1:]
+        intervals, t_starts, t_ends = _resample(intervals, cdfs, num_samples, stratified, sampling_type, near_plane,
+                                                far_plane)
         if requires_grad:
             self.prop_cache.append((intervals, None))
         return t_starts, t_ends
@@ -128,6 +126,18 @@ def get_proposal_requires_grad_fn(target: float = 5.0, num_steps: int = 1000) ->
         return fire
 
     return proposal_requires_grad_fn
+
+
+def _resample(intervals: RayIntervals, cdfs: Tensor, n: int, stratified: bool, sampling_type: str, t_min, t_max):
+    """One proposal level's resampling and s -> t mapping (ref :89-96, :120-125).  With scalar planes the mapping is
+    fused into the resampling kernel; Tensor planes take the reference's tensor expression."""
+    if isinstance(t_min, Tensor) or isinstance(t_max, Tensor):
+        intervals, _ = importance_sampling(intervals, cdfs, n, stratified)
+        t_vals = _transform_stot(sampling_type, intervals.vals, t_min, t_max)
+        return intervals, t_vals[..., :-1], t_vals[..., 1:]
+    intervals, _, t_starts, t_ends = importance_sampling(intervals, cdfs, n, stratified,
+                                                         transform=(sampling_type, t_min, t_max))
+    return intervals, t_starts, t_ends
 
 
 def _transform_stot(transform_type: Literal["uniform", "lindisp"], s_vals: Tensor, t_min, t_max) -> Tensor:

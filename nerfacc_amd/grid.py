@@ -341,10 +341,15 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
                 a.terminate_planes = None
                 sm_starts = packed_info[:, 0].contiguous()
                 a.sm_starts = B.ptr(sm_starts)
-                a.sm_t_starts, a.sm_t_ends, a.sm_ray_indices = B.ptr(t_starts), B.ptr(t_ends), B.ptr(ray_indices)
+                a.sm_t_starts, a.sm_t_ends = B.ptr(t_starts), B.ptr(t_ends)
                 if use_runs:  # only the rays whose runs did not fit (their counts already honour mask and limit)
+                    a.sm_ray_indices = B.ptr(ray_indices)
                     a.ray_filter, a.ray_filter_min = B.ptr(run_cnts), MAX_RUNS
-                _launch(a)
+                    _launch(a)
+                else:  # the marching kernel writes the distances; the ray ids are a coalesced fill from packed_info
+                    a.sm_ray_indices = None
+                    _launch(a)
+                    B.call("nfa_fill_ray_indices", n_rays, B.ptr(packed_info), B.ptr(ray_indices), B.stream())
     info = tag_trusted(packed_info, n_sm)
     tag_ray_indices(ray_indices, n_rays, info)
     out = (ray_indices, t_starts, t_ends, packed_info)

@@ -588,6 +588,59 @@ def test_sampler_odd_resolution_global_brick_mask(dev, oracle):
     assert (ts.cpu().numpy() == iv["vals"][iv["is_left"]]).all() and (te.cpu().numpy() == iv["vals"][iv["is_right"]]).all()
 
 
+def test_sampler_cone_angle_bit_exact(dev, oracle):
+    """Distance-dependent steps (cone_angle > 0) in the sampler == the oracle's serial two-pass traversal, bit for bit:
+    single grid with in-kernel intersection, nested levels with unrelated rays, resolutions that are not multiples of
+    4, cells much larger than the step (closed-form skips), zero direction components, per-ray near / far planes;
+    ray_indices come from the coalesced fill (nfa_fill_ray_indices), also for a ray of millions of samples."""
+    g = load_golden("traversal")
+    o, d, b, ab, nearp, step, cone = seeded_case(g["cone_params"])
+    assert cone > 0
+    far = np.full(o.shape[0], 1e10, np.float32)
+
+    def check(o, d, b, ab, near, far, step, cone):
+        ri, ts, te, pi = na.grid._traverse_samples(T(o, dev), T(d, dev), T(b, dev), T(ab, dev), T(near, dev), T(far, dev),
+                                                   step, cone)
+        iv, sm, _ = oracle.traverse_grids(o, d, b, ab, near_planes=near, far_planes=far, step_size=step, cone_angle=cone)
+        assert (pi.cpu().numpy() == sm["packed_info"]).all() and (ri.cpu().numpy() == sm["ray_indices"]).all()
+        assert (ts.cpu().numpy() == iv["vals"][iv["is_left"]]).all() and (te.cpu().numpy() == iv["vals"][iv["is_right"]]).all()
+        return ri.numel()
+
+    assert check(o, d, b, ab, nearp, far, step, cone) == int(g["cone_M"])
+    rng = np.random.default_rng(77)
+    for case in range(8):
+        levels = int(rng.integers(1, 5))
+        res = [int(rng.choice([8, 16, 30, 50]))] * 3 if case % 2 else [int(rng.choice([12, 32, 66])), 32, int(rng.choice([20, 48]))]
+        if case == 5:
+            res = [258, 255, 259]; levels = 1
+        if case == 3:
+            res = [8, 8, 8]; levels = 2                           # cells of 250+ steps: closed-form skips
+        n_rays = int(rng.integers(300, 1500))
+        b = rng.random((levels, *res)) < (0.03 if case == 3 else float(rng.choice([0.03, 0.2, 0.6])))
+        o = (rng.random((n_rays, 3)) * 3 - 1.5).astype(np.float32) * (0.3 if case % 2 else 1.0)
+        d = rng.standard_normal((n_rays, 3)).astype(np.float32)
+        d[rng.random(n_rays) < 0.1, int(rng.integers(0, 3))] = 0.0
+        d /= np.maximum(np.linalg.norm(d, axis=-1, keepdims=True), 1e-6)
+        est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=res, levels=levels).to(dev)
+        ab = est.aabbs.cpu().numpy()
+        near = (rng.random(n_rays) * 0.5).astype(np.float32) if case % 3 == 1 else np.full(n_rays, 0.05, np.float32)
+        far = (near + 0.5 + rng.random(n_rays) * 6).astype(np.float32) if case % 3 == 1 else np.full(n_rays, 1e10, np.float32)
+        step = 1e-3 if case == 3 else float(rng.choice([2e-3, 5e-3, 0.02]))
+        cone = float(rng.choice([0.004, 0.02, 1e-3]))
+        assert check(o, d, b, ab, near, far, step, cone) > 0, case
+    # nfa_fill_ray_indices alone: ragged counts with empty rays, and a window of more than 2^27 samples
+    from nerfacc_amd import _backend as B
+    for counts in (rng.integers(0, 700, 5000) * (rng.random(5000) < 0.7), np.array([3, 0, (1 << 27) + 5, 7, 0, 2])):
+        counts = counts.astype(np.int64)
+        starts = np.cumsum(counts) - counts
+        pi = T(np.stack([starts, counts], -1), dev)
+        out = torch.empty(int(counts.sum()), dtype=torch.int64, device=dev)
+        B.call("nfa_fill_ray_indices", len(counts), B.ptr(pi), B.ptr(out), B.stream())
+        ref = torch.repeat_interleave(torch.arange(len(counts), device=dev), T(counts, dev))
+        assert torch.equal(out, ref)
+        del out, ref
+
+
 # ----------------------------------------------------------------------------- pdf
 def test_importance_sampling_and_searchsorted(dev, oracle):
     g = load_golden("pdf")
@@ -635,6 +688,23 @@ def test_importance_sampling_and_searchsorted(dev, oracle):
     assert_close(s_sm.vals, e_sm, atol=1e-6, rtol=1e-6)                # same Philox stream as the oracle
     s2_iv, _ = na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), 16, stratified=True)
     assert not torch.equal(s_iv.vals, s2_iv.vals)                       # generator advanced
+    # s -> t mapping fused into the resampling: same intervals, and t rows bit-equal to the reference's tensor
+    # expression (estimators/prop_net.py:215-229) on them, for both mappings, short and long rows, packed input too
+    from nerfacc_amd.estimators.prop_net import _transform_stot
+    for kind, lo, hi in (("uniform", 2.0, 6.0), ("lindisp", 0.05, 1e3), ("lindisp", 0.2, 7.3)):
+        for S in (2, 16, 150):
+            p_iv, p_sm = na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), S)
+            f_iv, f_sm, f_ts, f_te = na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), S,
+                                                            transform=(kind, lo, hi))
+            assert torch.equal(p_iv.vals, f_iv.vals) and torch.equal(p_sm.vals, f_sm.vals)
+            t_ref = _transform_stot(kind, p_iv.vals, lo, hi)
+            assert f_ts.is_contiguous() and f_te.is_contiguous() and f_ts.shape == (33, S)
+            assert torch.equal(f_ts, t_ref[:, :-1]) and torch.equal(f_te, t_ref[:, 1:])
+    _, _, pk_ts, pk_te = na.importance_sampling(iv, torch.tensor([0.0, 0.5, 0.0, 0.5, 1.0], device=dev), 2,
+                                                transform=("uniform", 1.0, 3.0))
+    assert pk_ts.tolist() == [[1.0, 2.0], [1.0, 3.0]] and pk_te.tolist() == [[2.0, 3.0], [3.0, 5.0]]
+    with pytest.raises(ValueError):
+        na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), 4, transform=("log", 1.0, 2.0))
     with pytest.raises(ValueError):
         na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), 1)
     with pytest.raises(NotImplementedError):
