@@ -67,7 +67,7 @@ class PropNetEstimator(AbstractEstimator):
                 sigmas = level_fn(t_starts, t_ends)
                 assert sigmas.shape == t_starts.shape
                 trans, _ = render_transmittance_from_density(t_starts, t_ends, sigmas)
-                cdfs = 1.0 - torch.cat([trans, torch.zeros_like(trans[:, :1])], dim=-1)
+                cdfs = _cdfs_from_trans(trans)
                 if requires_grad:
                     self.prop_cache.append((intervals, cdfs))
         intervals, t_starts, t_ends = _resample(intervals, cdfs, num_samples, stratified, sampling_type, near_plane,
@@ -82,8 +82,7 @@ class PropNetEstimator(AbstractEstimator):
         if len(self.prop_cache) == 0:
             return torch.zeros((), device=self.device)
         intervals, _ = self.prop_cache.pop()
-        cdfs = 1.0 - torch.cat([trans, torch.zeros_like(trans[:, :1])], dim=-1)
-        cdfs = cdfs.detach()
+        cdfs = _cdfs_from_trans(trans.detach())
         loss = 0.0
         while self.prop_cache:
             prop_intervals, prop_cdfs = self.prop_cache.pop()
@@ -128,15 +127,39 @@ def get_proposal_requires_grad_fn(target: float = 5.0, num_steps: int = 1000) ->
     return proposal_requires_grad_fn
 
 
+class _CdfsFromTrans(torch.autograd.Function):
+    """``1 - cat([trans, 0], -1)`` (ref :104-107, :139-142) written into one buffer: the complement goes straight
+    into the first S columns and the backward is one negation of a view, instead of cat + zeros + rsub forward and
+    neg + slice copy backward (0.5 ms per cfg-3 step)."""
+
+    @staticmethod
+    def forward(ctx, trans: Tensor) -> Tensor:
+        S = trans.shape[-1]
+        cdfs = trans.new_empty((*trans.shape[:-1], S + 1))
+        torch.sub(1.0, trans, out=cdfs[..., :S])
+        cdfs[..., S] = 1.0
+        return cdfs
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        return torch.neg(g[..., :-1])
+
+
+def _cdfs_from_trans(trans: Tensor) -> Tensor:
+    if trans.requires_grad and torch.is_grad_enabled():
+        return _CdfsFromTrans.apply(trans)
+    return _CdfsFromTrans.forward(None, trans)
+
+
 def _resample(intervals: RayIntervals, cdfs: Tensor, n: int, stratified: bool, sampling_type: str, t_min, t_max):
     """One proposal level's resampling and s -> t mapping (ref :89-96, :120-125).  With scalar planes the mapping is
     fused into the resampling kernel; Tensor planes take the reference's tensor expression."""
     if isinstance(t_min, Tensor) or isinstance(t_max, Tensor):
-        intervals, _ = importance_sampling(intervals, cdfs, n, stratified)
+        intervals, _ = importance_sampling(intervals, cdfs, n, stratified, need_samples=False)
         t_vals = _transform_stot(sampling_type, intervals.vals, t_min, t_max)
         return intervals, t_vals[..., :-1], t_vals[..., 1:]
     intervals, _, t_starts, t_ends = importance_sampling(intervals, cdfs, n, stratified,
-                                                         transform=(sampling_type, t_min, t_max))
+                                                         transform=(sampling_type, t_min, t_max), need_samples=False)
     return intervals, t_starts, t_ends
 
 

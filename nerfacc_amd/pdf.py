@@ -61,6 +61,7 @@ def importance_sampling(
     n_intervals_per_ray: Union[Tensor, int],
     stratified: bool = False,
     transform: Optional[Tuple[str, float, float]] = None,
+    need_samples: bool = True,
 ) -> Tuple[RayIntervals, RaySamples]:
     """Inverse-transform resampling of each ray to ``n_intervals_per_ray`` intervals
     (ref: pdf.py:65-131; kernels cuda/csrc/pdf.cu:98-241).
@@ -68,7 +69,8 @@ def importance_sampling(
     ``transform=(type, t_min, t_max)`` (an extension used by ``PropNetEstimator.sampling``) additionally maps the
     new edges from s in [0,1] to metric distance in the same kernel and returns
     ``(intervals, samples, t_starts, t_ends)`` with contiguous ``(n_rays, n)`` rows; values are those of the
-    reference's tensor expression (estimators/prop_net.py:215-229), operation for operation.
+    reference's tensor expression (estimators/prop_net.py:215-229), operation for operation.  ``need_samples=False``
+    skips the sample centres (``None`` is returned in their place).
 
     With an int count the outputs are batched: ``intervals.vals`` (n_rays, n+1) and
     ``samples.vals`` (n_rays, n).  A per-ray Tensor count (packed outputs) is not functional in
@@ -99,13 +101,13 @@ def importance_sampling(
         assert pi is not None, "flattened intervals need packed_info"
         n_rays, per, lead = pi.shape[0], 0, (pi.shape[0],)
     out_iv = torch.empty((*lead, S + 1), dtype=torch.float32, device=dev)
-    out_sm = torch.empty((*lead, S), dtype=torch.float32, device=dev)
+    out_sm = torch.empty((*lead, S), dtype=torch.float32, device=dev) if need_samples else None
     seed, offset = _philox_seed_offset(dev) if stratified else (0, 0)
     if transform is None:
         with torch.cuda.device(dev):
             B.call("nfa_importance_sampling", B.ptr(vals), B.ptr(cdfs), B.ptr(pi), n_rays, per, S,
                    int(bool(stratified)), seed, offset, B.ptr(out_iv), B.ptr(out_sm), B.stream())
-        return RayIntervals(vals=out_iv), RaySamples(vals=out_sm)
+        return RayIntervals(vals=out_iv), (RaySamples(vals=out_sm) if need_samples else None)
     kind, t_min, t_max = transform
     if kind == "uniform":
         code, t_a, t_b = 1, float(t_min), float(t_max)
@@ -113,9 +115,10 @@ def importance_sampling(
         code, t_a, t_b = 2, 1 / float(t_min), 1 / float(t_max)  # reciprocals in double, rounded once, as Python does
     else:
         raise ValueError(f"Unknown transform_type: {kind}")
-    t_starts, t_ends = torch.empty_like(out_sm), torch.empty_like(out_sm)
+    t_starts = torch.empty((*lead, S), dtype=torch.float32, device=dev)
+    t_ends = torch.empty_like(t_starts)
     with torch.cuda.device(dev):
         B.call("nfa_importance_sampling_t", B.ptr(vals), B.ptr(cdfs), B.ptr(pi), n_rays, per, S,
                int(bool(stratified)), seed, offset, B.ptr(out_iv), B.ptr(out_sm), code, t_a, t_b, B.ptr(t_starts),
                B.ptr(t_ends), B.stream())
-    return RayIntervals(vals=out_iv), RaySamples(vals=out_sm), t_starts, t_ends
+    return RayIntervals(vals=out_iv), (RaySamples(vals=out_sm) if need_samples else None), t_starts, t_ends

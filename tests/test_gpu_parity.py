@@ -700,6 +700,8 @@ def test_importance_sampling_and_searchsorted(dev, oracle):
             t_ref = _transform_stot(kind, p_iv.vals, lo, hi)
             assert f_ts.is_contiguous() and f_te.is_contiguous() and f_ts.shape == (33, S)
             assert torch.equal(f_ts, t_ref[:, :-1]) and torch.equal(f_te, t_ref[:, 1:])
+    n_iv, n_sm = na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), 16, need_samples=False)
+    assert n_sm is None and torch.equal(n_iv.vals, na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), 16)[0].vals)
     _, _, pk_ts, pk_te = na.importance_sampling(iv, torch.tensor([0.0, 0.5, 0.0, 0.5, 1.0], device=dev), 2,
                                                 transform=("uniform", 1.0, 3.0))
     assert pk_ts.tolist() == [[1.0, 2.0], [1.0, 3.0]] and pk_te.tolist() == [[2.0, 3.0], [3.0, 5.0]]
