@@ -35,7 +35,7 @@ constexpr int EXP_QMAX = 1024;     // runs staged per batch (EXP_RPW * max_runs)
 #define NFA_EXP_WPB 2  /* measured on cfg 2: 1 wave 176 us, 2 waves 160 us, 4 waves 175 us */
 #endif
 constexpr int EXP_WPB = NFA_EXP_WPB;  // waves per workgroup of the expansion kernels (they never cooperate)
-constexpr int COARSE_LDS_WORDS = 8192;  // 32 KiB: up to 64^3 bricks (256^3 cells); next to the 32 KiB event lists
+constexpr int COARSE_LDS_WORDS = 2048;  // 8 KiB: up to 40^3 bricks (160^3 cells).  A larger mask in LDS costs occupancy: 256^3 (32 KiB) 1103 us in LDS, 634 us from L2
 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_bricks_kernel(const uint8_t *__restrict__ binaries, int32_t n_grids,
@@ -87,7 +87,16 @@ struct RunsParams {
 //   EV_OCC(thr)    emit steps while mid < thr              (grid.cu:207-262)
 //   EV_SPAN(thr)   start of a grid span: skip to thr only if the previous step was not emitted
 //                  (grid.cu:153-163, `if (!continuous)`)
-constexpr int EV_MAX = 32;  // measured on cfg2: 16 entries 630 us, 32 entries 566 us (fewer mid-walk flushes win over occupancy)
+#ifndef NFA_EV_MAX
+#define NFA_EV_MAX 24
+#endif
+constexpr int EV_MAX = NFA_EV_MAX;
+// Occupancy of the walk: 24 list entries (24 KiB per 256 rays) + the brick mask leave room for 5 workgroups per CU, and
+// the register allocator is asked for 5 waves per SIMD (96 VGPRs; 20 bytes of cold state spill).  Measured on cfg 2
+// (1 M rays = 16 waves per SIMD): 32 entries / 4 waves 330 us, 24 / 5: 307 us, 20 / 6: 311 us, 16 / 8: 348 us.
+#ifndef NFA_RUNS_WAVES
+#define NFA_RUNS_WAVES 5
+#endif
 enum { EV_EMPTY = 0, EV_OCC = 1, EV_SPAN = 2, EV_NONE = 3 };
 
 struct RunState {
@@ -261,6 +270,7 @@ __device__ __forceinline__ float min4_f32(float a, float b, float c, float d)
 // One ray = a loop of (phase 1: walk cells, opening the next span when one ends, until the event list is full or
 // the ray has no span left) + (phase 2: consume the list).  There is exactly ONE copy of each phase in the code.
 template <bool FUSED, bool COARSE_LDS>
+__attribute__((amdgpu_waves_per_eu(NFA_RUNS_WAVES, NFA_RUNS_WAVES)))
 __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, const RunsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
@@ -373,8 +383,11 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
                                         (int32_t)__umul24(__umul24(sp.cur[0] >> 2, p.by) + (sp.cur[1] >> 2), p.bz) + (sp.cur[2] >> 2);
                     if (bid != st.brick_id) {
                         st.brick_id = bid;
-                        const uint32_t cw = COARSE_LDS ? coarse_lds[bid >> 5] : p.coarse[bid >> 5];
-                        const unsigned long long w = ((cw >> (bid & 31)) & 1u) ? p.bricks[bid] : 0ull;
+                        // the 1-bit mask saves the 8-byte load for empty bricks when it sits in LDS; read from
+                        // global memory it would be a second, dependent access in front of the brick
+                        unsigned long long w;
+                        if (COARSE_LDS) w = ((coarse_lds[bid >> 5] >> (bid & 31)) & 1u) ? p.bricks[bid] : 0ull;
+                        else w = p.bricks[bid];
                         st.brick_lo = (uint32_t)w; st.brick_hi = (uint32_t)(w >> 32);
                     }
                     // bit ((x&3)<<4 | (y&3)<<2 | (z&3)) of the 64-bit brick word, on 32-bit halves
@@ -835,7 +848,9 @@ int nfa_traverse_runs(const nfa_traverse_args *pa, const uint64_t *bricks, const
     // differs bit-wise simply do not use the table.
     if (near_hint == near_hint) approach_table_build(p.approach, near_hint, a.step_size);
     else p.approach.n = 0;
-    const bool lds = p.n_coarse_words <= COARSE_LDS_WORDS;
+    int64_t lds_words = COARSE_LDS_WORDS;
+    if (const char *e = getenv("NFA_COARSE_LDS_WORDS")) lds_words = atol(e);  // tuning experiments
+    const bool lds = p.n_coarse_words <= lds_words;
     const size_t shmem = (size_t)EV_MAX * 256 * 4 + (lds ? (size_t)p.n_coarse_words * 4 : 0);
     const unsigned grid = grid_1d(a.n_rays, 256, 1 << 20);
     if (fused) {
