@@ -92,6 +92,14 @@ __device__ __forceinline__ float dpp_prev_lane(float old, float src)
 {
     return __int_as_float(dpp_prev_lane(__float_as_int(old), __float_as_int(src)));
 }
+// a * b + c on 24-bit unsigned operands as ONE full-rate instruction (hipcc turns __umul24(a, b) + c into the
+// quarter-rate 64-bit v_mad_u64_u32)
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ int32_t last_lane(int32_t v) { return __builtin_amdgcn_readlane(v, 63); }
 __device__ __forceinline__ float last_lane(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
 

@@ -171,7 +171,7 @@ __device__ __forceinline__ void traverse_span(const nfa_traverse_args &a, int64_
     // branches, and the brick word of the NEXT cell requested before the current cell is marched (the DDA does not
     // depend on the march), so that the load's latency overlaps the march.
     auto brick_of = [&](void) {
-        return brick_base + (int32_t)__umul24(__umul24(cur[0] >> 2, by) + (cur[1] >> 2), bz) + (cur[2] >> 2);
+        return brick_base + (int32_t)mad_u24(mad_u24((uint32_t)cur[0] >> 2, (uint32_t)by, (uint32_t)cur[1] >> 2), (uint32_t)bz, (uint32_t)cur[2] >> 2);
     };
     const bool use_bricks = a.bricks != nullptr;
     if (use_bricks) {

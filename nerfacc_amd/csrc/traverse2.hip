@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
                 bool span_done = false;
                 for (;;) {
                     const int32_t bid = sp.lvl_brick_base +
-                                        (int32_t)__umul24(__umul24(sp.cur[0] >> 2, p.by) + (sp.cur[1] >> 2), p.bz) + (sp.cur[2] >> 2);
+                                        (int32_t)mad_u24(mad_u24((uint32_t)sp.cur[0] >> 2, (uint32_t)p.by, (uint32_t)sp.cur[1] >> 2), (uint32_t)p.bz, (uint32_t)sp.cur[2] >> 2);
                     if (bid != st.brick_id) {
                         st.brick_id = bid;
                         // the 1-bit mask saves the 8-byte load for empty bricks when it sits in LDS; read from
@@ -804,6 +804,8 @@ int nfa_pack_bricks(const uint8_t *binaries, int32_t n_grids, const int32_t *res
     const int32_t bx = (res[0] + 3) / 4, by = (res[1] + 3) / 4, bz = (res[2] + 3) / 4;
     const int64_t nb = (int64_t)n_grids * bx * by * bz;
     NFA_REQUIRE(nb < ((int64_t)1 << 31), "pack_bricks: grid too large");
+    NFA_REQUIRE((int64_t)bx * by < ((int64_t)1 << 24) && bz < (1 << 24),
+                "pack_bricks: more than 2^24 bricks in an x-y slice (brick indices are formed with 24-bit multiplies)");
     hipStream_t s = as_stream(stream);
     if (hipMemsetAsync(coarse, 0, (size_t)((nb + 31) / 32) * 4, s) != hipSuccess) { set_error("pack_bricks: memset failed"); return NFA_EHIP; }
     hipLaunchKernelGGL(pack_bricks_kernel, dim3(grid_1d(nb, 256)), dim3(256), 0, s, binaries, n_grids, res[0], res[1], res[2],

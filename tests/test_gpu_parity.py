@@ -607,8 +607,8 @@ def test_sampler_cone_angle_bit_exact(dev, oracle):
         return ri.numel()
 
     assert check(o, d, b, ab, nearp, far, step, cone) == int(g["cone_M"])
-    rng = np.random.default_rng(77)
-    for case in range(8):
+    rng = np.random.default_rng(int(os.environ.get("NFA_FUZZ_SEED", "77")))            # soak runs: other seeds, more cases
+    for case in range(int(os.environ.get("NFA_FUZZ_CASES", "8"))):
         levels = int(rng.integers(1, 5))
         res = [int(rng.choice([8, 16, 30, 50]))] * 3 if case % 2 else [int(rng.choice([12, 32, 66])), 32, int(rng.choice([20, 48]))]
         if case == 5:
