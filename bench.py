@@ -17,6 +17,7 @@ across ranks (independent batches, weak scaling); the only collective is the all
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import math
 import os
@@ -370,6 +371,10 @@ def main():
     timer = None
     if not args.no_kernel_timing and rank == 0:
         timer = KernelTimer(); timer.install()
+    # As timeit does: no cyclic garbage collection of the host interpreter inside the timed region.  A generation-2
+    # pass (about one per 60 steps here, ~35 ms with torch loaded) would otherwise land in one of the two 40 ms loops
+    # at random and double its time; everything the step allocates is reference-counted and freed as usual.
+    gc.collect(); gc.disable()
     sync()
     t0 = time.perf_counter()
     m_last = 0
@@ -377,6 +382,7 @@ def main():
         m_last, _, _ = run_step(w, world)
     sync()
     dt = time.perf_counter() - t0
+    gc.enable()
     if timer is not None:
         ksum = timer.summary(args.steps); timer.uninstall()
     dt = max_over_ranks(dt, world, dev)
@@ -391,14 +397,17 @@ def main():
                                                        wait_for_inputs=False)
             for _ in range(max(2, args.warmup // 2)):
                 _, _, handle = run_step(w, world, handle, prefetch=True)
+            gc.collect(); gc.disable()
             sync()
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 _, _, handle = run_step(w, world, handle, prefetch=True)
             sync()
             dt_pipe = time.perf_counter() - t0
+            gc.enable()
         except Exception as e:  # the extra loop must never cost the headline line
             pipe_error = repr(e)
+            gc.enable()
         if world > 1:  # every rank takes part in the reduction, also after a local failure
             dt_pipe = max_over_ranks(dt_pipe if dt_pipe is not None else float("inf"), world, dev)
             if dt_pipe == float("inf"):

@@ -7,6 +7,7 @@ prints one JSON object per config with wall time per step and per-native-call HI
     python scripts/bench_configs.py [cfg3] [cfg5] [--steps K] [--warmup W] [--rays R]
 """
 import argparse
+import gc
 import json
 import math
 import os
@@ -26,12 +27,14 @@ def timed(fn, steps, warmup):
     for _ in range(warmup):
         fn()
     timer = bench.KernelTimer(); timer.install()
+    gc.collect(); gc.disable()   # as in bench.py: no interpreter GC pause inside the timed region
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         out = fn()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    gc.enable()
     ks = timer.summary(steps); timer.uninstall()
     return dt, ks, out
 
