@@ -377,7 +377,6 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
                     st.ev_span |= 1u << st.ev_cnt;  // the first cell always closes the EV_SPAN entry: its kind bit
                     in_span = true;
                 }
-                bool span_done = false;
                 for (;;) {
                     const int32_t bid = sp.lvl_brick_base +
                                         (int32_t)mad_u24(mad_u24((uint32_t)sp.cur[0] >> 2, (uint32_t)p.by, (uint32_t)sp.cur[1] >> 2), (uint32_t)p.bz, (uint32_t)sp.cur[2] >> 2);
@@ -409,10 +408,12 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
                     sp.cur[2] += s2 ? sp.step[2] : 0; sp.tdist[2] += s2 ? sp.delta[2] : 0.0f;
                     const bool hit_end = (s0 && sp.cur[0] == sp.overflow[0]) || (s1 && sp.cur[1] == sp.overflow[1]) ||
                                          (s2 && sp.cur[2] == sp.overflow[2]);
-                    span_done = hit_end || (--sp.cells_left <= 0);
-                    if (span_done || st.ev_cnt == EV_MAX) break;
+                    // the span ends when cells_left reaches 0 (one integer carries the exit reason out of the loop:
+                    // a bool would live in scalar lane masks and cost mask algebra on every cell)
+                    sp.cells_left = hit_end ? 0 : sp.cells_left - 1;
+                    if (sp.cells_left <= 0 || st.ev_cnt == EV_MAX) break;
                 }
-                if (span_done) in_span = false;
+                if (sp.cells_left <= 0) in_span = false;
                 if (st.ev_cnt == EV_MAX) break;
             }
             if (finished && st.open_type != EV_NONE) {
