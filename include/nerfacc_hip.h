@@ -153,6 +153,22 @@ int nfa_expand_runs(int64_t n_rays, float step_size, const int32_t *run_cnts, co
  * kernel does not scatter 8-byte indices (ref: grid.cu:247 writes them from the marching loop). */
 int nfa_fill_ray_indices(int64_t n_rays, const int64_t *packed_info /*[n_rays,2]*/, int64_t *ray_indices,
                          nfa_stream_t stream);
+/* Sampler path for distance-dependent steps (step_size > 0 and cone_angle > 0; ref grid.cu:207-262 recomputes
+ * dt = max(step, t * cone) for every sample, so samples are not arithmetic runs):
+ *   nfa_traverse_cone_runs  the count pass of nfa_traverse_grids (args->mode 0, samples only, no limit) that also leaves
+ *                           run records {t_first:f32 | k_start:31, continues_previous:1} in runs[max_runs][n_rays]
+ *                           (slot-major), one per chain of continuous samples and at least one per 64 samples; rays
+ *                           with more records are counted in *overflow_count and must be filled with
+ *                           nfa_traverse_grids(mode 1, ray_filter = run_cnts, ray_filter_min = max_runs);
+ *   nfa_expand_cone_runs    records + exclusive cumsum of the counts -> (t_starts, t_ends, ray_indices): every output
+ *                           re-runs the serial recurrence t <- t + max(step, t * cone) from its record's t_first (at
+ *                           most 63 steps), so the values are bit-identical to the marching loop's, and the second DDA
+ *                           walk of the fill pass is replaced by coalesced stores. */
+int nfa_traverse_cone_runs(const nfa_traverse_args *args, int32_t *run_cnts, uint64_t *runs, int32_t max_runs,
+                           int32_t *overflow_count, nfa_stream_t stream);
+int nfa_expand_cone_runs(int64_t n_rays, float step_size, float cone_angle, const int32_t *run_cnts,
+                         const uint64_t *runs, int32_t max_runs, const int64_t *packed_info, float *t_starts,
+                         float *t_ends, int64_t *ray_indices, nfa_stream_t stream);
 /* The interval stream of the API's traverse_grids from the same run records (ref: grid.cu:219-262; edge
  * values, ray_indices, is_left, is_right); iv_cnts as written by nfa_traverse_runs when args->iv_cnts is set
  * (edges = samples + one leading edge per chain of continuous samples), iv_packed_info its {start, count} rows. */

@@ -75,7 +75,20 @@ __global__ __launch_bounds__(256) void ray_aabb_kernel(const float *__restrict__
 
 // calc_dt / fast_forward: march.h (exact O(#binades) form of the loops at grid.cu:153-163, :196-205)
 
-enum { EMIT_NONE = 0, EMIT_API = 1, EMIT_DIRECT = 2 };
+enum { EMIT_NONE = 0, EMIT_API = 1, EMIT_DIRECT = 2, EMIT_RUNS = 3 };
+
+// EMIT_RUNS: a count pass that also leaves run records (same format as traverse2.hip's: {t_first : f32 | k_start : 31,
+// continues_previous : 1}, slot-major).  With a cone angle a chain of samples is the recurrence t <- t + max(step,
+// t * cone) from its first distance, so {t_first, k_start} determines every sample of it; chains are cut every
+// CONE_RUN_CAP samples so that the expansion (expand_runs_kernel<EXP_CONE>) iterates the recurrence at most that often
+// per output.  The second walk of the fill pass becomes a coalesced expansion.
+constexpr int CONE_RUN_CAP = 64;
+struct RunOut {
+    int32_t *run_cnts;          // [n_rays]
+    unsigned long long *runs;   // [max_runs, n_rays]
+    int32_t max_runs;
+    int32_t *overflow;          // [1]
+};
 
 struct RayState {
     float t_last;
@@ -84,6 +97,7 @@ struct RayState {
     int32_t n_samples;
     int32_t brick_id;       // brick cache (when the brick-packed grid is given)
     uint32_t brick_lo, brick_hi;
+    int32_t n_runs, run_len;  // EMIT_RUNS: records written, samples in the open record
 };
 
 // One [this_tmin, this_tmax) span inside grid `level`.
@@ -91,7 +105,7 @@ template <int EMIT, bool HAS_IV, bool HAS_SM>
 __device__ __forceinline__ void traverse_span(const nfa_traverse_args &a, int64_t tid, const float o[3],
                                               const float d[3], const float inv[3], int32_t level,
                                               float this_tmin, float this_tmax, int64_t iv_base,
-                                              int64_t sm_base, RayState &st)
+                                              int64_t sm_base, RayState &st, const RunOut &ro)
 {
     const float eps = 1e-6f;  // grid.cu:95
     const float step_size = a.step_size, cone = a.cone_angle;
@@ -130,6 +144,17 @@ __device__ __forceinline__ void traverse_span(const nfa_traverse_args &a, int64_
 
     // one sample [t_last, t_next) (grid.cu:219-258)
     auto emit = [&](float t_next) {
+        if (EMIT == EMIT_RUNS) {
+            const bool cut = !st.continuous || st.run_len == CONE_RUN_CAP;
+            if (cut) {
+                if (st.n_runs < ro.max_runs)
+                    ro.runs[(int64_t)st.n_runs * a.n_rays + tid] =
+                        (unsigned long long)f32_bits(st.t_last) |
+                        ((unsigned long long)((uint32_t)st.n_samples | (st.continuous ? 0x80000000u : 0u)) << 32);
+                st.n_runs++;
+            }
+            st.run_len = cut ? 1 : st.run_len + 1;
+        }
         if (HAS_IV) {
             if (EMIT == EMIT_API) {
                 // Both mask bytes of every edge are written (the reference zero-fills the
@@ -248,7 +273,7 @@ template <int EMIT, bool HAS_IV, bool HAS_SM, bool FUSED>
 #ifdef NFA_TRAVERSE_WAVES
 __attribute__((amdgpu_waves_per_eu(NFA_TRAVERSE_WAVES, 8)))
 #endif
-__global__ __launch_bounds__(256) void traverse_kernel(const nfa_traverse_args a)
+__global__ __launch_bounds__(256) void traverse_kernel(const nfa_traverse_args a, const RunOut ro)
 {
     for (int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tid < a.n_rays;
          tid += (int64_t)blockDim.x * gridDim.x) {
@@ -262,7 +287,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(const nfa_traverse_args a
         }
         if (a.ray_filter != nullptr && a.ray_filter[tid] <= a.ray_filter_min) continue;
         int64_t iv_base = 0, sm_base = 0;
-        if (EMIT != EMIT_NONE) {
+        if (EMIT != EMIT_NONE && EMIT != EMIT_RUNS) {
             if (a.mode == 1) {  // grid.cu:103-106: nothing to fill for empty rays
                 if (HAS_IV && a.iv_cnts[tid] == 0) continue;
                 if (HAS_SM && a.sm_cnts[tid] == 0) continue;
@@ -281,6 +306,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(const nfa_traverse_args a
         st.n_intervals = 0;
         st.n_samples = 0;
         st.brick_id = -1; st.brick_lo = st.brick_hi = 0u;
+        st.n_runs = 0; st.run_len = 0;
 
         if (FUSED) {
             // grid.py:158-162 with one grid: events are (t_min: enter 0), (t_max: leave 0).
@@ -291,7 +317,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(const nfa_traverse_args a
                 const float this_tmax = fminf(tmax, far_plane);
                 if (this_tmin < this_tmax)
                     traverse_span<EMIT, HAS_IV, HAS_SM>(a, tid, o, d, inv, 0, this_tmin, this_tmax, iv_base,
-                                                        sm_base, st);
+                                                        sm_base, st, ro);
             }
         } else {
             const int32_t G = a.n_grids;
@@ -313,23 +339,29 @@ __global__ __launch_bounds__(256) void traverse_kernel(const nfa_traverse_args a
                 const float this_tmax = fminf(ts[i + 1], far_plane);
                 if (this_tmin >= this_tmax) continue;
                 traverse_span<EMIT, HAS_IV, HAS_SM>(a, tid, o, d, inv, level, this_tmin, this_tmax, iv_base,
-                                                    sm_base, st);
+                                                    sm_base, st, ro);
             }
         }
         if (a.terminate_planes) a.terminate_planes[tid] = st.t_last;
-        if (EMIT == EMIT_NONE || overalloc) {
+        if (EMIT == EMIT_NONE || EMIT == EMIT_RUNS || overalloc) {
             if (HAS_IV) a.iv_cnts[tid] = st.n_intervals;
             if (HAS_SM) a.sm_cnts[tid] = st.n_samples;
+        }
+        if (EMIT == EMIT_RUNS) {
+            // rays with > 2^21 samples go to the serial fill (the expansion packs a 27-bit batch offset)
+            if (st.n_samples > (1 << 21) && st.n_runs <= ro.max_runs) st.n_runs = ro.max_runs + 1;
+            ro.run_cnts[tid] = st.n_runs;
+            if (st.n_runs > ro.max_runs) atomicAdd(ro.overflow, 1);
         }
     }
 }
 
 template <int EMIT, bool HAS_IV, bool HAS_SM>
-static void launch_traverse(const nfa_traverse_args &a, bool fused, hipStream_t s)
+static void launch_traverse(const nfa_traverse_args &a, bool fused, hipStream_t s, const RunOut ro = RunOut{})
 {
     const unsigned grid = grid_1d(a.n_rays, 256, 1 << 20);
-    if (fused) hipLaunchKernelGGL((traverse_kernel<EMIT, HAS_IV, HAS_SM, true>), dim3(grid), dim3(256), 0, s, a);
-    else       hipLaunchKernelGGL((traverse_kernel<EMIT, HAS_IV, HAS_SM, false>), dim3(grid), dim3(256), 0, s, a);
+    if (fused) hipLaunchKernelGGL((traverse_kernel<EMIT, HAS_IV, HAS_SM, true>), dim3(grid), dim3(256), 0, s, a, ro);
+    else       hipLaunchKernelGGL((traverse_kernel<EMIT, HAS_IV, HAS_SM, false>), dim3(grid), dim3(256), 0, s, a, ro);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -591,6 +623,36 @@ int nfa_traverse_grids(const nfa_traverse_args *pa, nfa_stream_t stream)
         }
     }
     NFA_CHECK_LAUNCH("traverse_grids");
+    return NFA_OK;
+}
+
+int nfa_traverse_cone_runs(const nfa_traverse_args *pa, int32_t *run_cnts, uint64_t *runs, int32_t max_runs,
+                           int32_t *overflow_count, nfa_stream_t stream)
+{
+    NFA_REQUIRE(pa != nullptr, "traverse_cone_runs: null args");
+    const nfa_traverse_args &a = *pa;
+    NFA_REQUIRE(a.n_rays >= 0 && a.n_rays < (int64_t)1 << 31, "traverse_cone_runs: n_rays out of range");
+    NFA_REQUIRE(overflow_count, "traverse_cone_runs: overflow_count is null");
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(overflow_count, 0, sizeof(int32_t), s) != hipSuccess) { set_error("traverse_cone_runs: memset failed"); return NFA_EHIP; }
+    if (a.n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(a.step_size > 0.0f && a.cone_angle > 0.0f, "traverse_cone_runs: needs step_size > 0 and cone_angle > 0");
+    NFA_REQUIRE(a.mode == 0 && a.traverse_steps_limit <= 0, "traverse_cone_runs: mode must be 0 and no traverse_steps_limit");
+    NFA_REQUIRE(a.rays_o && a.rays_d && a.binaries && a.aabbs && a.near_planes && a.far_planes && a.sm_cnts && !a.iv_cnts &&
+                    run_cnts && runs, "traverse_cone_runs: null pointer (or interval outputs requested)");
+    NFA_REQUIRE(max_runs >= 1 && max_runs <= 32, "traverse_cone_runs: max_runs must be in [1, 32]");
+    NFA_REQUIRE(a.n_grids >= 1 && a.res[0] > 0 && a.res[1] > 0 && a.res[2] > 0, "traverse_cone_runs: bad grid shape");
+    NFA_REQUIRE((int64_t)a.res[0] * a.res[1] * a.res[2] < (int64_t)1 << 31, "traverse_cone_runs: grid level too large");
+    const bool fused = !a.t_sorted && !a.t_indices && !a.hits;
+    NFA_REQUIRE(fused || (a.t_sorted && a.t_indices && a.hits), "traverse_cone_runs: t_sorted, t_indices and hits must be given together");
+    NFA_REQUIRE(!fused || a.n_grids == 1, "traverse_cone_runs: in-kernel intersection supports one grid");
+    RunOut ro;
+    ro.run_cnts = run_cnts;
+    ro.runs = reinterpret_cast<unsigned long long *>(runs);
+    ro.max_runs = max_runs;
+    ro.overflow = overflow_count;
+    launch_traverse<EMIT_RUNS, false, true>(a, fused, s, ro);
+    NFA_CHECK_LAUNCH("traverse_cone_runs");
     return NFA_OK;
 }
 

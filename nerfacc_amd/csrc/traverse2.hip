@@ -443,13 +443,14 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
 // (t_first = NaN) so that its output range is skipped (the serial kernel fills it).  Outputs are then
 // produced chunk by chunk (256 per step, 16 B per lane and array) with a scatter + "most recent entry"
 // scan that tells every output its run.
-enum { EXP_STARTS_ENDS = 0, EXP_MIDS = 1 /* the API's sample centres */, EXP_RAY_INDICES = 2 /* ray_indices only, from packed_info alone */ };
+enum { EXP_STARTS_ENDS = 0, EXP_MIDS = 1 /* the API's sample centres */, EXP_RAY_INDICES = 2 /* ray_indices only, from packed_info alone */,
+       EXP_CONE = 3 /* (t_starts, t_ends) of cone-angle chains: the recurrence t <- t + max(step, t * cone) from the record's t_first */ };
 template <int MODE>
 __global__ __launch_bounds__(64 * EXP_WPB) void expand_runs_kernel(int64_t n_rays, float dt, const int32_t *__restrict__ run_cnts,
                                                           const unsigned long long *__restrict__ runs, int32_t max_runs,
                                                           const longlong2 *__restrict__ packed_info,
                                                           float *__restrict__ t_starts, float *__restrict__ t_ends,
-                                                          float *__restrict__ t_mids, int64_t *__restrict__ ray_indices, int vec)
+                                                          float *__restrict__ t_mids, int64_t *__restrict__ ray_indices, int vec, float cone)
 {
     __shared__ uint32_t s_pos[EXP_WPB][EXP_QMAX];
     __shared__ float s_t0[EXP_WPB][EXP_QMAX];
@@ -583,11 +584,24 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_runs_kernel(int64_t n_ray
                     if (t0 != t0) continue;  // sentinel: overflowed ray, filled by the serial kernel
                     const uint32_t e = pos[j];
                     const uint32_t kk = (uint32_t)(pa - W0) - (e & 0x7FFFFFFu);
-                    const float inc = (t0 + dt) - t0;  // the run's exact per-step increment
-                    // t0 + k * inc is exactly representable for every sample of a run (that is what makes it a run),
-                    // so one fused multiply-add (single rounding of the exact value) reproduces the serial sums
-                    ts4[k] = __builtin_fmaf((float)kk, inc, t0);
-                    te4[k] = __builtin_fmaf((float)(kk + 1), inc, t0);
+                    if (MODE == EXP_CONE) {
+                        // the serial loop's own arithmetic (grid.cu:213-216: dt = calc_dt(t_last), t_next = t_last + dt);
+                        // inside a record the previous element's end is this element's start
+                        if (k > 0 && valid[k - 1] && j4[k - 1] == j) {
+                            ts4[k] = te4[k - 1];
+                        } else {
+                            float t = t0;
+                            for (uint32_t i = 0; i < kk; ++i) t = t + calc_dt(t, cone, dt);
+                            ts4[k] = t;
+                        }
+                        te4[k] = ts4[k] + calc_dt(ts4[k], cone, dt);
+                    } else {
+                        const float inc = (t0 + dt) - t0;  // the run's exact per-step increment
+                        // t0 + k * inc is exactly representable for every sample of a run (that is what makes it a run),
+                        // so one fused multiply-add (single rounding of the exact value) reproduces the serial sums
+                        ts4[k] = __builtin_fmaf((float)kk, inc, t0);
+                        te4[k] = __builtin_fmaf((float)(kk + 1), inc, t0);
+                    }
                     ri4[k] = r0 + (e >> 27);
                     valid[k] = true;
                 }
@@ -598,7 +612,7 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_runs_kernel(int64_t n_ray
                 if (vec && valid[0] && valid[1] && valid[2] && valid[3]) {
                     if (MODE == EXP_MIDS) {
                         *reinterpret_cast<float4 *>(t_mids + p0) = make_float4(ts4[0], ts4[1], ts4[2], ts4[3]);
-                    } else if (MODE == EXP_STARTS_ENDS) {
+                    } else if (MODE == EXP_STARTS_ENDS || MODE == EXP_CONE) {
                         *reinterpret_cast<float4 *>(t_starts + p0) = make_float4(ts4[0], ts4[1], ts4[2], ts4[3]);
                         *reinterpret_cast<float4 *>(t_ends + p0) = make_float4(te4[0], te4[1], te4[2], te4[3]);
                     }
@@ -610,7 +624,7 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_runs_kernel(int64_t n_ray
                     for (int k = 0; k < 4; ++k)
                         if (valid[k]) {
                             if (MODE == EXP_MIDS) t_mids[p0 + k] = ts4[k];
-                            else if (MODE == EXP_STARTS_ENDS) { t_starts[p0 + k] = ts4[k]; t_ends[p0 + k] = te4[k]; }
+                            else if (MODE == EXP_STARTS_ENDS || MODE == EXP_CONE) { t_starts[p0 + k] = ts4[k]; t_ends[p0 + k] = te4[k]; }
                             ray_indices[p0 + k] = ri4[k];
                         }
                 }
@@ -883,12 +897,31 @@ int nfa_expand_runs(int64_t n_rays, float step_size, const int32_t *run_cnts, co
     if (t_mids)
         hipLaunchKernelGGL(expand_runs_kernel<EXP_MIDS>, dim3(grid), dim3(64 * EXP_WPB), 0, as_stream(stream), n_rays, step_size, run_cnts,
                            reinterpret_cast<const unsigned long long *>(runs), max_runs,
-                           reinterpret_cast<const longlong2 *>(packed_info), t_starts, t_ends, t_mids, ray_indices, vec);
+                           reinterpret_cast<const longlong2 *>(packed_info), t_starts, t_ends, t_mids, ray_indices, vec, 0.0f);
     else
         hipLaunchKernelGGL(expand_runs_kernel<EXP_STARTS_ENDS>, dim3(grid), dim3(64 * EXP_WPB), 0, as_stream(stream), n_rays, step_size, run_cnts,
                            reinterpret_cast<const unsigned long long *>(runs), max_runs,
-                           reinterpret_cast<const longlong2 *>(packed_info), t_starts, t_ends, t_mids, ray_indices, vec);
+                           reinterpret_cast<const longlong2 *>(packed_info), t_starts, t_ends, t_mids, ray_indices, vec, 0.0f);
     NFA_CHECK_LAUNCH("expand_runs");
+    return NFA_OK;
+}
+
+int nfa_expand_cone_runs(int64_t n_rays, float step_size, float cone_angle, const int32_t *run_cnts, const uint64_t *runs,
+                         int32_t max_runs, const int64_t *packed_info, float *t_starts, float *t_ends, int64_t *ray_indices,
+                         nfa_stream_t stream)
+{
+    NFA_REQUIRE(n_rays >= 0, "expand_cone_runs: negative n_rays");
+    if (n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(run_cnts && runs && packed_info && ray_indices && t_starts && t_ends, "expand_cone_runs: null pointer");
+    NFA_REQUIRE(max_runs >= 1 && max_runs * EXP_RPW <= EXP_QMAX, "expand_cone_runs: max_runs must be in [1, 32]");
+    NFA_REQUIRE(step_size > 0.0f && cone_angle > 0.0f, "expand_cone_runs: step_size and cone_angle must be > 0");
+    const int vec = ((reinterpret_cast<uintptr_t>(t_starts) | reinterpret_cast<uintptr_t>(t_ends) |
+                      reinterpret_cast<uintptr_t>(ray_indices)) & 15) == 0;
+    const unsigned grid = grid_1d(ceil_div64(n_rays, EXP_RPW) * 64, 64 * EXP_WPB, 1 << 22);
+    hipLaunchKernelGGL(expand_runs_kernel<EXP_CONE>, dim3(grid), dim3(64 * EXP_WPB), 0, as_stream(stream), n_rays, step_size, run_cnts,
+                       reinterpret_cast<const unsigned long long *>(runs), max_runs,
+                       reinterpret_cast<const longlong2 *>(packed_info), t_starts, t_ends, nullptr, ray_indices, vec, cone_angle);
+    NFA_CHECK_LAUNCH("expand_cone_runs");
     return NFA_OK;
 }
 
@@ -901,7 +934,7 @@ int nfa_fill_ray_indices(int64_t n_rays, const int64_t *packed_info, int64_t *ra
     const unsigned grid = grid_1d(ceil_div64(n_rays, EXP_RPW) * 64, 64 * EXP_WPB, 1 << 22);
     hipLaunchKernelGGL(expand_runs_kernel<EXP_RAY_INDICES>, dim3(grid), dim3(64 * EXP_WPB), 0, as_stream(stream), n_rays, 0.0f,
                        nullptr, nullptr, 1, reinterpret_cast<const longlong2 *>(packed_info), nullptr, nullptr, nullptr,
-                       ray_indices, vec);
+                       ray_indices, vec, 0.0f);
     NFA_CHECK_LAUNCH("fill_ray_indices");
     return NFA_OK;
 }

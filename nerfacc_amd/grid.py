@@ -9,6 +9,7 @@ reference's two.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -279,6 +280,9 @@ def _get_bricks(binaries: Tensor):
     return bricks, coarse
 
 
+CONE_RUNS = os.environ.get("NERFACC_AMD_CONE_RUNS", "1") != "0"   # 0: the serial count + fill passes (A/B testing)
+
+
 @torch.no_grad()
 def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size, cone_angle,
                       rays_mask=None, traverse_steps_limit=None, t_sorted=None, t_indices=None, hits=None,
@@ -298,6 +302,8 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
     """
     limit = -1 if traverse_steps_limit is None else int(traverse_steps_limit)
     use_runs = float(step_size) > 0.0 and float(cone_angle) == 0.0
+    # distance-dependent steps: run records from the count pass + a coalesced expansion instead of a second walk
+    use_cone_runs = CONE_RUNS and float(step_size) > 0.0 and float(cone_angle) > 0.0
     if not use_runs and (rays_mask is not None or limit > 0):
         # marching with a cone angle / per-cell mode: the reference's route (over-allocate + compaction)
         iv, sm, term = traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size, cone_angle,
@@ -325,6 +331,11 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
             # near_hint: the scalar near plane when the caller built near_planes from one (accelerator only)
             B.call("nfa_traverse_runs", C.byref(a), B.ptr(bricks), B.ptr(coarse), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
                    B.ptr(meta[1:2]), float("nan") if near_hint is None else float(near_hint), B.stream())
+        elif use_cone_runs:
+            _get_bricks(binaries)
+            run_cnts = torch.empty(n_rays, dtype=torch.int32, device=dev)
+            runs = torch.empty((MAX_RUNS, n_rays), dtype=torch.int64, device=dev)
+            B.call("nfa_traverse_cone_runs", C.byref(a), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS, B.ptr(meta[1:2]), B.stream())
         else:
             _launch(a)
         packed_info = _cumsum_packed(sm_cnts, meta[0:1])
@@ -336,13 +347,16 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
             if use_runs:
                 B.call("nfa_expand_runs", n_rays, float(step_size), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
                        B.ptr(packed_info), B.ptr(t_starts), B.ptr(t_ends), None, B.ptr(ray_indices), B.stream())
-            if not use_runs or n_overflow > 0:
+            elif use_cone_runs:
+                B.call("nfa_expand_cone_runs", n_rays, float(step_size), float(cone_angle), B.ptr(run_cnts), B.ptr(runs),
+                       MAX_RUNS, B.ptr(packed_info), B.ptr(t_starts), B.ptr(t_ends), B.ptr(ray_indices), B.stream())
+            if not (use_runs or use_cone_runs) or n_overflow > 0:
                 a.mode = 1
                 a.terminate_planes = None
                 sm_starts = packed_info[:, 0].contiguous()
                 a.sm_starts = B.ptr(sm_starts)
                 a.sm_t_starts, a.sm_t_ends = B.ptr(t_starts), B.ptr(t_ends)
-                if use_runs:  # only the rays whose runs did not fit (their counts already honour mask and limit)
+                if use_runs or use_cone_runs:  # only the rays whose runs did not fit (their counts already honour mask and limit)
                     a.sm_ray_indices = B.ptr(ray_indices)
                     a.ray_filter, a.ray_filter_min = B.ptr(run_cnts), MAX_RUNS
                     _launch(a)

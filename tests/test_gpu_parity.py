@@ -591,8 +591,10 @@ def test_sampler_odd_resolution_global_brick_mask(dev, oracle):
 def test_sampler_cone_angle_bit_exact(dev, oracle):
     """Distance-dependent steps (cone_angle > 0) in the sampler == the oracle's serial two-pass traversal, bit for bit:
     single grid with in-kernel intersection, nested levels with unrelated rays, resolutions that are not multiples of
-    4, cells much larger than the step (closed-form skips), zero direction components, per-ray near / far planes;
-    ray_indices come from the coalesced fill (nfa_fill_ray_indices), also for a ray of millions of samples."""
+    4, cells much larger than the step (closed-form skips), zero direction components, per-ray near / far planes.
+    The sampler's path is run records from the count pass + the recurrence expansion (nfa_traverse_cone_runs,
+    nfa_expand_cone_runs), with the serial fill for rays of more than 32 records; it is also compared with the serial
+    count + fill passes (ray_indices from nfa_fill_ray_indices, also for a ray of millions of samples)."""
     g = load_golden("traversal")
     o, d, b, ab, nearp, step, cone = seeded_case(g["cone_params"])
     assert cone > 0
@@ -628,6 +630,31 @@ def test_sampler_cone_angle_bit_exact(dev, oracle):
         step = 1e-3 if case == 3 else float(rng.choice([2e-3, 5e-3, 0.02]))
         cone = float(rng.choice([0.004, 0.02, 1e-3]))
         assert check(o, d, b, ab, near, far, step, cone) > 0, case
+    # rays with more than 32 records (checkerboard: a chain per cell) take the serial fill; and a training-sized batch
+    # of unrelated rays through 4 levels, run records + expansion against the serial count + fill passes
+    ii = np.indices((48, 48, 48)).sum(0)
+    b = np.broadcast_to(ii % 2 == 0, (2, 48, 48, 48)).copy()
+    est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=48, levels=2).to(dev)
+    o = (rng.random((700, 3)) * 2 - 1).astype(np.float32)
+    d = rng.standard_normal((700, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    assert check(o, d, b, est.aabbs.cpu().numpy(), np.full(700, 0.05, np.float32), np.full(700, 1e10, np.float32), 4e-3, 0.004) > 0
+    n_rays, levels, res = 40000, 4, 64
+    b = T(rng.random((levels, res, res, res)) < 0.1, dev)
+    o = T((rng.random((n_rays, 3)) - 0.5).astype(np.float32), dev)
+    d = rng.standard_normal((n_rays, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=res, levels=levels).to(dev)
+    args = (o, T(d, dev), b, est.aabbs, torch.full((n_rays,), 0.2, device=dev), torch.full((n_rays,), 1e10, device=dev),
+            2e-3, 0.004)
+    assert na.grid.CONE_RUNS
+    new = na.grid._traverse_samples(*args, return_terminate=True)
+    na.grid.CONE_RUNS = False
+    try:
+        old = na.grid._traverse_samples(*args, return_terminate=True)
+    finally:
+        na.grid.CONE_RUNS = True
+    assert new[0].numel() > 1_000_000
+    for x, y in zip(new, old):
+        assert torch.equal(x, y)
     # nfa_fill_ray_indices alone: ragged counts with empty rays, and a window of more than 2^27 samples
     from nerfacc_amd import _backend as B
     for counts in (rng.integers(0, 700, 5000) * (rng.random(5000) < 0.7), np.array([3, 0, (1 << 27) + 5, 7, 0, 2])):
