@@ -421,12 +421,24 @@ __global__ __launch_bounds__(CS_THREADS) void cumsum_spine_kernel(int64_t *parti
 
 // out_starts[i*out_stride] = exclusive prefix; optionally copies the counts next to it
 // (pairs != 0 writes packed_info rows {start, count}).
+// SPINE: `partials` holds the raw per-block sums and every workgroup adds up the ones before it by itself (a few
+// loads per thread from L2) instead of waiting for a one-workgroup spine kernel in between: two launches, not three.
+template <bool SPINE>
 __global__ __launch_bounds__(CS_THREADS) void cumsum_final_kernel(const int64_t *__restrict__ in, int64_t n,
                                                                    int64_t in_stride,
                                                                    const int64_t *__restrict__ partials,
-                                                                   int64_t *__restrict__ out, int pairs)
+                                                                   int64_t *__restrict__ out, int pairs,
+                                                                   int64_t *__restrict__ total)
 {
     __shared__ int64_t lds[8];
+    int64_t block_off = 0;
+    if (SPINE) {
+        int64_t before = 0;
+        for (int64_t j = threadIdx.x; j < (int64_t)blockIdx.x; j += CS_THREADS) before += partials[j];
+        block_excl_scan_i64(before, block_off, lds);  // block_off = sum over the workgroup
+    } else {
+        block_off = partials[blockIdx.x];
+    }
     const int64_t base = (int64_t)blockIdx.x * CS_BLOCK + (int64_t)threadIdx.x * CS_ITEMS;
     int64_t v[CS_ITEMS];
     int64_t s = 0;
@@ -436,7 +448,8 @@ __global__ __launch_bounds__(CS_THREADS) void cumsum_final_kernel(const int64_t 
         s += v[k];
     }
     int64_t tot;
-    int64_t run = partials[blockIdx.x] + block_excl_scan_i64(s, tot, lds);
+    int64_t run = block_off + block_excl_scan_i64(s, tot, lds);
+    if (SPINE && total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = block_off + tot;
 #pragma unroll
     for (int k = 0; k < CS_ITEMS; ++k) {
         if (base + k < n) {
@@ -453,8 +466,14 @@ static int run_cumsum(const int64_t *in, int64_t n, int64_t in_stride, int64_t *
     const int64_t n_blocks = ceil_div64(n > 0 ? n : 1, CS_BLOCK);
     int64_t *partials = reinterpret_cast<int64_t *>(scratch);
     hipLaunchKernelGGL(cumsum_partials_kernel, dim3((unsigned)n_blocks), dim3(CS_THREADS), 0, s, in, n, in_stride, partials);
-    hipLaunchKernelGGL(cumsum_spine_kernel, dim3(1), dim3(CS_THREADS), 0, s, partials, n_blocks, total);
-    hipLaunchKernelGGL(cumsum_final_kernel, dim3((unsigned)n_blocks), dim3(CS_THREADS), 0, s, in, n, in_stride, partials, out, pairs);
+    if (n_blocks <= 2048) {  // up to 4 M elements: 8 partials per thread at most
+        hipLaunchKernelGGL(cumsum_final_kernel<true>, dim3((unsigned)n_blocks), dim3(CS_THREADS), 0, s, in, n, in_stride, partials,
+                           out, pairs, total);
+    } else {
+        hipLaunchKernelGGL(cumsum_spine_kernel, dim3(1), dim3(CS_THREADS), 0, s, partials, n_blocks, total);
+        hipLaunchKernelGGL(cumsum_final_kernel<false>, dim3((unsigned)n_blocks), dim3(CS_THREADS), 0, s, in, n, in_stride, partials,
+                           out, pairs, nullptr);
+    }
     NFA_CHECK_LAUNCH("exclusive_cumsum_i64");
     return NFA_OK;
 }

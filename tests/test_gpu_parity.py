@@ -34,6 +34,21 @@ def test_native_library_is_loaded(dev):
 
 
 # ----------------------------------------------------------------------------- pack / scans
+def test_exclusive_cumsum_i64(dev):
+    """nfa_exclusive_cumsum_i64 / _pairs_i64 vs torch.cumsum: empty, one element, block edges, the two-launch form
+    (every workgroup adds up the partial sums before it) and, beyond 4 M elements, the three-launch form with a spine."""
+    g = torch.Generator(device=dev); g.manual_seed(9)
+    for n in (0, 1, 2047, 2048, 2049, 333_333, 1 << 20, (1 << 22) + 4097):
+        cnts = torch.randint(0, 1000, (n,), generator=g, device=dev, dtype=torch.int64)
+        total = torch.full((1,), -7, dtype=torch.int64, device=dev)
+        starts = na.grid._exclusive_cumsum(cnts, total)
+        ref = torch.cumsum(cnts, 0) - cnts
+        assert torch.equal(starts, ref) and int(total) == int(cnts.sum())
+        total.fill_(-7)
+        packed = na.grid._cumsum_packed(cnts, total)
+        assert torch.equal(packed[:, 0], ref) and torch.equal(packed[:, 1], cnts) and int(total) == int(cnts.sum())
+
+
 def test_pack_info(dev, oracle):
     # tests/test_pack.py:8-18
     ri = torch.tensor([0, 2, 2, 2, 2], dtype=torch.int64, device=dev)
