@@ -209,23 +209,43 @@ def init_distributed(backend: str, device=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not torch.distributed.is_initialized():
+    # under torchrun the process group is created also for a single rank, so that `--nproc-per-node 1` exercises the
+    # same RCCL calls (init, all_reduce, barrier) as the multi-GPU launch
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ
+    if (world > 1 or launched) and not torch.distributed.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
-        torch.distributed.init_process_group(backend=backend, **kw)
+        # librccl prints a "Librccl path : ..." banner to STDOUT when its communicator is created; stdout carries the
+        # one JSON line, so file descriptor 1 points at stderr while the group and its first collective are set up
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            torch.distributed.init_process_group(backend=backend, **kw)
+            if backend == "nccl":
+                torch.distributed.barrier()
+                torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     return world, rank, local_rank
 
 
 def allreduce_grads(params, world: int):
     """Rays are independent, so ranks own disjoint ray batches and the only exchange is the SUM of
     the (tiny) parameter gradient: d/dp sum_over_all_rays = sum over ranks of the local gradient."""
-    if world > 1:
+    if world > 1 or _group_live():
         for p in params:
             torch.distributed.all_reduce(p.grad, op=torch.distributed.ReduceOp.SUM)
 
 
+def _group_live() -> bool:
+    return torch.distributed.is_available() and torch.distributed.is_initialized()
+
+
 def max_over_ranks(seconds: float, world: int, device="cpu") -> float:
-    if world == 1:
+    if world == 1 and not _group_live():
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -362,7 +382,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or _group_live():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
@@ -408,7 +428,7 @@ def main():
         except Exception as e:  # the extra loop must never cost the headline line
             pipe_error = repr(e)
             gc.enable()
-        if world > 1:  # every rank takes part in the reduction, also after a local failure
+        if world > 1 or _group_live():  # every rank takes part in the reduction, also after a local failure
             dt_pipe = max_over_ranks(dt_pipe if dt_pipe is not None else float("inf"), world, dev)
             if dt_pipe == float("inf"):
                 dt_pipe = None
@@ -519,7 +539,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))
-    if world > 1:
+    if _group_live():
         torch.distributed.destroy_process_group()
 
 
