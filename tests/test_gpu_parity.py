@@ -819,6 +819,13 @@ def test_prefetched_traversal_is_the_same_sampling(dev):
         est.sampling(ro, rd, traversal=h, **dict(kw, near_plane=0.2))
     with pytest.raises(AssertionError):
         got = est.sampling(ro, rd, traversal=h, **kw); est.sampling(ro, rd, traversal=h, **kw)
+    # with a cone angle (run records + recurrence expansion, overflow rays on a nested side stream)
+    est.binaries = T(np.indices((64, 64, 64)).sum(0)[None] % 2 == 0, dev)       # checkerboard: rays with > 32 chains
+    kwc = dict(kw, cone_angle=0.01)
+    ref = est.sampling(ro, rd, **kwc)
+    h = est.prefetch_traversal(ro, rd, near_plane=0.1, render_step_size=0.004, cone_angle=0.01)
+    got = est.sampling(ro, rd, traversal=h, **kwc)
+    assert all(torch.equal(a, b_) for a, b_ in zip(ref, got)) and ref[0].numel() > 10000
 
 
 def test_traversal_fuzz_bit_exact(dev, oracle):
