@@ -25,6 +25,7 @@ import torch
 from torch import Tensor
 
 from . import _backend as B
+from ._segments import tag_trusted
 from .estimators.occ_grid import OccGridEstimator
 from .grid import _traverse_samples, ray_aabb_intersect
 from .volrend import accumulate_along_rays_, render_weight_from_density
@@ -100,8 +101,23 @@ def render_rays_test_mode(
                 # accumulations (:370-405) as one pass of the segmented engine
                 if alpha_thre > 0 and n_visible is None:
                     n_visible = torch.zeros(1, dtype=torch.int64, device=device)
-                _render_step_native(seg[2], t_starts, t_ends, sigmas.contiguous(), rgbs.contiguous(), alpha_thre,
-                                    rgb, opacity, depth, n_visible if alpha_thre > 0 else None)
+                counter = n_visible if alpha_thre > 0 else None
+                if 2 * n_alive < num_rays:
+                    # Most rays are finished: their empty rows all "start" at the same element and the engine's tile
+                    # that owns that element would walk them one window after another (1.5 ms for 0.5 M dead rays).
+                    # The pass runs on the rows that have samples (element offsets are unchanged, so the chunks stay
+                    # contiguous) with the per-ray images gathered before and scattered back after: same values.
+                    has = packed_info[:, 1] > 0
+                    rows = torch.nonzero(has).squeeze(1)
+                    pi_c = packed_info[rows].contiguous()
+                    info = tag_trusted(pi_c, int(ray_indices.shape[0]))
+                    rgb_c, op_c, dp_c = rgb[rows], opacity[rows], depth[rows]
+                    _render_step_native(info, t_starts, t_ends, sigmas.contiguous(), rgbs.contiguous(), alpha_thre,
+                                        rgb_c, op_c, dp_c, counter)
+                    rgb[rows], opacity[rows], depth[rows] = rgb_c, op_c, dp_c
+                else:
+                    _render_step_native(seg[2], t_starts, t_ends, sigmas.contiguous(), rgbs.contiguous(), alpha_thre,
+                                        rgb, opacity, depth, counter)
                 n_counted = 0 if alpha_thre > 0 else ray_indices.shape[0]
             else:
                 weights, _, alphas = render_weight_from_density(

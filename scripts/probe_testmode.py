@@ -16,3 +16,14 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(5): out = run()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
 print("test-mode loop: %.2f ms per 1M-ray image, %d samples, %.1f M rays/s" % (dt * 1e3, out[3], w["n_rays"] / dt / 1e6))
+# per-launch breakdown of one image
+timer = bench.KernelTimer(); timer.install()
+torch.cuda.synchronize()
+out = run()
+torch.cuda.synchronize()
+ks = timer.summary(1); timer.uninstall()
+tot = 0.0
+for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms_per_step"]):
+    print("  %-40s %7.2f ms  %4d launches" % (k, v["ms_per_step"], v["launches_per_step"]))
+    tot += v["ms_per_step"]
+print("  native total %.2f ms" % tot)
