@@ -103,10 +103,10 @@ def render_rays_test_mode(
                     n_visible = torch.zeros(1, dtype=torch.int64, device=device)
                 counter = n_visible if alpha_thre > 0 else None
                 if 2 * n_alive < num_rays:
-                    # Most rays are finished: their empty rows all "start" at the same element and the engine's tile
-                    # that owns that element would walk them one window after another (1.5 ms for 0.5 M dead rays).
-                    # The pass runs on the rows that have samples (element offsets are unchanged, so the chunks stay
-                    # contiguous) with the per-ray images gathered before and scattered back after: same values.
+                    # Most rays are finished: the pass runs on the rows that have samples (element offsets are
+                    # unchanged, so the chunks stay contiguous) with the per-ray images gathered before and scattered
+                    # back after -- same values, and the engine neither searches over the blocks of finished rays
+                    # nor touches their image rows (19 vs 23 ms per 1 M-ray image).
                     has = packed_info[:, 1] > 0
                     rows = torch.nonzero(has).squeeze(1)
                     pi_c = packed_info[rows].contiguous()

@@ -34,6 +34,53 @@ def test_native_library_is_loaded(dev):
 
 
 # ----------------------------------------------------------------------------- pack / scans
+def test_long_runs_of_empty_rays(dev):
+    """Blocks of hundreds to hundreds of thousands of rays without samples (finished rays of the test-mode loop,
+    background pixels of an image-order batch): the engine jumps over them by a search on the row starts instead of
+    walking them.  Every packed op, forward and reverse scans and the fused rendering passes with gradients, must give
+    for the rays that have samples exactly what it gives on the batch without the empty rays, and zeros elsewhere."""
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    R = 300_000
+    patterns = []
+    c = torch.zeros(R, dtype=torch.int64, device=dev); c[120_000:121_500] = 37; patterns.append(c)          # one block alive
+    c = torch.zeros(R, dtype=torch.int64, device=dev); c[:700] = 5; c[-900:] = 9; patterns.append(c)        # huge middle gap
+    c = torch.randint(1, 40, (R,), generator=g, device=dev)
+    for a, b in ((10, 74), (1000, 1129), (5000, 5700), (50_000, 250_000), (299_000, 300_000)):
+        c[a:b] = 0
+    patterns.append(c)                                                                                       # gaps of 64 .. 200 k
+    for cnts in patterns:
+        has = cnts > 0
+        rows = torch.nonzero(has).squeeze(1)
+        ri = torch.repeat_interleave(torch.arange(R, device=dev), cnts)
+        ri_c = torch.repeat_interleave(torch.arange(rows.numel(), device=dev), cnts[rows])
+        n = ri.numel()
+        ts = torch.rand(n, generator=g, device=dev); te = ts + 0.02
+        sig = (torch.rand(n, generator=g, device=dev) * 4).requires_grad_(True)
+        rgbs = torch.rand(n, 3, generator=g, device=dev).requires_grad_(True)
+        sig_c, rgbs_c = sig.detach().clone().requires_grad_(True), rgbs.detach().clone().requires_grad_(True)
+        full = na.rendering(ts, te, ri, n_rays=R, rgb_sigma_fn=lambda a, b, c_: (rgbs, sig))
+        comp = na.rendering(ts, te, ri_c, n_rays=rows.numel(), rgb_sigma_fn=lambda a, b, c_: (rgbs_c, sig_c))
+        gw = torch.rand(R, 3, generator=g, device=dev)
+        ((full[0] * gw).sum() + (full[2] * gw[:, :1]).sum()).backward()
+        ((comp[0] * gw[rows]).sum() + (comp[2] * gw[rows, :1]).sum()).backward()
+        for k in range(3):
+            assert torch.equal(full[k][rows], comp[k]) and (full[k][~has] == 0).all()
+        assert torch.equal(full[3]["weights"], comp[3]["weights"]) and torch.equal(full[3]["trans"], comp[3]["trans"])
+        assert torch.equal(sig.grad, sig_c.grad) and torch.equal(rgbs.grad, rgbs_c.grad)
+        x = torch.rand(n, generator=g, device=dev).requires_grad_(True)
+        x_c = x.detach().clone().requires_grad_(True)
+        pi = na.pack_info(ri, R); pi_c = na.pack_info(ri_c, rows.numel())
+        y, y_c = na.exclusive_sum(x, pi), na.exclusive_sum(x_c, pi_c)
+        z, z_c = na.inclusive_prod(0.5 + 0.5 * x, pi), na.inclusive_prod(0.5 + 0.5 * x_c, pi_c)
+        (y * ts + z).sum().backward(); (y_c * ts + z_c).sum().backward()                                     # reverse scans
+        assert torch.equal(y, y_c) and torch.equal(z, z_c) and torch.equal(x.grad, x_c.grad)
+        vis = na.render_visibility_from_density(ts, te, sig.detach(), ray_indices=ri, n_rays=R, early_stop_eps=0.05, alpha_thre=0.01)
+        vis_c = na.render_visibility_from_density(ts, te, sig.detach(), ray_indices=ri_c, n_rays=rows.numel(), early_stop_eps=0.05, alpha_thre=0.01)
+        assert torch.equal(vis, vis_c)
+        acc = na.accumulate_along_rays(full[3]["weights"].detach(), None, ri, R)
+        assert torch.equal(acc[rows], na.accumulate_along_rays(comp[3]["weights"].detach(), None, ri_c, rows.numel())) and (acc[~has] == 0).all()
+
+
 def test_exclusive_cumsum_i64(dev):
     """nfa_exclusive_cumsum_i64 / _pairs_i64 vs torch.cumsum: empty, one element, block edges, the two-launch form
     (every workgroup adds up the partial sums before it) and, beyond 4 M elements, the three-launch form with a spine."""
