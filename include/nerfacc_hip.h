@@ -143,7 +143,14 @@ int nfa_pack_bricks(const uint8_t *binaries, int32_t n_grids, const int32_t *res
                     uint32_t *coarse, nfa_stream_t stream);
 int nfa_traverse_runs(const nfa_traverse_args *args, const uint64_t *bricks, const uint32_t *coarse,
                       int32_t *run_cnts, uint64_t *runs, int32_t max_runs, int32_t *overflow_count,
-                      float near_hint, nfa_stream_t stream);
+                      float near_hint, const int32_t *ray_order, nfa_stream_t stream);
+/* Lane -> ray assignment for nfa_traverse_runs (ray_order; NULL = identity): order[n_rays] = the ray ids sorted into 256
+ * bins by the length of the ray's path through box[6] = {min xyz, max xyz} (the outermost grid box), so that the rays a
+ * wave walks together are of similar length.  For batches of unrelated rays (training) the walk is ~1.6x faster;
+ * image-ordered rays are coherent already.  Everything the walk writes stays indexed by ray id: results do not depend on
+ * the order.  scratch: 1024 + n_rays bytes. */
+int nfa_bin_rays(const float *rays_o, const float *rays_d, int64_t n_rays, const float *box, int32_t *order,
+                 void *scratch, nfa_stream_t stream);
 int nfa_expand_runs(int64_t n_rays, float step_size, const int32_t *run_cnts, const uint64_t *runs,
                     int32_t max_runs, const int64_t *packed_info /*[n_rays,2] {start, count}*/, float *t_starts,
                     float *t_ends, float *t_mids, int64_t *ray_indices, nfa_stream_t stream);

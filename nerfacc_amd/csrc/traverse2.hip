@@ -76,6 +76,7 @@ struct RunsParams {
     int64_t n_rays;
     int32_t max_runs;
     int32_t *overflow;           // [1] number of rays with more runs than max_runs
+    const int32_t *order;        // [n_rays] lane -> ray assignment (a permutation) or NULL
     ApproachTable approach;      // shared start of every ray's march (march.h); n == 0: none
 };
 
@@ -283,8 +284,12 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
     float *ev_col = ev_thr + threadIdx.x;
     const float dt = a.step_size;
     const int32_t limit = a.traverse_steps_limit;
-    for (int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tid < a.n_rays;
-         tid += (int64_t)blockDim.x * gridDim.x) {
+    for (int64_t slot_i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; slot_i < a.n_rays;
+         slot_i += (int64_t)blockDim.x * gridDim.x) {
+        // which ray this lane walks: the rays of a training batch are unrelated and a wave runs as long as its longest
+        // ray, so the caller may pass an assignment that puts rays of similar length side by side (nfa_bin_rays);
+        // everything the walk writes stays indexed by the ray itself
+        const int64_t tid = p.order ? (int64_t)p.order[slot_i] : slot_i;
         if (a.mode == 2 && a.rays_mask != nullptr && !a.rays_mask[tid]) {
             if (a.terminate_planes) a.terminate_planes[tid] = a.near_planes[tid];
             a.sm_cnts[tid] = 0;
@@ -433,6 +438,82 @@ __global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, co
         p.run_cnts[tid] = st.n_runs;
         if (st.n_runs > p.max_runs) atomicAdd(p.overflow, 1);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Lane -> ray assignment for batches of unrelated rays: a counting sort of the ray ids by the length of the ray's
+// path through the outermost grid box (BIN_COUNT bins), so that the 64 rays of a wave take about the same number of
+// cells.  Three small launches; the order inside a bin is whatever the atomics give (results do not depend on it).
+constexpr int BIN_COUNT = 256;
+
+__device__ __forceinline__ int ray_bin(const float *__restrict__ rays_o, const float *__restrict__ rays_d, int64_t r,
+                                       const float *__restrict__ box)
+{
+    const float ex = box[3] - box[0], ey = box[4] - box[1], ez = box[5] - box[2];
+    const float inv_diag = 1.0f / sqrtf(ex * ex + ey * ey + ez * ez);
+    float tmin = -INFINITY, tmax = INFINITY;
+    bool hit = true;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const float o = rays_o[3 * r + ax], inv = 1.0f / rays_d[3 * r + ax];
+        float lo = (box[ax] - o) * inv, hi = (box[3 + ax] - o) * inv;
+        if (lo > hi) { const float t = lo; lo = hi; hi = t; }
+        if (!(lo <= hi)) hit = false;  // NaN: direction component 0 and origin on the slab plane
+        tmin = fmaxf(tmin, lo); tmax = fminf(tmax, hi);
+    }
+    tmin = fmaxf(tmin, 0.0f);
+    if (!hit || !(tmin < tmax)) return 0;
+    const int b = 1 + (int)((tmax - tmin) * inv_diag * (float)(BIN_COUNT - 1));
+    return b < 1 ? 1 : (b > BIN_COUNT - 1 ? BIN_COUNT - 1 : b);
+}
+
+// Every workgroup owns one contiguous range of rays in both passes, so the global histogram / cursors see 256 atomics
+// per workgroup (not per 256 rays), and inside a workgroup the counting is LDS atomics.
+__global__ __launch_bounds__(256) void bin_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                        int64_t n_rays, int64_t per_block, const float *__restrict__ box,
+                                                        uint8_t *__restrict__ bins, int32_t *__restrict__ hist)
+{
+    __shared__ int32_t h[BIN_COUNT];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t r_lo = (int64_t)blockIdx.x * per_block, r_hi = min(r_lo + per_block, n_rays);
+    for (int64_t r = r_lo + threadIdx.x; r < r_hi; r += blockDim.x) {
+        const int b = ray_bin(rays_o, rays_d, r, box);
+        bins[r] = (uint8_t)b;
+        atomicAdd(&h[b], 1);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// one workgroup: exclusive scan of the histogram in place (-> first output slot of every bin)
+__global__ __launch_bounds__(256) void bin_scan_kernel(int32_t *__restrict__ hist)
+{
+    __shared__ int32_t h[BIN_COUNT];
+    h[threadIdx.x] = hist[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t run = 0;
+        for (int i = 0; i < BIN_COUNT; ++i) { const int32_t c = h[i]; h[i] = run; run += c; }
+    }
+    __syncthreads();
+    hist[threadIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void bin_scatter_kernel(const uint8_t *__restrict__ bins, int64_t n_rays, int64_t per_block,
+                                                          int32_t *__restrict__ cursor, int32_t *__restrict__ order)
+{
+    __shared__ int32_t h[BIN_COUNT];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t r_lo = (int64_t)blockIdx.x * per_block, r_hi = min(r_lo + per_block, n_rays);
+    for (int64_t r = r_lo + threadIdx.x; r < r_hi; r += blockDim.x) atomicAdd(&h[bins[r]], 1);
+    __syncthreads();
+    const int32_t mine = h[threadIdx.x];
+    __syncthreads();
+    h[threadIdx.x] = mine ? atomicAdd(&cursor[threadIdx.x], mine) : 0;  // the workgroup's slots of this bin; then its local cursor
+    __syncthreads();
+    for (int64_t r = r_lo + threadIdx.x; r < r_hi; r += blockDim.x) order[atomicAdd(&h[bins[r]], 1)] = (int32_t)r;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -829,8 +910,29 @@ int nfa_pack_bricks(const uint8_t *binaries, int32_t n_grids, const int32_t *res
     return NFA_OK;
 }
 
+int nfa_bin_rays(const float *rays_o, const float *rays_d, int64_t n_rays, const float *box, int32_t *order,
+                 void *scratch, nfa_stream_t stream)
+{
+    NFA_REQUIRE(n_rays >= 0 && n_rays < ((int64_t)1 << 31), "bin_rays: n_rays out of range");
+    if (n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(rays_o && rays_d && box && order && scratch, "bin_rays: null pointer");
+    hipStream_t s = as_stream(stream);
+    int32_t *hist = reinterpret_cast<int32_t *>(scratch);                      // [BIN_COUNT]
+    uint8_t *bins = reinterpret_cast<uint8_t *>(hist + BIN_COUNT);             // [n_rays]
+    if (hipMemsetAsync(hist, 0, sizeof(int32_t) * BIN_COUNT, s) != hipSuccess) { set_error("bin_rays: memset failed"); return NFA_EHIP; }
+    int64_t per_block = ceil_div64(n_rays, 512);  // up to 512 workgroups (two per CU), at least 1024 rays each
+    if (per_block < 1024) per_block = 1024;
+    const unsigned grid = (unsigned)ceil_div64(n_rays, per_block);
+    hipLaunchKernelGGL(bin_count_kernel, dim3(grid), dim3(256), 0, s, rays_o, rays_d, n_rays, per_block, box, bins, hist);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, s, hist);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(grid), dim3(256), 0, s, bins, n_rays, per_block, hist, order);
+    NFA_CHECK_LAUNCH("bin_rays");
+    return NFA_OK;
+}
+
 int nfa_traverse_runs(const nfa_traverse_args *pa, const uint64_t *bricks, const uint32_t *coarse, int32_t *run_cnts,
-                      uint64_t *runs, int32_t max_runs, int32_t *overflow_count, float near_hint, nfa_stream_t stream)
+                      uint64_t *runs, int32_t max_runs, int32_t *overflow_count, float near_hint,
+                      const int32_t *ray_order, nfa_stream_t stream)
 {
     NFA_REQUIRE(pa != nullptr, "traverse_runs: null args");
     const nfa_traverse_args &a = *pa;
@@ -861,6 +963,7 @@ int nfa_traverse_runs(const nfa_traverse_args *pa, const uint64_t *bricks, const
     p.max_runs = max_runs;
     p.n_rays = a.n_rays;
     p.overflow = overflow_count;
+    p.order = ray_order;
     // near_hint: the value most (or all) entries of near_planes hold, NaN if unknown.  Rays whose near plane
     // differs bit-wise simply do not use the table.
     if (near_hint == near_hint) approach_table_build(p.approach, near_hint, a.step_size);

@@ -96,6 +96,12 @@ class OccGridEstimator(AbstractEstimator):
             self._planes_cache = cached
         return cached[1], cached[2]
 
+    #: Set to True for batches of unrelated rays (random pixels of random images, the usual training batch): the traversal
+    #: then walks rays of similar path length side by side (``nfa_bin_rays``), ~1.6x faster for such batches.  Results
+    #: are identical either way; image-ordered rays are coherent already and gain nothing.  (Extension: the reference
+    #: has no such switch.)
+    bin_rays: bool = False
+
     def _occs_mean(self) -> float:
         """``self.occs.mean().item()`` (ref :183) cached until ``occs`` changes."""
         key = (self.occs.data_ptr(), self.occs._version)
@@ -112,7 +118,7 @@ class OccGridEstimator(AbstractEstimator):
         if stratified:
             near_planes = near_planes + torch.rand_like(near_planes) * render_step_size
         return _traverse_samples(rays_o, rays_d, self.binaries, self.aabbs, near_planes, far_planes, render_step_size,
-                                 cone_angle, near_hint=near_plane)
+                                 cone_angle, near_hint=near_plane, bin_rays=self.bin_rays)
 
     @torch.no_grad()
     def prefetch_traversal(

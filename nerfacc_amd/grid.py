@@ -195,7 +195,7 @@ def traverse_grids(
             run_cnts = torch.empty(n_rays, dtype=torch.int32, device=dev)
             runs = torch.empty((MAX_RUNS, n_rays), dtype=torch.int64, device=dev)
             B.call("nfa_traverse_runs", C.byref(a), B.ptr(bricks), B.ptr(coarse), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
-                   B.ptr(meta[2:3]), float("nan") if near_hint is None else near_hint, B.stream())
+                   B.ptr(meta[2:3]), float("nan") if near_hint is None else near_hint, None, B.stream())
             iv_packed = _cumsum_packed(iv_cnts, meta[0:1])
             sm_packed = _cumsum_packed(sm_cnts, meta[1:2])
             n_iv, n_sm, n_overflow = (int(v) for v in meta.tolist())  # the one device->host read
@@ -298,7 +298,7 @@ CONE_RUNS = os.environ.get("NERFACC_AMD_CONE_RUNS", "1") != "0"   # 0: the seria
 @torch.no_grad()
 def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size, cone_angle,
                       rays_mask=None, traverse_steps_limit=None, t_sorted=None, t_indices=None, hits=None,
-                      return_terminate=False, near_hint=None):
+                      return_terminate=False, near_hint=None, bin_rays=False):
     """Sampler fast path: (ray_indices, t_starts, t_ends, packed_info) straight from the traversal.
 
     Same values as ``intervals.vals[is_left]``, ``intervals.vals[is_right]``,
@@ -340,9 +340,16 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
             bricks, coarse = _get_bricks(binaries)
             run_cnts = torch.empty(n_rays, dtype=torch.int32, device=dev)
             runs = torch.empty((MAX_RUNS, n_rays), dtype=torch.int64, device=dev)  # slot-major run records
+            order = None
+            if bin_rays and n_rays >= 4096:
+                # unrelated rays: lanes of a wave get rays of similar path length (results do not depend on it)
+                order = torch.empty(n_rays, dtype=torch.int32, device=dev)
+                scratch = torch.empty(1024 + n_rays, dtype=torch.uint8, device=dev)
+                B.call("nfa_bin_rays", B.ptr(rays_o), B.ptr(rays_d), n_rays, B.ptr(aabbs[-1]), B.ptr(order), B.ptr(scratch),
+                       B.stream())
             # near_hint: the scalar near plane when the caller built near_planes from one (accelerator only)
             B.call("nfa_traverse_runs", C.byref(a), B.ptr(bricks), B.ptr(coarse), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
-                   B.ptr(meta[1:2]), float("nan") if near_hint is None else float(near_hint), B.stream())
+                   B.ptr(meta[1:2]), float("nan") if near_hint is None else float(near_hint), B.ptr(order), B.stream())
         elif use_cone_runs:
             _get_bricks(binaries)
             run_cnts = torch.empty(n_rays, dtype=torch.int32, device=dev)

@@ -34,6 +34,35 @@ def test_native_library_is_loaded(dev):
 
 
 # ----------------------------------------------------------------------------- pack / scans
+def test_binned_ray_assignment_same_results(dev):
+    """estimator.bin_rays: the lane -> ray assignment of the walk is a permutation sorted by path length; every output
+    of the sampler is exactly what it is without it (unrelated rays, rays missing the box, a mask with a step limit)."""
+    import bench
+    rng = np.random.default_rng(12)
+    R = 50_000
+    o = rng.standard_normal((R, 3)).astype(np.float32)
+    d = rng.standard_normal((R, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    d[:50, 1] = 0.0
+    b = T(bench.make_grid(64, "shell10"), dev)
+    ab = T(np.array([[-1, -1, -1, 1, 1, 1]], np.float32), dev)
+    ro, rd = T(o, dev), T(d, dev)
+    near, far = torch.zeros(R, device=dev), torch.full((R,), 1e10, device=dev)
+    order = torch.empty(R, dtype=torch.int32, device=dev)
+    from nerfacc_amd import _backend as B
+    scratch = torch.empty(1024 + R, dtype=torch.uint8, device=dev)
+    B.call("nfa_bin_rays", B.ptr(ro), B.ptr(rd), R, B.ptr(ab[0]), B.ptr(order), B.ptr(scratch), B.stream())
+    assert torch.equal(torch.sort(order.long())[0], torch.arange(R, device=dev))          # a permutation
+    tmin, tmax, hit = na.ray_aabb_intersect(ro, rd, ab)
+    plen = torch.where(hit[:, 0], tmax[:, 0] - tmin[:, 0].clamp_min(0), torch.zeros(R, device=dev)).clamp_min(0)
+    bins = torch.where(plen > 0, (1 + (plen / 12 ** 0.5 * 255).long()).clamp(1, 255), torch.zeros(R, dtype=torch.long, device=dev))
+    bins = bins[order.long()]
+    assert (bins[1:] - bins[:-1] >= -1).all() and bins[0] == 0 and bins[-1] >= 200       # sorted by bin (+-1 at bin edges)
+    for kw in (dict(), dict(rays_mask=T(rng.random(R) < 0.6, dev), traverse_steps_limit=7)):
+        ref = na.grid._traverse_samples(ro, rd, b, ab, near, far, 4e-3, 0.0, return_terminate=True, **kw)
+        got = na.grid._traverse_samples(ro, rd, b, ab, near, far, 4e-3, 0.0, return_terminate=True, bin_rays=True, **kw)
+        assert ref[0].numel() > 30_000 and all(torch.equal(x, y) for x, y in zip(ref, got))
+
+
 def test_long_runs_of_empty_rays(dev):
     """Blocks of hundreds to hundreds of thousands of rays without samples (finished rays of the test-mode loop,
     background pixels of an image-order batch): the engine jumps over them by a search on the row starts instead of
