@@ -63,6 +63,37 @@ def test_binned_ray_assignment_same_results(dev):
         assert ref[0].numel() > 30_000 and all(torch.equal(x, y) for x, y in zip(ref, got))
 
 
+def test_degenerate_batches(dev):
+    """No rays, one ray, rays that all miss the grid and an all-empty grid through every sampler path (constant step,
+    cone angle, binned assignment, mask + limit), and the new entry points with n_rays = 0."""
+    est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=32, levels=2).to(dev)
+    est.binaries = torch.rand((2, 32, 32, 32), device=dev) < 0.3
+    est.bin_rays = True
+    for R in (0, 1, 5000):
+        ro = torch.randn(R, 3, device=dev) * 0.3
+        rd = torch.nn.functional.normalize(torch.randn(R, 3, device=dev), dim=-1)
+        for cone in (0.0, 0.01):
+            ri, ts, te = est.sampling(ro, rd, render_step_size=0.01, cone_angle=cone)
+            assert ri.dtype == torch.int64 and ts.shape == te.shape == ri.shape and (R == 0) == (ri.numel() == 0)
+            far_o = ro + 100.0                                                           # every ray misses
+            ri, ts, te = est.sampling(far_o, rd.abs(), render_step_size=0.01, cone_angle=cone)
+            assert ri.numel() == 0 and ts.numel() == 0
+        mask = torch.zeros(R, dtype=torch.bool, device=dev)
+        out = na.grid._traverse_samples(ro, rd, est.binaries, est.aabbs, torch.zeros(R, device=dev),
+                                        torch.full((R,), 1e10, device=dev), 0.01, 0.0, rays_mask=mask,
+                                        traverse_steps_limit=4, return_terminate=True, bin_rays=True)
+        assert out[0].numel() == 0 and out[3].shape == (R, 2) and (out[3] == 0).all()
+    est.binaries = torch.zeros_like(est.binaries)
+    for cone in (0.0, 0.01):
+        ri, ts, te = est.sampling(ro, rd, render_step_size=0.01, cone_angle=cone)
+        assert ri.numel() == 0
+    from nerfacc_amd import _backend as B
+    z = torch.empty(0, device=dev)
+    B.call("nfa_fill_ray_indices", 0, None, None, B.stream())
+    B.call("nfa_bin_rays", None, None, 0, None, None, None, B.stream())
+    B.call("nfa_expand_cone_runs", 0, 0.01, 0.01, None, None, 32, None, None, None, None, B.stream())
+
+
 def test_long_runs_of_empty_rays(dev):
     """Blocks of hundreds to hundreds of thousands of rays without samples (finished rays of the test-mode loop,
     background pixels of an image-order batch): the engine jumps over them by a search on the row starts instead of
