@@ -365,7 +365,8 @@ def main():
     ap.add_argument("--ray-variant", default="image", choices=["image", "random"])
     ap.add_argument("--field", default="native", choices=["native", "torch"],
                     help="synthetic radiance field: three streaming HIP kernels (bench_csrc/field.hip) or torch elementwise ops")
-    ap.add_argument("--bin-rays", action="store_true", help="estimator.bin_rays = True (for --ray-variant random)")
+    ap.add_argument("--bin-rays", default="auto", choices=["auto", "on", "off"],
+                    help="estimator.bin_rays: auto = decided from the previous batch's coherence (the default of the library)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the second (software-pipelined) timed loop")
@@ -380,7 +381,7 @@ def main():
     assert world == max(1, args.gpus) or world == 1, "launch with torchrun --nproc-per-node == --gpus"
 
     w = make_workload(dev, args.rays, args.res, args.grid, args.ray_variant, rank, args.field)
-    w["estimator"].bin_rays = bool(args.bin_rays)
+    w["estimator"].bin_rays = {"auto": None, "on": True, "off": False}[args.bin_rays]
 
     def sync():
         torch.cuda.synchronize()

@@ -52,6 +52,12 @@ int nfa_exclusive_cumsum_i64(const int64_t *cnts, int64_t n, int64_t *starts, in
 /* Same scan, written as packed_info rows {start, count} (ref: data_specs.py:68-69 stacks them afterwards). */
 int nfa_exclusive_cumsum_pairs_i64(const int64_t *cnts, int64_t n, int64_t *packed_info /*[n,2]*/, int64_t *total,
                                    void *scratch, nfa_stream_t stream);
+/* The same with a coherence measure for the caller's next batch: total_and_stats[0] = total; over a sample of the input
+ * (every 8th block of 2048 counts) [1] += sum over groups of 64 consecutive counts of the group's maximum and [2] += sum
+ * of the counts ([1], [2] zeroed by the caller; n <= 4 M, else left untouched).  64 * [1] / [2] is how much longer a
+ * wave of 64 neighbouring rays runs than its average ray. */
+int nfa_exclusive_cumsum_pairs_stats_i64(const int64_t *cnts, int64_t n, int64_t *packed_info /*[n,2]*/,
+                                         int64_t *total_and_stats /*[3]*/, void *scratch, nfa_stream_t stream);
 
 /* packed_info[r] = {start, count} of ray r in a ray-sorted index stream; also
  * reports (flags[0]) whether ray_indices is non-decreasing and in range.

@@ -45,6 +45,7 @@ class TraverseArgs(C.Structure):
 _SIGS = {
     "nfa_exclusive_cumsum_i64": [_vp, _i64, _vp, _vp, _vp, _vp],
     "nfa_exclusive_cumsum_pairs_i64": [_vp, _i64, _vp, _vp, _vp, _vp],
+    "nfa_exclusive_cumsum_pairs_stats_i64": [_vp, _i64, _vp, _vp, _vp, _vp],
     "nfa_pack_info": [_vp, _i64, _i64, _vp, _vp, _vp, _vp],
     "nfa_pdf_loss_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _vp],
     "nfa_pdf_loss_bwd": [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _vp, _vp],

@@ -423,12 +423,16 @@ __global__ __launch_bounds__(CS_THREADS) void cumsum_spine_kernel(int64_t *parti
 // (pairs != 0 writes packed_info rows {start, count}).
 // SPINE: `partials` holds the raw per-block sums and every workgroup adds up the ones before it by itself (a few
 // loads per thread from L2) instead of waiting for a one-workgroup spine kernel in between: two launches, not three.
+// stats (optional, [2], zeroed by the caller): += sum over groups of 64 consecutive inputs of the group's maximum,
+// += sum of all inputs.  64 * stats[0] / stats[1] = how much longer a wave of 64 neighbouring rays runs than its
+// average ray: the coherence measure behind OccGridEstimator's automatic ray binning.
 template <bool SPINE>
 __global__ __launch_bounds__(CS_THREADS) void cumsum_final_kernel(const int64_t *__restrict__ in, int64_t n,
                                                                    int64_t in_stride,
                                                                    const int64_t *__restrict__ partials,
                                                                    int64_t *__restrict__ out, int pairs,
-                                                                   int64_t *__restrict__ total)
+                                                                   int64_t *__restrict__ total,
+                                                                   unsigned long long *__restrict__ stats = nullptr)
 {
     __shared__ int64_t lds[8];
     int64_t block_off = 0;
@@ -450,6 +454,18 @@ __global__ __launch_bounds__(CS_THREADS) void cumsum_final_kernel(const int64_t 
     int64_t tot;
     int64_t run = block_off + block_excl_scan_i64(s, tot, lds);
     if (SPINE && total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = block_off + tot;
+    if (SPINE && stats && (blockIdx.x & 7) == 0) {  // a sample (one workgroup in 8) keeps the atomics off the critical path;
+                                                  // all lanes are here: the loads above are bounds-checked, not skipped
+        int64_t m = 0;
+#pragma unroll
+        for (int k = 0; k < CS_ITEMS; ++k) m = v[k] > m ? v[k] : m;
+        // 8 lanes x 8 items = 64 consecutive inputs
+        for (int off = 1; off < 8; off <<= 1) { const int64_t u = __shfl_xor(m, off, 64); m = u > m ? u : m; }
+        int64_t gm = (lane_id() & 7) == 0 ? m : 0;
+        for (int off = 8; off < 64; off <<= 1) gm += __shfl_xor(gm, off, 64);
+        if (lane_id() == 0) atomicAdd(&stats[0], (unsigned long long)gm);
+        if (threadIdx.x == 0) atomicAdd(&stats[1], (unsigned long long)tot);
+    }
 #pragma unroll
     for (int k = 0; k < CS_ITEMS; ++k) {
         if (base + k < n) {
@@ -461,18 +477,18 @@ __global__ __launch_bounds__(CS_THREADS) void cumsum_final_kernel(const int64_t 
 }
 
 static int run_cumsum(const int64_t *in, int64_t n, int64_t in_stride, int64_t *out, int pairs, int64_t *total,
-                      void *scratch, hipStream_t s)
+                      void *scratch, hipStream_t s, unsigned long long *stats = nullptr)
 {
     const int64_t n_blocks = ceil_div64(n > 0 ? n : 1, CS_BLOCK);
     int64_t *partials = reinterpret_cast<int64_t *>(scratch);
     hipLaunchKernelGGL(cumsum_partials_kernel, dim3((unsigned)n_blocks), dim3(CS_THREADS), 0, s, in, n, in_stride, partials);
     if (n_blocks <= 2048) {  // up to 4 M elements: 8 partials per thread at most
         hipLaunchKernelGGL(cumsum_final_kernel<true>, dim3((unsigned)n_blocks), dim3(CS_THREADS), 0, s, in, n, in_stride, partials,
-                           out, pairs, total);
+                           out, pairs, total, stats);
     } else {
         hipLaunchKernelGGL(cumsum_spine_kernel, dim3(1), dim3(CS_THREADS), 0, s, partials, n_blocks, total);
         hipLaunchKernelGGL(cumsum_final_kernel<false>, dim3((unsigned)n_blocks), dim3(CS_THREADS), 0, s, in, n, in_stride, partials,
-                           out, pairs, nullptr);
+                           out, pairs, nullptr, nullptr);
     }
     NFA_CHECK_LAUNCH("exclusive_cumsum_i64");
     return NFA_OK;
@@ -560,6 +576,15 @@ int nfa_exclusive_cumsum_pairs_i64(const int64_t *cnts, int64_t n, int64_t *pack
 {
     NFA_REQUIRE(n >= 0 && scratch && (n == 0 || (cnts && packed_info)), "exclusive_cumsum_pairs_i64: bad arguments");
     return run_cumsum(cnts, n, 1, packed_info, 1, total, scratch, as_stream(stream));
+}
+
+int nfa_exclusive_cumsum_pairs_stats_i64(const int64_t *cnts, int64_t n, int64_t *packed_info, int64_t *total_and_stats,
+                                         void *scratch, nfa_stream_t stream)
+{
+    NFA_REQUIRE(n >= 0 && scratch && total_and_stats && (n == 0 || (cnts && packed_info)),
+                "exclusive_cumsum_pairs_stats_i64: bad arguments");
+    return run_cumsum(cnts, n, 1, packed_info, 1, total_and_stats, scratch, as_stream(stream),
+                      reinterpret_cast<unsigned long long *>(total_and_stats + 1));
 }
 
 int nfa_pack_info(const int64_t *ray_indices, int64_t n, int64_t n_rays, int64_t *packed_info, int32_t *flags,

@@ -78,12 +78,13 @@ def _exclusive_cumsum(cnts: Tensor, total_out: Tensor):
     return starts
 
 
-def _cumsum_packed(cnts: Tensor, total_out: Tensor) -> Tensor:
-    """packed_info rows {exclusive start, count} from per-ray counts (one pass, no torch.stack)."""
+def _cumsum_packed(cnts: Tensor, total_out: Tensor, stats: bool = False) -> Tensor:
+    """packed_info rows {exclusive start, count} from per-ray counts (one pass, no torch.stack).  With ``stats``,
+    ``total_out`` has three slots: the total and the two sums of the coherence measure (include/nerfacc_hip.h)."""
     packed = torch.empty((cnts.numel(), 2), dtype=torch.int64, device=cnts.device)
     scratch = B.cumsum_scratch(cnts.numel(), cnts.device)
-    B.call("nfa_exclusive_cumsum_pairs_i64", B.ptr(cnts), cnts.numel(), B.ptr(packed), B.ptr(total_out), B.ptr(scratch),
-           B.stream())
+    B.call("nfa_exclusive_cumsum_pairs_stats_i64" if stats else "nfa_exclusive_cumsum_pairs_i64", B.ptr(cnts), cnts.numel(),
+           B.ptr(packed), B.ptr(total_out), B.ptr(scratch), B.stream())
     return packed
 
 
@@ -298,7 +299,7 @@ CONE_RUNS = os.environ.get("NERFACC_AMD_CONE_RUNS", "1") != "0"   # 0: the seria
 @torch.no_grad()
 def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size, cone_angle,
                       rays_mask=None, traverse_steps_limit=None, t_sorted=None, t_indices=None, hits=None,
-                      return_terminate=False, near_hint=None, bin_rays=False):
+                      return_terminate=False, near_hint=None, bin_rays=False, stats_sink=None):
     """Sampler fast path: (ray_indices, t_starts, t_ends, packed_info) straight from the traversal.
 
     Same values as ``intervals.vals[is_left]``, ``intervals.vals[is_right]``,
@@ -329,7 +330,8 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
     n_rays = rays_o.shape[0]
     with torch.cuda.device(dev):
         sm_cnts = torch.empty(n_rays, dtype=torch.int64, device=dev)
-        meta = torch.zeros(2, dtype=torch.int64, device=dev)  # [total samples, rays with too many runs]
+        # [total samples, coherence sums (2), rays with too many runs]
+        meta = torch.zeros(4, dtype=torch.int64, device=dev)
         terminate = torch.empty(n_rays, dtype=torch.float32, device=dev) if return_terminate else None
         masked = rays_mask is not None or limit > 0
         a = _traverse_args(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indices, hits, near_planes, far_planes,
@@ -349,16 +351,19 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
                        B.stream())
             # near_hint: the scalar near plane when the caller built near_planes from one (accelerator only)
             B.call("nfa_traverse_runs", C.byref(a), B.ptr(bricks), B.ptr(coarse), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
-                   B.ptr(meta[1:2]), float("nan") if near_hint is None else float(near_hint), B.ptr(order), B.stream())
+                   B.ptr(meta[3:4]), float("nan") if near_hint is None else float(near_hint), B.ptr(order), B.stream())
         elif use_cone_runs:
             _get_bricks(binaries)
             run_cnts = torch.empty(n_rays, dtype=torch.int32, device=dev)
             runs = torch.empty((MAX_RUNS, n_rays), dtype=torch.int64, device=dev)
-            B.call("nfa_traverse_cone_runs", C.byref(a), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS, B.ptr(meta[1:2]), B.stream())
+            B.call("nfa_traverse_cone_runs", C.byref(a), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS, B.ptr(meta[3:4]), B.stream())
         else:
             _launch(a)
-        packed_info = _cumsum_packed(sm_cnts, meta[0:1])
-        n_sm, n_overflow = (int(v) for v in meta.tolist())  # the one device->host read of the traversal
+        packed_info = _cumsum_packed(sm_cnts, meta[0:3], stats=True)
+        n_sm, s_max, s_sum, n_overflow = (int(v) for v in meta.tolist())  # the one device->host read of the traversal
+        if stats_sink is not None and s_sum > 0:
+            # how much longer a wave of 64 neighbouring rays runs than its average ray (1 = perfectly coherent)
+            stats_sink["max_over_mean"] = 64.0 * s_max / s_sum
         t_starts = torch.empty(n_sm, dtype=torch.float32, device=dev)
         t_ends = torch.empty(n_sm, dtype=torch.float32, device=dev)
         ray_indices = torch.empty(n_sm, dtype=torch.int64, device=dev)

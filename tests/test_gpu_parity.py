@@ -94,6 +94,36 @@ def test_degenerate_batches(dev):
     B.call("nfa_expand_cone_runs", 0, 0.01, 0.01, None, None, 32, None, None, None, None, B.stream())
 
 
+def test_automatic_ray_binning_decision(dev):
+    """bin_rays = None: the estimator measures, on the counts the traversal produces anyway, how much longer a wave of 64
+    neighbouring rays runs than its average ray, and bins the next batch when that exceeds 5 -- image-ordered rays stay
+    unbinned, unrelated rays get binned from the second call on, and the results never change."""
+    import bench
+    R = 256 * 256
+    b = bench.make_grid(64, "shell10")
+    est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=64).to(dev)
+    est.binaries = T(b, dev)
+    assert est.bin_rays is None
+    o, d = bench.make_rays(R, "image", rank=0)
+    for _ in range(2):
+        est.sampling(T(o, dev), T(d, dev), render_step_size=0.01)
+    assert 1.0 <= est._walk_stats["max_over_mean"] < 4.0
+    o, d = bench.make_rays(R, "random", rank=0)
+    ro, rd = T(o, dev), T(d, dev)
+    first = est.sampling(ro, rd, render_step_size=0.01)
+    assert est._walk_stats["max_over_mean"] > 6.0
+    second = est.sampling(ro, rd, render_step_size=0.01)                               # binned now
+    est.bin_rays = False
+    third = est.sampling(ro, rd, render_step_size=0.01)
+    assert all(torch.equal(x, y) and torch.equal(x, z) for x, y, z in zip(first, second, third))
+    # the measure itself: 64 * sum of group maxima / sum
+    cnts = torch.randint(0, 50, (100_000,), device=dev)
+    meta = torch.zeros(3, dtype=torch.int64, device=dev)
+    na.grid._cumsum_packed(cnts, meta, stats=True)
+    pad = torch.cat([cnts, cnts.new_zeros((-cnts.numel()) % 2048)]).view(-1, 2048)[::8]     # every 8th block of 2048
+    assert meta.tolist() == [int(cnts.sum()), int(pad.reshape(-1, 64).max(1)[0].sum()), int(pad.sum())]
+
+
 def test_long_runs_of_empty_rays(dev):
     """Blocks of hundreds to hundreds of thousands of rays without samples (finished rays of the test-mode loop,
     background pixels of an image-order batch): the engine jumps over them by a search on the row starts instead of
