@@ -378,6 +378,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     world, rank, local_rank = init_distributed("nccl", dev)
+    if world > 1:  # one process per GPU: the ranks share the host's cores (the step itself is single-threaded on the host)
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // (2 * world)))
     assert world == max(1, args.gpus) or world == 1, "launch with torchrun --nproc-per-node == --gpus"
 
     w = make_workload(dev, args.rays, args.res, args.grid, args.ray_variant, rank, args.field)
