@@ -195,7 +195,8 @@ int nfa_expand_intervals(int64_t n_rays, float step_size, const int32_t *run_cnt
  * tile_elems element offsets (nfa_seg_plan picks both); a tile OWNS the rays whose chunk starts
  * inside it.  tiles holds (n_tiles + 1) {first ray, first element} int64 pairs.  Requires
  * contiguous chunks (starts[r+1] == starts[r] + cnts[r]); flags[0] is set to 1 when they are not,
- * in which case the caller must use the *_generic entry points. */
+ * in which case the caller must use the *_generic entry points (flags may be NULL for a packed_info the
+ * caller knows to be contiguous: no check result, and no memset launch). */
 void nfa_seg_plan(int64_t n_elems, int64_t *tile_elems, int64_t *n_tiles);
 int nfa_seg_build_tiles(const int64_t *packed_info /*[n_rays,2]*/, int64_t n_rays, int64_t n_elems,
                         int64_t tile_elems, int64_t n_tiles, int64_t *tiles /*[2*(n_tiles+1)]*/,

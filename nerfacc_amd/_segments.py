@@ -39,7 +39,7 @@ def _build_tiles(packed_info: Tensor, n_elems: int, trusted: bool) -> SegInfo:
     with torch.cuda.device(dev):
         tile_elems, n_tiles = B.seg_plan(n_elems)
         tiles = torch.empty((n_tiles + 1, 2), dtype=torch.int64, device=dev)
-        flag = torch.empty(1, dtype=torch.int32, device=dev)
+        flag = None if trusted else torch.empty(1, dtype=torch.int32, device=dev)  # (no flag: no memset launch either)
         B.call("nfa_seg_build_tiles", B.ptr(packed_info), n_rays, n_elems, tile_elems, n_tiles, B.ptr(tiles), B.ptr(flag),
                B.stream())
         ok = True if trusted else (int(flag.item()) == 0)  # one read-back for foreign packed_info

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void seg_build_tiles_kernel(const int64_t *__r
                 bad |= (ps + pn != s);
             }
             bad |= (n < 0) || (s < 0) || (s + n > n_elems);
-            if (bad) { atomicOr(flags, 1); continue; }
+            if (bad) { if (flags) atomicOr(flags, 1); continue; }
             b_lo = (s_prev < 0) ? 0 : s_prev / tile_elems + 1;
             b_hi = s / tile_elems;
             e_first = s;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void seg_build_tiles_kernel(const int64_t *__r
             b_lo = (s_prev < 0) ? 0 : s_prev / tile_elems + 1;
             b_hi = n_tiles;
             e_first = (s_prev < 0) ? 0 : s_prev + n_prev;
-            if (s_prev > n_elems) { atomicOr(flags, 1); continue; }
+            if (s_prev > n_elems) { if (flags) atomicOr(flags, 1); continue; }
         }
         for (int64_t b = b_lo; b <= b_hi && b <= n_tiles; ++b) tiles[b] = make_longlong2(r, e_first);
     }
@@ -1491,13 +1491,13 @@ void nfa_seg_plan(int64_t n_elems, int64_t *tile_elems, int64_t *n_tiles)
 int nfa_seg_build_tiles(const int64_t *packed_info, int64_t n_rays, int64_t n_elems, int64_t tile_elems, int64_t n_tiles,
                         int64_t *tiles, int32_t *flags, nfa_stream_t stream)
 {
-    NFA_REQUIRE(n_rays >= 0 && n_elems >= 0 && tiles && flags, "seg_build_tiles: bad arguments");
+    NFA_REQUIRE(n_rays >= 0 && n_elems >= 0 && tiles, "seg_build_tiles: bad arguments");
     NFA_REQUIRE(n_rays == 0 || packed_info, "seg_build_tiles: packed_info is null");
     NFA_REQUIRE(n_rays < ((int64_t)1 << 31) - 64, "seg_build_tiles: too many rays");
     NFA_REQUIRE(tile_elems >= 256 && tile_elems % 256 == 0 && n_tiles == n_elems / tile_elems + 1,
                 "seg_build_tiles: tile_elems must be a multiple of 256 and n_tiles == n_elems / tile_elems + 1");
     hipStream_t s = as_stream(stream);
-    if (hipMemsetAsync(flags, 0, sizeof(int32_t), s) != hipSuccess) { set_error("seg_build_tiles: memset failed"); return NFA_EHIP; }
+    if (flags && hipMemsetAsync(flags, 0, sizeof(int32_t), s) != hipSuccess) { set_error("seg_build_tiles: memset failed"); return NFA_EHIP; }
     hipLaunchKernelGGL(seg_build_tiles_kernel, dim3(grid_1d(n_rays + 1, 256)), dim3(256), 0, s, packed_info, n_rays,
                        n_elems, tile_elems, n_tiles, reinterpret_cast<longlong2 *>(tiles), flags);
     NFA_CHECK_LAUNCH("seg_build_tiles");
