@@ -129,27 +129,33 @@ typedef struct nfa_traverse_args {
 } nfa_traverse_args;
 int nfa_traverse_grids(const nfa_traverse_args *args, nfa_stream_t stream);
 
-/* Run-length traversal used by the sampler when step_size > 0 and cone_angle == 0 (same results
- * as nfa_traverse_grids' sample-only path, one DDA walk instead of two, coalesced output):
- *   nfa_pack_bricks    torch.bool grid -> 4x4x4-cell 64-bit bricks + 1 bit per brick ("coarse");
- *                      bricks has nfa_bricks_words() entries, coarse (words+31)/32 uint32.
- *   nfa_traverse_runs  per ray: sample count (args->sm_cnts), terminate plane, run count and up to
- *                      max_runs (<= 32) run records {t_first:f32 | k_start:31, continues_previous:1} in
- *                      runs[max_runs][n_rays] (slot-major: record i of ray r at runs[i * n_rays + r]); rays with
+/* Run-length traversal used by the sampler and by traverse_grids when step_size > 0 and cone_angle == 0 (same
+ * results as nfa_traverse_grids, one DDA walk instead of the reference's count + fill passes, ref: cuda/csrc/grid.cu:
+ * 405-471; coalesced output):
+ *   nfa_walk_bits_words  size (uint32 words) of the 1-bit-per-cell grid copy the walk reads: the cells of all levels in
+ *                      the order of `binaries`, *pad_bits zero bits in front of cell 0 and behind the last cell
+ *                      (a multiple of 32: nfa_pack_bits(binaries, n_cells, bits + *pad_bits / 32) fills a zeroed buffer).
+ *   nfa_traverse_runs  per ray: sample count (args->sm_cnts), edge count (args->iv_cnts, optional), terminate plane,
+ *                      run count and up to max_runs (<= 32) run records {t_first:f32 | k_start:31, continues_previous:1}
+ *                      in runs[max_runs][n_rays] (slot-major: record i of ray r at runs[i * n_rays + r]); rays with
  *                      more runs are counted in *overflow_count and must be filled with
  *                      nfa_traverse_grids(mode 1, ray_filter = run_cnts, ray_filter_min = max_runs).
- *                      args->mode: 0 = all rays, 2 = honour rays_mask (+ traverse_steps_limit).
- *                      near_hint: the value (most of) args->near_planes hold, NaN if unknown; a pure
+ *                      args->mode: 0 = all rays, 2 = honour rays_mask (+ traverse_steps_limit).  At most 512 cells
+ *                      per axis.  near_hint: the value (most of) args->near_planes hold, NaN if unknown; a pure
  *                      accelerator (the march from a common near plane to the grid is tabulated once on
  *                      the host), rays with another near plane are unaffected, results never change.
+ *   nfa_pack_bricks    torch.bool grid -> 4x4x4-cell 64-bit bricks + 1 bit per brick ("coarse") for the serial
+ *                      kernels of nfa_traverse_grids (args->bricks / args->coarse);
+ *                      bricks has nfa_bricks_words() entries, coarse (words+31)/32 uint32.
  *   nfa_expand_runs    runs + exclusive cumsum of the counts -> (t_starts, t_ends) or, when t_mids is given,
  *                      the API's sample values (t_start + t_end) / 2; and ray_indices. */
 int64_t nfa_bricks_words(int32_t n_grids, const int32_t *res);
 int nfa_pack_bricks(const uint8_t *binaries, int32_t n_grids, const int32_t *res, uint64_t *bricks,
                     uint32_t *coarse, nfa_stream_t stream);
-int nfa_traverse_runs(const nfa_traverse_args *args, const uint64_t *bricks, const uint32_t *coarse,
-                      int32_t *run_cnts, uint64_t *runs, int32_t max_runs, int32_t *overflow_count,
-                      float near_hint, const int32_t *ray_order, nfa_stream_t stream);
+int64_t nfa_walk_bits_words(int32_t n_grids, const int32_t *res, int32_t *pad_bits);
+int nfa_traverse_runs(const nfa_traverse_args *args, const uint32_t *bits, int32_t *run_cnts, uint64_t *runs,
+                      int32_t max_runs, int32_t *overflow_count, float near_hint, const int32_t *ray_order,
+                      nfa_stream_t stream);
 /* Lane -> ray assignment for nfa_traverse_runs (ray_order; NULL = identity): order[n_rays] = the ray ids sorted into 256
  * bins by the length of the ray's path through box[6] = {min xyz, max xyz} (the outermost grid box), so that the rays a
  * wave walks together are of similar length.  For batches of unrelated rays (training) the walk is ~1.6x faster;

@@ -1,22 +1,8 @@
-// traverse2.hip -- run-length traversal (constant step, cone_angle == 0): the sampler's and the API's fast path.
-//
-// The reference walks every ray twice with the same divergent DDA kernel (count pass, fill pass;
-// cuda/csrc/grid.cu:405-471), one 1-byte scattered grid load per cell and per-thread strided
-// output writes.  Restructured for MI355X:
+// traverse2.hip -- what surrounds the run-length walk (walk.hip) of the constant-step traversal: the brick-packed grid
+// copy used by the serial kernels, the ray binning, and the coalesced EXPANSIONS of the run records.
 //
 //   pack_bricks   binaries (torch.bool, 1 B/cell)  ->  4x4x4-cell bricks, one 64-bit word each,
-//                 plus a 1-bit-per-brick "any occupied" mask (128^3: 256 KiB + 4 KiB).
-//   runs pass     ONE DDA walk per ray (thread per ray).  The brick mask lives in LDS, a brick
-//                 word is fetched (8 B, L2) only when the ray enters a non-empty brick, and the
-//                 current word is cached in registers, so most cells cost no memory access.
-//                 The walk does no marching: it records one typed threshold per run of cells of
-//                 one kind (a handful per ray, in LDS).  A second, lock-step phase marches through
-//                 those thresholds with march.h's Stepper (remembered stable increment per binade,
-//                 verified jump counts, tabulated approach from a common near plane) -- skipping and
-//                 sample emission are the same code path, emission being "count the steps" -- so
-//                 there is no per-sample loop and no per-cell divergence.  Instead of samples the
-//                 pass emits RUN RECORDS: n consecutive samples with one exact fp32 increment,
-//                 typically 2-10 per ray (8 B each, slot-major).
+//                 plus a 1-bit-per-brick "any occupied" mask (grid.hip's serial kernels read occupancy from them).
 //   expand passes after the device-side cumsum of the counts, every output element is computed
 //                 independently: t = fma(k, inc, t_first) (exact: every sample of a run is t_first + k*inc).
 //                 A wave stages the records of 32 rays in LDS; per 256-output chunk the run starts are
@@ -35,7 +21,6 @@ constexpr int EXP_QMAX = 1024;     // runs staged per batch (EXP_RPW * max_runs)
 #define NFA_EXP_WPB 2  /* measured on cfg 2: 1 wave 176 us, 2 waves 160 us, 4 waves 175 us */
 #endif
 constexpr int EXP_WPB = NFA_EXP_WPB;  // waves per workgroup of the expansion kernels (they never cooperate)
-constexpr int COARSE_LDS_WORDS = 2048;  // 8 KiB: up to 40^3 bricks (160^3 cells).  A larger mask in LDS costs occupancy: 256^3 (32 KiB) 1103 us in LDS, 634 us from L2
 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_bricks_kernel(const uint8_t *__restrict__ binaries, int32_t n_grids,
@@ -62,381 +47,6 @@ __global__ __launch_bounds__(256) void pack_bricks_kernel(const uint8_t *__restr
             }
         bricks[b] = w;
         if (w) atomicOr(&coarse[b >> 5], 1u << (b & 31));
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-struct RunsParams {
-    const unsigned long long *bricks;
-    const uint32_t *coarse;      // global copy of the brick mask
-    int32_t n_coarse_words;
-    int32_t bx, by, bz;
-    int32_t *run_cnts;           // [n_rays]
-    unsigned long long *runs;    // [max_runs, n_rays] (slot-major: a wave reads one slot of 32 rays as one 256 B line)
-    int64_t n_rays;
-    int32_t max_runs;
-    int32_t *overflow;           // [1] number of rays with more runs than max_runs
-    const int32_t *order;        // [n_rays] lane -> ray assignment (a permutation) or NULL
-    ApproachTable approach;      // shared start of every ray's march (march.h); n == 0: none
-};
-
-// Events recorded by the cell walk (phase 1) and consumed by the marcher (phase 2).  Along a ray
-// the thresholds are non-decreasing and "advance while the step's mid-point is before the
-// threshold" is monotone in the threshold, so consecutive cells of one kind collapse into one
-// event carrying the last cell's exit distance:
-//   EV_EMPTY(thr)  skip steps while mid < thr              (grid.cu:193-206, continuous = false)
-//   EV_OCC(thr)    emit steps while mid < thr              (grid.cu:207-262)
-//   EV_SPAN(thr)   start of a grid span: skip to thr only if the previous step was not emitted
-//                  (grid.cu:153-163, `if (!continuous)`)
-#ifndef NFA_EV_MAX
-#define NFA_EV_MAX 24
-#endif
-constexpr int EV_MAX = NFA_EV_MAX;
-// Occupancy of the walk: 24 list entries (24 KiB per 256 rays) + the brick mask leave room for 5 workgroups per CU, and
-// the register allocator is asked for 5 waves per SIMD (96 VGPRs; 20 bytes of cold state spill).  Measured on cfg 2
-// (1 M rays = 16 waves per SIMD): 32 entries / 4 waves 330 us, 24 / 5: 307 us, 20 / 6: 311 us, 16 / 8: 348 us.
-#ifndef NFA_RUNS_WAVES
-#define NFA_RUNS_WAVES 5
-#endif
-enum { EV_EMPTY = 0, EV_OCC = 1, EV_SPAN = 2, EV_NONE = 3 };
-
-struct RunState {
-    float t_last;
-    bool continuous;
-    int32_t n_samples, n_runs, n_chains;  // n_chains: samples emitted while not continuous (each adds one edge)
-    Stepper stp;  // remembered stable increment of the current binade (march.h)
-    bool at_near; // t_last is still the near plane
-    // open run
-    bool open, run_cont;
-    float run_t0, run_inc;
-    int32_t run_n;
-    // brick cache
-    int32_t brick_id;
-    uint32_t brick_lo, brick_hi;
-    // event list: open (unmerged) entry in registers, closed entries in LDS
-    int32_t ev_cnt;
-    uint32_t ev_occ, ev_span;  // kind of closed entry k: bit k of ev_span -> EV_SPAN, else bit k of ev_occ -> EV_OCC / EV_EMPTY
-    int32_t open_type;
-    float open_thr;
-};
-
-// Run record: {t_first : f32 | k_start : 31, continues_previous : 1}, k_start = number of samples of
-// this ray before the run (the run's length is the next record's k_start, or the ray's count).
-__device__ __forceinline__ void close_run(RunState &st, const RunsParams &p, int64_t tid)
-{
-    if (!st.open) return;
-    if (st.n_runs < p.max_runs) {
-        const uint32_t k_start = (uint32_t)(st.n_samples - st.run_n);
-        p.runs[(int64_t)st.n_runs * p.n_rays + tid] =
-            (unsigned long long)f32_bits(st.run_t0) | ((unsigned long long)(k_start | (st.run_cont ? 0x80000000u : 0u)) << 32);
-    }
-    st.n_runs++;
-    st.open = false;
-}
-
-// n samples t, t + inc, ... (exact sums) join the ray's run list
-__device__ __forceinline__ void emit_steps(RunState &st, float t, float inc, uint32_t n, const RunsParams &p, int64_t tid)
-{
-    if (st.open && st.continuous && inc == st.run_inc) {
-        st.run_n += (int32_t)n;
-    } else {
-        close_run(st, p, tid);
-        st.open = true; st.run_t0 = t; st.run_inc = inc; st.run_n = (int32_t)n; st.run_cont = st.continuous;
-        st.n_chains += st.continuous ? 0 : 1;
-    }
-    st.n_samples += (int32_t)n;
-    st.continuous = true;
-}
-
-// Advance t_last while the step's mid-point is before `thr`; with `emit` every step is a sample
-// and is appended to the ray's run list.  march.h's Stepper does the arithmetic: one exact jump per
-// binade (the stable increment is remembered across the marches of a ray), plus the sample budget of
-// traverse_steps_limit.
-__device__ __forceinline__ void march(RunState &st, float thr, float dt, float half, bool emit, int32_t limit,
-                                      const RunsParams &p, int64_t tid)
-{
-    if (st.at_near) {  // first march of the ray: the way from the near plane is the same for all rays
-        st.at_near = false;
-        if (!emit) approach_table_apply(p.approach, st.stp, st.t_last, half, thr);
-    }
-    for (;;) {
-        if (!(st.t_last + half < thr)) return;
-        uint32_t budget = 0xFFFFFFFFu;
-        if (emit && limit > 0) {
-            if (st.n_samples >= limit) return;
-            budget = (uint32_t)(limit - st.n_samples);
-        }
-        const float t = st.t_last;
-        float tn = t, inc;
-        const uint32_t n = stepper_advance(st.stp, tn, dt, half, thr, budget, &inc);
-        if (n == 0u) {  // no progress (see oracle): skipping jumps to the target, emission stops
-            if (!emit) { st.t_last = thr; stepper_reset(st.stp); }
-            return;
-        }
-        if (emit) emit_steps(st, t, inc, n, p, tid);
-        st.t_last = tn;
-    }
-}
-
-// Phase 2: consume the closed entries of this lane's list (all lanes loop over the entry index in
-// lock-step; one code path for all three kinds).
-__device__ __forceinline__ void process_events(RunState &st, const float *ev_thr /*LDS, [EV_MAX][256]*/, float dt,
-                                               int32_t limit, const RunsParams &p, int64_t tid)
-{
-    const float half = dt * 0.5f;
-    for (int k = 0; k < st.ev_cnt; ++k) {
-        const int type = ((st.ev_span >> k) & 1u) ? EV_SPAN : (int)((st.ev_occ >> k) & 1u);
-        const float thr = ev_thr[k * 256 + threadIdx.x];
-        if (limit > 0 && st.n_samples >= limit) break;  // grid.cu:184: nothing moves once the limit is hit
-        if (type == EV_SPAN && st.continuous) continue;
-        // common case in one shot (aligned inside the binade, threshold well before its end, no sample budget);
-        // everything else -- and the rare under-estimate -- goes through the general loop
-        bool handled = false;
-        if (limit <= 0 && !st.at_near) {
-            float t = st.t_last;
-            StepSeg g0, g1, g2;
-            if (stepper_run_event(st.stp, t, dt, half, thr, g0, g1, g2)) {
-                if (type == EV_OCC) {
-                    if (g0.n > 0u) emit_steps(st, g0.t0, g0.inc, g0.n, p, tid);
-                    if (g1.n > 0u) emit_steps(st, g1.t0, g1.inc, g1.n, p, tid);
-                    if (g2.n > 0u) emit_steps(st, g2.t0, g2.inc, g2.n, p, tid);
-                }
-                st.t_last = t;
-                handled = true;
-            }
-        }
-        if (!handled) march(st, thr, dt, half, type == EV_OCC, limit, p, tid);
-        if (type == EV_EMPTY) st.continuous = false;
-    }
-    st.ev_cnt = 0;
-    st.ev_occ = 0u; st.ev_span = 0u;
-}
-
-__device__ __forceinline__ void push_closed(RunState &st, float *ev_thr, int type, float thr)
-{
-    ev_thr[st.ev_cnt * 256 + threadIdx.x] = thr;
-    st.ev_occ |= (uint32_t)(type & 1) << st.ev_cnt;
-    st.ev_span |= (uint32_t)(type >> 1) << st.ev_cnt;
-    st.ev_cnt++;
-}
-
-// DDA state of the span being walked (setup_traversal, include/utils_grid.cuh:58-114)
-struct SpanDDA {
-    float tdist[3], delta[3], this_tmax;
-    int32_t step[3], cur[3], overflow[3];
-    int32_t lvl_brick_base, cells_left;
-};
-
-__device__ __forceinline__ void span_setup(const nfa_traverse_args &a, const RunsParams &p, const float o[3], const float d[3],
-                                           const float inv[3], int32_t level, float this_tmin, float this_tmax, SpanDDA &sp)
-{
-    const float eps = 1e-6f;
-    const float *bmin = a.aabbs + 6 * level, *bmax = bmin + 3;
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-        const float resf = (float)a.res[ax];
-        const float extent = bmax[ax] - bmin[ax];
-        const float voxel = extent / resf;
-        const float ray_start = o[ax] + d[ax] * (this_tmin + eps);
-        const float ray_end = o[ax] + d[ax] * (this_tmax - eps);
-        int32_t c = (int32_t)(((ray_start - bmin[ax]) / extent) * resf);
-        int32_t f = (int32_t)(((ray_end - bmin[ax]) / extent) * resf);
-        c = max(0, min(c, a.res[ax] - 1));
-        f = max(0, min(f, a.res[ax] - 1));
-        const int32_t start_index = c + (d[ax] > 0.0f ? 1 : 0);
-        const float tmax_ax = ((bmin[ax] + (((float)start_index * voxel) - ray_start)) * inv[ax]) + this_tmin;
-        const float step_f = (d[ax] == 0.0f) ? 0.0f : (d[ax] > 0.0f ? 1.0f : -1.0f);
-        sp.tdist[ax] = (d[ax] == 0.0f) ? this_tmax : tmax_ax;
-        sp.step[ax] = (int32_t)step_f;
-        const float delta_tmp = voxel * inv[ax] * step_f;
-        sp.delta[ax] = (d[ax] == 0.0f) ? this_tmax : delta_tmp;
-        sp.cur[ax] = c;
-        sp.overflow[ax] = f + sp.step[ax];
-    }
-    sp.this_tmax = this_tmax;
-    sp.lvl_brick_base = level * p.bx * p.by * p.bz;
-    sp.cells_left = a.res[0] + a.res[1] + a.res[2] + 3;
-}
-
-// min of four finite-or-inf floats as two instructions (fminf's IEEE canonicalisation of signalling NaNs costs
-// three more per cell; the DDA's distances are never NaN: d == 0 axes carry this_tmax)
-__device__ __forceinline__ float min4_f32(float a, float b, float c, float d)
-{
-    float m;
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
-    asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(d));
-    return m;
-}
-
-// One ray = a loop of (phase 1: walk cells, opening the next span when one ends, until the event list is full or
-// the ray has no span left) + (phase 2: consume the list).  There is exactly ONE copy of each phase in the code.
-template <bool FUSED, bool COARSE_LDS>
-__attribute__((amdgpu_waves_per_eu(NFA_RUNS_WAVES, NFA_RUNS_WAVES)))
-__global__ __launch_bounds__(256) void runs_kernel(const nfa_traverse_args a, const RunsParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    float *ev_thr = reinterpret_cast<float *>(lds_raw);          // [EV_MAX][256]
-    uint32_t *coarse_lds = lds_raw + EV_MAX * 256;          // [n_coarse_words] (COARSE_LDS only)
-    if (COARSE_LDS) {
-        for (int i = threadIdx.x; i < p.n_coarse_words; i += blockDim.x) coarse_lds[i] = p.coarse[i];
-        __syncthreads();
-    }
-    float *ev_col = ev_thr + threadIdx.x;
-    const float dt = a.step_size;
-    const int32_t limit = a.traverse_steps_limit;
-    for (int64_t slot_i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; slot_i < a.n_rays;
-         slot_i += (int64_t)blockDim.x * gridDim.x) {
-        // which ray this lane walks: the rays of a training batch are unrelated and a wave runs as long as its longest
-        // ray, so the caller may pass an assignment that puts rays of similar length side by side (nfa_bin_rays);
-        // everything the walk writes stays indexed by the ray itself
-        const int64_t tid = p.order ? (int64_t)p.order[slot_i] : slot_i;
-        if (a.mode == 2 && a.rays_mask != nullptr && !a.rays_mask[tid]) {
-            if (a.terminate_planes) a.terminate_planes[tid] = a.near_planes[tid];
-            a.sm_cnts[tid] = 0;
-            if (a.iv_cnts) a.iv_cnts[tid] = 0;
-            p.run_cnts[tid] = 0;
-            continue;
-        }
-        const float near_plane = a.near_planes[tid], far_plane = a.far_planes[tid];
-        const float o[3] = {a.rays_o[3 * tid], a.rays_o[3 * tid + 1], a.rays_o[3 * tid + 2]};
-        const float d[3] = {a.rays_d[3 * tid], a.rays_d[3 * tid + 1], a.rays_d[3 * tid + 2]};
-        const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
-        RunState st;
-        st.t_last = near_plane; st.continuous = false; stepper_init(st.stp); st.at_near = true;
-        st.n_samples = 0; st.n_runs = 0; st.n_chains = 0; st.open = false; st.run_cont = false; st.run_t0 = 0.f; st.run_inc = 0.f;
-        st.run_n = 0; st.brick_id = -1; st.brick_lo = st.brick_hi = 0u;
-        st.ev_cnt = 0; st.ev_occ = 0u; st.ev_span = 0u; st.open_type = EV_NONE; st.open_thr = 0.f;
-
-        // the ray's spans: one (slab test here) or the event walk over the sorted intersections (grid.cu:125-150)
-        float f_tmin = 0.f, f_tmax = 0.f;
-        bool f_pending = false;
-        if (FUSED) {
-            float tmin, tmax, lo, hi;
-            bool hit = true;
-            {   // slab test (include/utils_grid.cuh:10-55) with near = -inf, far = +inf (grid.py:158)
-                const float *bmin = a.aabbs, *bmax = a.aabbs + 3;
-                if (inv[0] >= 0) { tmin = (bmin[0] - o[0]) * inv[0]; tmax = (bmax[0] - o[0]) * inv[0]; }
-                else             { tmin = (bmax[0] - o[0]) * inv[0]; tmax = (bmin[0] - o[0]) * inv[0]; }
-#pragma unroll
-                for (int ax = 1; ax < 3; ++ax) {
-                    if (inv[ax] >= 0) { lo = (bmin[ax] - o[ax]) * inv[ax]; hi = (bmax[ax] - o[ax]) * inv[ax]; }
-                    else              { lo = (bmax[ax] - o[ax]) * inv[ax]; hi = (bmin[ax] - o[ax]) * inv[ax]; }
-                    if (tmin > hi || lo > tmax) hit = false;
-                    if (lo > tmin) tmin = lo;
-                    if (hi < tmax) tmax = hi;
-                }
-                if (tmax <= 0) hit = false;
-            }
-            f_tmin = fmaxf(tmin, near_plane); f_tmax = fminf(tmax, far_plane);
-            f_pending = hit && f_tmin < f_tmax;
-        }
-        const int32_t G = a.n_grids;
-        int32_t next_i = 0;  // next entry of the event walk (non-fused)
-
-        SpanDDA sp;
-        sp.this_tmax = 0.f; sp.lvl_brick_base = 0; sp.cells_left = 0;
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) { sp.tdist[ax] = sp.delta[ax] = 0.f; sp.step[ax] = sp.cur[ax] = sp.overflow[ax] = 0; }
-        bool in_span = false;
-
-        for (;;) {
-            // ---------------- phase 1: the reference's cell loop (grid.cu:184-272) reduced to the DDA and one event
-            // per run of cells of one kind, straight-line predicated code, 32-bit integer ops only.  The open entry's
-            // threshold is written to slot ev_cnt on EVERY cell; the slot becomes a closed entry when the kind changes.
-            bool finished = false;
-            for (;;) {
-                if (!in_span) {
-                    if (st.ev_cnt >= EV_MAX - 1) break;  // a span start needs two entries: flush first
-                    float this_tmin = 0.f, this_tmax = 0.f;
-                    int32_t level = 0;
-                    bool found = false;
-                    if (FUSED) {
-                        found = f_pending; f_pending = false;
-                        this_tmin = f_tmin; this_tmax = f_tmax;
-                    } else {
-                        const uint8_t *hits = a.hits + tid * G;
-                        const float *ts = a.t_sorted + tid * 2 * G;
-                        const int64_t *ti = a.t_indices + tid * 2 * G;
-                        while (!found && next_i < 2 * G - 1) {
-                            const int32_t i = next_i++;
-                            const int64_t idx = ti[i];
-                            level = (int32_t)(idx % G);
-                            if (!hits[level]) continue;
-                            if (!(idx < G)) {
-                                const int64_t nidx = ti[i + 1];
-                                if (nidx < G) continue;
-                                level = (int32_t)(nidx % G);
-                                if (!hits[level]) continue;
-                            }
-                            this_tmin = fmaxf(ts[i], near_plane); this_tmax = fminf(ts[i + 1], far_plane);
-                            if (this_tmin >= this_tmax) continue;
-                            found = true;
-                        }
-                    }
-                    if (!found) { finished = true; break; }
-                    // span start: the (conditional) skip to this_tmin becomes the open entry; the first cell closes it
-                    if (st.open_type != EV_NONE) push_closed(st, ev_thr, st.open_type, st.open_thr);
-                    st.open_type = EV_SPAN;
-                    st.open_thr = this_tmin;
-                    span_setup(a, p, o, d, inv, level, this_tmin, this_tmax, sp);
-                    st.ev_span |= 1u << st.ev_cnt;  // the first cell always closes the EV_SPAN entry: its kind bit
-                    in_span = true;
-                }
-                for (;;) {
-                    const int32_t bid = sp.lvl_brick_base +
-                                        (int32_t)mad_u24(mad_u24((uint32_t)sp.cur[0] >> 2, (uint32_t)p.by, (uint32_t)sp.cur[1] >> 2), (uint32_t)p.bz, (uint32_t)sp.cur[2] >> 2);
-                    if (bid != st.brick_id) {
-                        st.brick_id = bid;
-                        // the 1-bit mask saves the 8-byte load for empty bricks when it sits in LDS; read from
-                        // global memory it would be a second, dependent access in front of the brick
-                        unsigned long long w;
-                        if (COARSE_LDS) w = ((coarse_lds[bid >> 5] >> (bid & 31)) & 1u) ? p.bricks[bid] : 0ull;
-                        else w = p.bricks[bid];
-                        st.brick_lo = (uint32_t)w; st.brick_hi = (uint32_t)(w >> 32);
-                    }
-                    // bit ((x&3)<<4 | (y&3)<<2 | (z&3)) of the 64-bit brick word, on 32-bit halves
-                    const uint32_t half_w = (sp.cur[0] & 2) ? st.brick_hi : st.brick_lo;
-                    const int sh = ((sp.cur[0] & 1) << 4) | ((sp.cur[1] & 3) << 2) | (sp.cur[2] & 3);
-                    const int type = (int)((half_w >> sh) & 1u);  // EV_EMPTY / EV_OCC
-                    const bool changed = type != st.open_type;
-                    ev_col[st.ev_cnt * 256] = st.open_thr;
-                    st.ev_occ |= (changed ? (uint32_t)(st.open_type & 1) : 0u) << st.ev_cnt;
-                    st.ev_cnt += changed ? 1 : 0;
-                    st.open_type = type;
-                    st.open_thr = min4_f32(sp.tdist[0], sp.tdist[1], sp.tdist[2], sp.this_tmax);  // t_traverse, non-decreasing
-                    // single_traversal (include/utils_grid.cuh:116-142), branch-free
-                    const bool s0 = (sp.tdist[0] < sp.tdist[1]) && (sp.tdist[0] < sp.tdist[2]);
-                    const bool s1 = !s0 && (sp.tdist[1] < sp.tdist[2]);
-                    const bool s2 = !s0 && !s1;
-                    sp.cur[0] += s0 ? sp.step[0] : 0; sp.tdist[0] += s0 ? sp.delta[0] : 0.0f;
-                    sp.cur[1] += s1 ? sp.step[1] : 0; sp.tdist[1] += s1 ? sp.delta[1] : 0.0f;
-                    sp.cur[2] += s2 ? sp.step[2] : 0; sp.tdist[2] += s2 ? sp.delta[2] : 0.0f;
-                    const bool hit_end = (s0 && sp.cur[0] == sp.overflow[0]) || (s1 && sp.cur[1] == sp.overflow[1]) ||
-                                         (s2 && sp.cur[2] == sp.overflow[2]);
-                    // the span ends when cells_left reaches 0 (one integer carries the exit reason out of the loop:
-                    // a bool would live in scalar lane masks and cost mask algebra on every cell)
-                    sp.cells_left = hit_end ? 0 : sp.cells_left - 1;
-                    if (sp.cells_left <= 0 || st.ev_cnt == EV_MAX) break;
-                }
-                if (sp.cells_left <= 0) in_span = false;
-                if (st.ev_cnt == EV_MAX) break;
-            }
-            if (finished && st.open_type != EV_NONE) {
-                if (st.ev_cnt == EV_MAX) finished = false;  // no slot for the last open entry: flush and come back
-                else { push_closed(st, ev_thr, st.open_type, st.open_thr); st.open_type = EV_NONE; }
-            }
-            // ---------------- phase 2
-            process_events(st, ev_thr, dt, limit, p, tid);
-            if (finished) break;
-        }
-        close_run(st, p, tid);
-        if (a.terminate_planes) a.terminate_planes[tid] = st.t_last;
-        a.sm_cnts[tid] = st.n_samples;
-        if (a.iv_cnts) a.iv_cnts[tid] = st.n_samples + st.n_chains;  // edges = samples + one leading edge per chain
-        // rays with > 2^21 samples go to the serial fill too (the expansion packs a 27-bit batch offset)
-        if (st.n_samples > (1 << 21) && st.n_runs <= p.max_runs) st.n_runs = p.max_runs + 1;
-        p.run_cnts[tid] = st.n_runs;
-        if (st.n_runs > p.max_runs) atomicAdd(p.overflow, 1);
     }
 }
 
@@ -927,60 +537,6 @@ int nfa_bin_rays(const float *rays_o, const float *rays_d, int64_t n_rays, const
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, s, hist);
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(grid), dim3(256), 0, s, bins, n_rays, per_block, hist, order);
     NFA_CHECK_LAUNCH("bin_rays");
-    return NFA_OK;
-}
-
-int nfa_traverse_runs(const nfa_traverse_args *pa, const uint64_t *bricks, const uint32_t *coarse, int32_t *run_cnts,
-                      uint64_t *runs, int32_t max_runs, int32_t *overflow_count, float near_hint,
-                      const int32_t *ray_order, nfa_stream_t stream)
-{
-    NFA_REQUIRE(pa != nullptr, "traverse_runs: null args");
-    const nfa_traverse_args &a = *pa;
-    NFA_REQUIRE(a.n_rays >= 0 && a.n_rays < (int64_t)1 << 31, "traverse_runs: n_rays out of range");
-    NFA_REQUIRE(overflow_count, "traverse_runs: overflow_count is null");
-    hipStream_t s = as_stream(stream);
-    if (hipMemsetAsync(overflow_count, 0, sizeof(int32_t), s) != hipSuccess) { set_error("traverse_runs: memset failed"); return NFA_EHIP; }
-    if (a.n_rays == 0) return NFA_OK;
-    NFA_REQUIRE(a.step_size > 0.0f && a.cone_angle == 0.0f, "traverse_runs: needs step_size > 0 and cone_angle == 0");
-    NFA_REQUIRE(a.mode == 0 || a.mode == 2, "traverse_runs: mode must be 0 (all rays) or 2 (rays_mask + limit)");
-    NFA_REQUIRE(a.mode != 2 || a.traverse_steps_limit > 0, "traverse_steps_limit must be > 0 when over_allocate is true");
-    NFA_REQUIRE(a.rays_o && a.rays_d && a.aabbs && a.near_planes && a.far_planes && a.sm_cnts && bricks && coarse &&
-                    run_cnts && runs, "traverse_runs: null pointer");
-    NFA_REQUIRE(max_runs >= 1 && max_runs * EXP_RPW <= EXP_QMAX, "traverse_runs: max_runs must be in [1, 32]");
-    NFA_REQUIRE(a.n_grids >= 1 && a.res[0] > 0 && a.res[1] > 0 && a.res[2] > 0, "traverse_runs: bad grid shape");
-    const bool fused = !a.t_sorted && !a.t_indices && !a.hits;
-    NFA_REQUIRE(fused || (a.t_sorted && a.t_indices && a.hits), "traverse_runs: t_sorted, t_indices and hits must be given together");
-    NFA_REQUIRE(!fused || a.n_grids == 1, "traverse_runs: in-kernel intersection supports one grid");
-    RunsParams p;
-    p.bricks = reinterpret_cast<const unsigned long long *>(bricks);
-    p.coarse = coarse;
-    p.bx = (a.res[0] + 3) / 4; p.by = (a.res[1] + 3) / 4; p.bz = (a.res[2] + 3) / 4;
-    const int64_t nb = (int64_t)a.n_grids * p.bx * p.by * p.bz;
-    NFA_REQUIRE(nb < ((int64_t)1 << 31), "traverse_runs: grid too large");
-    p.n_coarse_words = (int32_t)((nb + 31) / 32);
-    p.run_cnts = run_cnts;
-    p.runs = reinterpret_cast<unsigned long long *>(runs);
-    p.max_runs = max_runs;
-    p.n_rays = a.n_rays;
-    p.overflow = overflow_count;
-    p.order = ray_order;
-    // near_hint: the value most (or all) entries of near_planes hold, NaN if unknown.  Rays whose near plane
-    // differs bit-wise simply do not use the table.
-    if (near_hint == near_hint) approach_table_build(p.approach, near_hint, a.step_size);
-    else p.approach.n = 0;
-    int64_t lds_words = COARSE_LDS_WORDS;
-    if (const char *e = getenv("NFA_COARSE_LDS_WORDS")) lds_words = atol(e);  // tuning experiments
-    const bool lds = p.n_coarse_words <= lds_words;
-    const size_t shmem = (size_t)EV_MAX * 256 * 4 + (lds ? (size_t)p.n_coarse_words * 4 : 0);
-    const unsigned grid = grid_1d(a.n_rays, 256, 1 << 20);
-    if (fused) {
-        if (lds) hipLaunchKernelGGL((runs_kernel<true, true>), dim3(grid), dim3(256), shmem, s, a, p);
-        else     hipLaunchKernelGGL((runs_kernel<true, false>), dim3(grid), dim3(256), shmem, s, a, p);
-    } else {
-        if (lds) hipLaunchKernelGGL((runs_kernel<false, true>), dim3(grid), dim3(256), shmem, s, a, p);
-        else     hipLaunchKernelGGL((runs_kernel<false, false>), dim3(grid), dim3(256), shmem, s, a, p);
-    }
-    NFA_CHECK_LAUNCH("traverse_runs");
     return NFA_OK;
 }
 

@@ -1,0 +1,483 @@
+// walk.hip -- the run-length walk of the constant-step traversal (cone_angle == 0): one DDA pass per ray that leaves
+// RUN RECORDS (n consecutive samples with one exact fp32 increment) for traverse2.hip's coalesced expansions.
+//
+// Reference semantics: cuda/csrc/grid.cu:68-282 (kernel), include/utils_grid.cuh:58-142 (setup_traversal,
+// single_traversal); the reference walks every ray twice (count + fill) with one scattered 1-byte grid load, a
+// per-sample loop and three-way divergence per cell.  The walk is bound by instruction issue, not by memory, so it
+// is built around the instruction count per cell:
+//
+//   phase 1  the cell loop does ONLY the DDA: the three boundary distances, a packed step counter that ends the span
+//            (three 10-bit fields with a guard bit each: the step that would leave the span's last cell clears a guard),
+//            a linear bit index that moves by a per-axis stride, one 4-byte load per cell from the 1-bit-per-cell copy of
+//            the grid (issued for the NEXT cell: the cell sequence does not depend on occupancy), and one LDS store: the
+//            exit distance of the current cell goes to the slot of the ray's open list entry, and the slot index moves
+//            on when the occupancy flips.  No marching, no branches besides the loop's own.  ~25 vector instructions.
+//   phase 2  a ray's list is a handful of thresholds of alternating kind (skip to / emit to).  Inside one binade every
+//            step of the serial accumulation t += dt adds the same number q of ulps (march.h), so the march to a
+//            threshold is "the smallest J with fl(t + J q ulp + dt/2) >= thr": an fp32 estimate and four exact probes,
+//            straight-line code, no loop.  Events that leave the binade (or stand on the near plane, or meet an exact
+//            tie) are left for a general path that the whole wave runs together once the lock-step loop has drained.
+//
+// Results are bit-identical to the serial accumulation (oracle/nerfacc_oracle.c; tests/test_march_cpu.py checks
+// the same marching code against the serial loop on the CPU).
+#include "common.hip.h"
+#include "march.h"
+
+namespace nfa {
+
+constexpr int WK_EV = 16;                  // list slots per ray: 16 KiB of LDS per 256 rays -> 8 workgroups per CU
+constexpr uint32_t WK_GUARD = (1u << 9) | (1u << 19) | (1u << 29);
+constexpr int WK_MAX_RES = 512;            // 9-bit step counters
+
+struct WalkParams {
+    const uint32_t *bits;        // 1 bit per cell, `pad` zero bits in front of cell 0 and behind the last cell
+    int32_t pad;                 // multiple of 32, >= the largest index stride (one step outside the grid stays inside the buffer)
+    int32_t cells_per_level;
+    int32_t *run_cnts;           // [n_rays]
+    unsigned long long *runs;    // [max_runs, n_rays] slot-major
+    int64_t n_rays;
+    int32_t max_runs;
+    int32_t *overflow;           // [1] rays with more runs than max_runs
+    const int32_t *order;        // lane -> ray assignment or NULL
+    ApproachTable approach;      // march.h; n == 0: none
+};
+
+enum { WK_EMPTY = 0, WK_OCC = 1, WK_SPAN = 2 };
+
+// Marcher state of one ray (phase 2)
+struct Marcher {
+    float t_last;
+    int32_t continuous;          // 0 / 1
+    int32_t n_samples, n_chains, n_runs;
+    float run_inc;               // increment of the open run (0: none)
+    float span_tmax;             // this_tmax of the span the list entries belong to (thresholds are clamped here)
+    int32_t ptype;               // kind of the next cell entry (kinds alternate inside a span)
+    int32_t at_near;             // t_last is still the near plane
+    // stable increment of the binade t_last is in: fe = biased exponent it was derived for, fq = 0: none (exact tie)
+    uint32_t fe, fq;
+    float fstep, frcp;
+};
+
+__device__ __forceinline__ float vmin_f32(float a, float b)
+{
+    float m;
+    asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));  // fminf costs two canonicalisations more; no NaN reaches it for finite rays
+    return m;
+}
+
+__device__ __forceinline__ void marcher_refresh(Marcher &s, float dt)
+{
+    const uint32_t e = f32_bits(s.t_last) >> 23;
+    if (e == s.fe) return;
+    s.fe = e; s.fq = 0u; s.fstep = 0.f; s.frcp = 0.f;
+    if (e >= 1u && e < 254u) {
+        const float r = ldexpf(dt, 150 - (int)e);   // dt / ulp(t): exact
+        if (r >= 0.5f && r < 8388608.0f) {
+            const float k = floorf(r), f = r - k;
+            if (f != 0.5f) {                         // an exact tie depends on t's parity: general path
+                s.fq = (uint32_t)k + (f > 0.5f ? 1u : 0u);
+                s.fstep = ldexpf((float)s.fq, (int)e - 150);  // q ulps, exact
+                s.frcp = 1.0f / s.fstep;
+            }
+        }
+    }
+}
+
+// n samples t0, t0 + inc, ... join the ray's run list; a run record {t_first : f32 | k_start : 31, continues_previous : 1}
+// is written when a run starts (its length is the next record's k_start, or the ray's count)
+__device__ __forceinline__ void marcher_emit(Marcher &s, float t0, float inc, uint32_t n, const WalkParams &p, int64_t tid)
+{
+    if (!(s.continuous && inc == s.run_inc)) {
+        if (s.n_runs < p.max_runs)
+            p.runs[(int64_t)s.n_runs * p.n_rays + tid] =
+                (unsigned long long)f32_bits(t0) |
+                ((unsigned long long)((uint32_t)s.n_samples | (s.continuous ? 0x80000000u : 0u)) << 32);
+        s.n_runs++;
+        s.n_chains += s.continuous ? 0 : 1;
+        s.run_inc = inc;
+    }
+    s.n_samples += (int32_t)n;
+    s.continuous = 1;
+}
+
+// One list entry in straight-line code: t_last stays inside its binade and the stable increment is known.
+// Returns false (nothing changed) when the general path has to do it.
+__device__ __forceinline__ bool marcher_fast(Marcher &s, float thr, int type, float half, int32_t limit, const WalkParams &p,
+                                             int64_t tid)
+{
+    if (s.at_near) return false;
+    const float t = s.t_last;
+    if (!(t + half < thr)) {  // the serial loop would not take a step
+        if (type == WK_EMPTY) s.continuous = 0;
+        return true;
+    }
+    const uint32_t bt = f32_bits(t);
+    if ((bt >> 23) != s.fe || s.fq == 0u) return false;
+    const uint32_t q = s.fq;
+    const float est = ((thr - half) - t) * s.frcp;        // steps until the condition fails: an estimate, probed below
+    if (!(est < 4194304.0f)) return false;
+    const uint32_t c = (uint32_t)fmaxf(est, 1.0f);
+    const uint32_t a = c - 1u;
+    const uint32_t room = (bt | 0x7FFFFFu) - bt;          // bit patterns left in the binade
+    // (a + 3) q <= room, exactly: products below 2^24 are exact in fp32, larger ones exceed room < 2^23 anyway
+    if (!((float)(a + 3u) * (float)q <= (float)room)) return false;
+    // cond(j) = fl(t_j + half) < thr is non-increasing in j; cond(0) holds
+    const uint32_t b0 = mad_u24(a, q, bt);
+    const bool f0 = bits_f32(b0) + half < thr;
+    const bool f1 = bits_f32(b0 + q) + half < thr;
+    const bool f2 = bits_f32(b0 + 2u * q) + half < thr;
+    const bool f3 = bits_f32(b0 + 3u * q) + half < thr;
+    if (!f0 || f3) return false;                          // the estimate was off by more than the window
+    uint32_t J = a + 1u + (f1 ? 1u : 0u) + (f2 ? 1u : 0u);  // cond(J - 1) true, cond(J) false
+    if (type == WK_OCC) {
+        if (limit > 0) J = min(J, (uint32_t)(limit - s.n_samples));
+        marcher_emit(s, t, s.fstep, J, p, tid);
+    } else if (type == WK_EMPTY) {
+        s.continuous = 0;
+    }
+    s.t_last = bits_f32(bt + J * q);
+    return true;
+}
+
+// The same entry through march.h's stepper: binade boundaries, exact ties, the way from the near plane (tabulated),
+// denormal / huge distances, no-progress steps.
+__device__ __forceinline__ void marcher_general(Marcher &s, float thr, int type, float dt, float half, int32_t limit,
+                                                const WalkParams &p, int64_t tid)
+{
+    Stepper stp;
+    stepper_init(stp);
+    const bool emit = type == WK_OCC;
+    if (s.at_near) {
+        s.at_near = 0;
+        if (!emit) approach_table_apply(p.approach, stp, s.t_last, half, thr);
+    }
+    for (;;) {
+        if (!(s.t_last + half < thr)) break;
+        uint32_t budget = 0xFFFFFFFFu;
+        if (emit && limit > 0) {
+            if (s.n_samples >= limit) break;
+            budget = (uint32_t)(limit - s.n_samples);
+        }
+        const float t = s.t_last;
+        float tn = t, inc;
+        const uint32_t n = stepper_advance(stp, tn, dt, half, thr, budget, &inc);
+        if (n == 0u) {  // no progress (see oracle): skipping jumps to the target, emission stops
+            if (!emit) s.t_last = thr;
+            break;
+        }
+        if (emit) marcher_emit(s, t, inc, n, p, tid);
+        s.t_last = tn;
+    }
+    if (type == WK_EMPTY) s.continuous = 0;
+    marcher_refresh(s, dt);
+}
+
+// Phase 2: the closed entries [0, cnt) of this lane's list.  ev_span bit k: slots k, k + 1 hold (this_tmin, this_tmax) of a
+// span start; bit 16 + k: kind of the cell entry in slot k when it is the first one of its span.
+__device__ __forceinline__ void marcher_run(Marcher &s, const char *col /* LDS column of this lane */, int32_t cnt, uint32_t ev_span,
+                                            float dt, int32_t limit, const WalkParams &p, int64_t tid)
+{
+    const float half = dt * 0.5f;
+    int32_t k = 0;
+    for (;;) {
+        bool slow = false;
+        float thr = 0.f;
+        int type = 0, adv = 1, next_ptype = 0;
+        while (k < cnt) {
+            if (limit > 0 && s.n_samples >= limit) { k = cnt; break; }  // grid.cu:184: nothing moves once the limit is hit
+            const float v0 = *reinterpret_cast<const float *>(col + (k << 10));
+            if ((ev_span >> k) & 1u) {
+                s.span_tmax = *reinterpret_cast<const float *>(col + ((k + 1) << 10));
+                thr = v0; type = WK_SPAN; adv = 2;
+                next_ptype = (int)((ev_span >> (16 + k + 2)) & 1u);
+            } else {
+                thr = vmin_f32(v0, s.span_tmax);
+                type = s.ptype; adv = 1;
+                next_ptype = s.ptype ^ 1;
+            }
+            if (type == WK_SPAN && s.continuous) { k += adv; s.ptype = next_ptype; continue; }  // grid.cu:153: `if (!continuous)`
+            if (!marcher_fast(s, thr, type, half, limit, p, tid)) { slow = true; break; }
+            k += adv; s.ptype = next_ptype;
+        }
+        if (!__any(slow)) break;
+        if (slow) {
+            marcher_general(s, thr, type, dt, half, limit, p, tid);
+            k += adv; s.ptype = next_ptype;
+        }
+    }
+}
+
+// DDA state of the span being walked
+struct WalkSpan {
+    float tx, ty, tz, dx, dy, dz;
+    int32_t sx, sy, sz;       // index stride of a step along each axis
+    uint32_t rem;             // steps left per axis (9 bits + guard each)
+    int32_t idx;              // padded bit index of the current cell
+};
+
+// setup_traversal (include/utils_grid.cuh:58-114) in the reference's operation order
+__device__ __forceinline__ void walk_span_setup(const nfa_traverse_args &a, const WalkParams &p, const float o[3], const float d[3],
+                                                int32_t level, float this_tmin, float this_tmax, WalkSpan &sp)
+{
+    const float eps = 1e-6f;
+    const float *bmin = a.aabbs + 6 * level, *bmax = bmin + 3;
+    float tdist[3], delta[3];
+    int32_t cur[3], stepi[3], nst[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const float inv = 1.0f / d[ax];
+        const float resf = (float)a.res[ax];
+        const float extent = bmax[ax] - bmin[ax];
+        const float voxel = extent / resf;
+        const float ray_start = o[ax] + d[ax] * (this_tmin + eps);
+        const float ray_end = o[ax] + d[ax] * (this_tmax - eps);
+        int32_t c = (int32_t)(((ray_start - bmin[ax]) / extent) * resf);
+        int32_t f = (int32_t)(((ray_end - bmin[ax]) / extent) * resf);
+        c = max(0, min(c, a.res[ax] - 1));
+        f = max(0, min(f, a.res[ax] - 1));
+        const int32_t start_index = c + (d[ax] > 0.0f ? 1 : 0);
+        const float tmax_ax = ((bmin[ax] + (((float)start_index * voxel) - ray_start)) * inv) + this_tmin;
+        const float step_f = (d[ax] == 0.0f) ? 0.0f : (d[ax] > 0.0f ? 1.0f : -1.0f);
+        tdist[ax] = (d[ax] == 0.0f) ? this_tmax : tmax_ax;
+        const int32_t st = (int32_t)step_f;
+        const float delta_tmp = voxel * inv * step_f;
+        delta[ax] = (d[ax] == 0.0f) ? this_tmax : delta_tmp;
+        cur[ax] = c;
+        stepi[ax] = st;
+        // The reference leaves the loop when cur == final + step (utils_grid.cuh:138).  Steps along this axis until then:
+        // |f - c| + 1 when the final cell lies in the direction of travel; otherwise that test never fires and the ray
+        // would walk out of the grid (undefined upstream): stop where it would leave the grid.
+        const int32_t ahead = (f - c) * st;
+        int32_t n = ahead + 1;
+        if (st == 0) n = (f == c) ? 1 : WK_MAX_RES;
+        else if (ahead < 0) n = (st > 0 ? a.res[ax] - 1 - c : c) + 1;
+        nst[ax] = max(1, min(n, WK_MAX_RES));
+    }
+    sp.tx = tdist[0]; sp.ty = tdist[1]; sp.tz = tdist[2];
+    sp.dx = delta[0]; sp.dy = delta[1]; sp.dz = delta[2];
+    const int32_t ryz = a.res[1] * a.res[2];
+    sp.sx = stepi[0] * ryz; sp.sy = stepi[1] * a.res[2]; sp.sz = stepi[2];
+    sp.rem = (uint32_t)(nst[0] - 1) | ((uint32_t)(nst[1] - 1) << 10) | ((uint32_t)(nst[2] - 1) << 20) | WK_GUARD;
+    sp.idx = p.pad + level * p.cells_per_level + cur[0] * ryz + cur[1] * a.res[2] + cur[2];
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(256) void walk_kernel(const nfa_traverse_args a, const WalkParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char ev_lds[];   // [WK_EV][256] floats
+    char *const col = ev_lds + 4 * threadIdx.x;
+    const float dt = a.step_size;
+    const int32_t limit = a.traverse_steps_limit;
+    const uint32_t *__restrict__ bits = p.bits;
+    for (int64_t slot_i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; slot_i < a.n_rays;
+         slot_i += (int64_t)blockDim.x * gridDim.x) {
+        const int64_t tid = p.order ? (int64_t)p.order[slot_i] : slot_i;
+        if (a.mode == 2 && a.rays_mask != nullptr && !a.rays_mask[tid]) {
+            if (a.terminate_planes) a.terminate_planes[tid] = a.near_planes[tid];
+            a.sm_cnts[tid] = 0;
+            if (a.iv_cnts) a.iv_cnts[tid] = 0;
+            p.run_cnts[tid] = 0;
+            continue;
+        }
+        const float near_plane = a.near_planes[tid], far_plane = a.far_planes[tid];
+        const float o[3] = {a.rays_o[3 * tid], a.rays_o[3 * tid + 1], a.rays_o[3 * tid + 2]};
+        const float d[3] = {a.rays_d[3 * tid], a.rays_d[3 * tid + 1], a.rays_d[3 * tid + 2]};
+        Marcher s;
+        s.t_last = near_plane; s.continuous = 0; s.n_samples = 0; s.n_chains = 0; s.n_runs = 0; s.run_inc = 0.f;
+        s.span_tmax = 0.f; s.ptype = 0; s.at_near = 1; s.fe = 0xFFFFFFFFu; s.fq = 0u; s.fstep = 0.f; s.frcp = 0.f;
+
+        float f_tmin = 0.f, f_tmax = 0.f;
+        bool f_pending = false;
+        if (FUSED) {  // slab test (include/utils_grid.cuh:10-55) with near = -inf, far = +inf (grid.py:158)
+            const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
+            float tmin, tmax, lo, hi;
+            bool hit = true;
+            const float *bmin = a.aabbs, *bmax = a.aabbs + 3;
+            if (inv[0] >= 0) { tmin = (bmin[0] - o[0]) * inv[0]; tmax = (bmax[0] - o[0]) * inv[0]; }
+            else             { tmin = (bmax[0] - o[0]) * inv[0]; tmax = (bmin[0] - o[0]) * inv[0]; }
+#pragma unroll
+            for (int ax = 1; ax < 3; ++ax) {
+                if (inv[ax] >= 0) { lo = (bmin[ax] - o[ax]) * inv[ax]; hi = (bmax[ax] - o[ax]) * inv[ax]; }
+                else              { lo = (bmax[ax] - o[ax]) * inv[ax]; hi = (bmin[ax] - o[ax]) * inv[ax]; }
+                if (tmin > hi || lo > tmax) hit = false;
+                if (lo > tmin) tmin = lo;
+                if (hi < tmax) tmax = hi;
+            }
+            if (tmax <= 0) hit = false;
+            f_tmin = fmaxf(tmin, near_plane); f_tmax = fminf(tmax, far_plane);
+            f_pending = hit && f_tmin < f_tmax;
+        }
+        const int32_t G = a.n_grids;
+        int32_t next_i = 0;  // next entry of the event walk over the sorted intersections (non-fused)
+
+        WalkSpan sp;
+        sp.tx = sp.ty = sp.tz = sp.dx = sp.dy = sp.dz = 0.f; sp.sx = sp.sy = sp.sz = 0; sp.rem = 0u; sp.idx = p.pad;
+        int32_t in_span = 0, has_open = 0, open_type = 0, type = 0;
+        uint32_t ev_addr = 0u;      // byte offset of the open entry's slot in this lane's column
+        uint32_t ev_span = 0u;
+        float m_last = 0.f;
+        const uint32_t ev_last = (uint32_t)(WK_EV - 1) << 10;
+
+        for (;;) {
+            // ---------------- phase 1
+            int32_t finished = 0;
+            for (;;) {
+                if (!in_span) {
+                    const uint32_t used = (ev_addr >> 10) + (uint32_t)has_open;
+                    if (used > (uint32_t)(WK_EV - 3)) break;  // a span start needs two slots and one for its first entry: flush first
+                    float this_tmin = 0.f, this_tmax = 0.f;
+                    int32_t level = 0;
+                    bool found = false;
+                    if (FUSED) {
+                        found = f_pending; f_pending = false;
+                        this_tmin = f_tmin; this_tmax = f_tmax;
+                    } else {  // grid.cu:125-150
+                        const uint8_t *hits = a.hits + tid * G;
+                        const float *ts = a.t_sorted + tid * 2 * G;
+                        const int64_t *ti = a.t_indices + tid * 2 * G;
+                        while (!found && next_i < 2 * G - 1) {
+                            const int32_t i = next_i++;
+                            const int64_t idx = ti[i];
+                            level = (int32_t)(idx % G);
+                            if (!hits[level]) continue;
+                            if (!(idx < G)) {
+                                const int64_t nidx = ti[i + 1];
+                                if (nidx < G) continue;
+                                level = (int32_t)(nidx % G);
+                                if (!hits[level]) continue;
+                            }
+                            this_tmin = fmaxf(ts[i], near_plane); this_tmax = fminf(ts[i + 1], far_plane);
+                            if (this_tmin >= this_tmax) continue;
+                            found = true;
+                        }
+                    }
+                    if (!found) { finished = 1; break; }
+                    // the open entry of the previous span is complete; then the span start: (this_tmin, this_tmax)
+                    uint32_t kk = used;
+                    *reinterpret_cast<float *>(col + (kk << 10)) = this_tmin;
+                    *reinterpret_cast<float *>(col + ((kk + 1u) << 10)) = this_tmax;
+                    ev_span |= 1u << kk;
+                    walk_span_setup(a, p, o, d, level, this_tmin, this_tmax, sp);
+                    const uint32_t w0 = bits[(uint32_t)sp.idx >> 5];
+                    type = (int32_t)((w0 >> (sp.idx & 31)) & 1u);
+                    ev_span |= (uint32_t)type << (16u + kk + 2u);
+                    open_type = type;
+                    ev_addr = (kk + 2u) << 10;
+                    has_open = 1;
+                    in_span = 1;
+                }
+                // the reference's cell loop (grid.cu:184-272) reduced to the DDA
+                float tx = sp.tx, ty = sp.ty, tz = sp.tz;
+                uint32_t rem = sp.rem;
+                int32_t idx = sp.idx;
+                do {
+                    const uint32_t changed = (uint32_t)(type ^ open_type);
+                    ev_addr += changed << 10;                 // the open entry is complete when the occupancy flips
+                    open_type = type;
+                    const float n = vmin_f32(ty, tz);
+                    const float m = vmin_f32(tx, n);          // exit distance of this cell (clamped to this_tmax by phase 2)
+                    *reinterpret_cast<float *>(col + ev_addr) = m;
+                    m_last = m;
+                    // single_traversal (include/utils_grid.cuh:116-142): x if tx < ty && tx < tz, else y if ty < tz, else z.
+                    // The chosen axis' distance IS m, so its update is m + delta.
+                    const bool s0 = tx < n;
+                    const bool s1 = ty < tz;
+                    const float dsel = s0 ? sp.dx : (s1 ? sp.dy : sp.dz);
+                    const float nm = m + dsel;
+                    const float ty1 = s1 ? nm : ty, tz1 = s1 ? tz : nm;
+                    tx = s0 ? nm : tx;
+                    ty = s0 ? ty : ty1;
+                    tz = s0 ? tz : tz1;
+                    idx += s0 ? sp.sx : (s1 ? sp.sy : sp.sz);
+                    rem -= s0 ? 1u : (s1 ? (1u << 10) : (1u << 20));
+                    const uint32_t w = bits[(uint32_t)idx >> 5];   // one step outside the grid stays inside the padding
+                    type = (int32_t)__builtin_amdgcn_ubfe(w, (uint32_t)idx, 1u);  // bit (idx & 31)
+                } while ((rem & WK_GUARD) == WK_GUARD && ev_addr < ev_last);
+                sp.tx = tx; sp.ty = ty; sp.tz = tz; sp.rem = rem; sp.idx = idx;
+                if ((rem & WK_GUARD) != WK_GUARD) in_span = 0;
+                else break;  // list full
+            }
+            // ---------------- phase 2
+            int32_t cnt = (int32_t)(ev_addr >> 10);
+            if (finished && has_open) { cnt += 1; has_open = 0; }
+            marcher_run(s, col, cnt, ev_span, dt, limit, p, tid);
+            if (finished || (limit > 0 && s.n_samples >= limit)) break;
+            // the open entry moves to slot 0
+            ev_span = 0u;
+            ev_addr = 0u;
+            if (has_open) *reinterpret_cast<float *>(col) = m_last;
+        }
+        if (a.terminate_planes) a.terminate_planes[tid] = s.t_last;
+        a.sm_cnts[tid] = s.n_samples;
+        if (a.iv_cnts) a.iv_cnts[tid] = s.n_samples + s.n_chains;  // edges = samples + one leading edge per chain
+        // rays with > 2^21 samples go to the serial fill too (the expansion packs a 27-bit batch offset)
+        int32_t n_runs = s.n_runs;
+        if (s.n_samples > (1 << 21) && n_runs <= p.max_runs) n_runs = p.max_runs + 1;
+        p.run_cnts[tid] = n_runs;
+        if (n_runs > p.max_runs) atomicAdd(p.overflow, 1);
+    }
+}
+
+}  // namespace nfa
+
+using namespace nfa;
+
+extern "C" {
+
+int64_t nfa_walk_bits_words(int32_t n_grids, const int32_t *res, int32_t *pad_out)
+{
+    const int64_t cells = (int64_t)n_grids * res[0] * res[1] * res[2];
+    const int64_t stride = (int64_t)res[1] * res[2];
+    const int64_t pad = ((stride + 31) / 32) * 32 + 32;
+    if (pad_out) *pad_out = (int32_t)pad;
+    return pad / 32 + (cells + 31) / 32 + pad / 32 + 1;
+}
+
+int nfa_traverse_runs(const nfa_traverse_args *pa, const uint32_t *bits, int32_t *run_cnts, uint64_t *runs, int32_t max_runs,
+                      int32_t *overflow_count, float near_hint, const int32_t *ray_order, nfa_stream_t stream)
+{
+    NFA_REQUIRE(pa != nullptr, "traverse_runs: null args");
+    const nfa_traverse_args &a = *pa;
+    NFA_REQUIRE(a.n_rays >= 0 && a.n_rays < (int64_t)1 << 31, "traverse_runs: n_rays out of range");
+    NFA_REQUIRE(overflow_count, "traverse_runs: overflow_count is null");
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(overflow_count, 0, sizeof(int32_t), s) != hipSuccess) { set_error("traverse_runs: memset failed"); return NFA_EHIP; }
+    if (a.n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(a.step_size > 0.0f && a.cone_angle == 0.0f, "traverse_runs: needs step_size > 0 and cone_angle == 0");
+    NFA_REQUIRE(a.mode == 0 || a.mode == 2, "traverse_runs: mode must be 0 (all rays) or 2 (rays_mask + limit)");
+    NFA_REQUIRE(a.mode != 2 || a.traverse_steps_limit > 0, "traverse_steps_limit must be > 0 when over_allocate is true");
+    NFA_REQUIRE(a.rays_o && a.rays_d && a.aabbs && a.near_planes && a.far_planes && a.sm_cnts && bits && run_cnts && runs,
+                "traverse_runs: null pointer");
+    NFA_REQUIRE(max_runs >= 1 && max_runs <= 32, "traverse_runs: max_runs must be in [1, 32]");
+    NFA_REQUIRE(a.n_grids >= 1 && a.res[0] > 0 && a.res[1] > 0 && a.res[2] > 0, "traverse_runs: bad grid shape");
+    NFA_REQUIRE(a.res[0] <= WK_MAX_RES && a.res[1] <= WK_MAX_RES && a.res[2] <= WK_MAX_RES,
+                "traverse_runs: at most 512 cells per axis (use nfa_traverse_grids beyond)");
+    const bool fused = !a.t_sorted && !a.t_indices && !a.hits;
+    NFA_REQUIRE(fused || (a.t_sorted && a.t_indices && a.hits), "traverse_runs: t_sorted, t_indices and hits must be given together");
+    NFA_REQUIRE(!fused || a.n_grids == 1, "traverse_runs: in-kernel intersection supports one grid");
+    WalkParams p;
+    p.bits = bits;
+    int32_t pad = 0;
+    const int64_t words = nfa_walk_bits_words(a.n_grids, a.res, &pad);
+    NFA_REQUIRE(words < ((int64_t)1 << 26), "traverse_runs: grid too large");  // bit indices stay below 2^31
+    p.pad = pad;
+    p.cells_per_level = a.res[0] * a.res[1] * a.res[2];
+    p.run_cnts = run_cnts;
+    p.runs = reinterpret_cast<unsigned long long *>(runs);
+    p.max_runs = max_runs;
+    p.n_rays = a.n_rays;
+    p.overflow = overflow_count;
+    p.order = ray_order;
+    // near_hint: the value most (or all) entries of near_planes hold, NaN if unknown.  Rays whose near plane
+    // differs bit-wise simply do not use the table.
+    if (near_hint == near_hint) approach_table_build(p.approach, near_hint, a.step_size);
+    else p.approach.n = 0;
+    const size_t shmem = (size_t)WK_EV * 256 * 4;
+    const unsigned grid = grid_1d(a.n_rays, 256, 1 << 20);
+    if (fused) hipLaunchKernelGGL((walk_kernel<true>), dim3(grid), dim3(256), shmem, s, a, p);
+    else       hipLaunchKernelGGL((walk_kernel<false>), dim3(grid), dim3(256), shmem, s, a, p);
+    NFA_CHECK_LAUNCH("traverse_runs");
+    return NFA_OK;
+}
+
+}  // extern "C"

@@ -184,7 +184,7 @@ def traverse_grids(
             # masks (grid.cu:401-403, examples/utils.py:362-365).
             iv_starts = _exclusive_cumsum(iv_cnts, totals[0:1])
             sm_starts = _exclusive_cumsum(sm_cnts, totals[1:2])
-        elif float(step_size) > 0.0 and float(cone_angle) == 0.0:
+        elif float(step_size) > 0.0 and float(cone_angle) == 0.0 and max(binaries.shape[1:]) <= WALK_MAX_RES:
             # constant step: ONE walk (run records) + two coalesced expansions instead of the reference's count and
             # fill passes (grid.cu:405-471); rays with more than MAX_RUNS runs are filled by the serial kernel.
             iv_cnts, sm_cnts = torch.empty(n_rays, **i64), torch.empty(n_rays, **i64)
@@ -192,10 +192,10 @@ def traverse_grids(
             a = _traverse_args(rays_o, rays_d, None, binaries, aabbs, t_sorted, t_indices, hits, near_planes,
                                far_planes, step_size, cone_angle, traverse_steps_limit, 0)
             a.iv_cnts, a.sm_cnts, a.terminate_planes = B.ptr(iv_cnts), B.ptr(sm_cnts), B.ptr(terminate)
-            bricks, coarse = _get_bricks(binaries)
+            bits = _get_walk_bits(binaries)
             run_cnts = torch.empty(n_rays, dtype=torch.int32, device=dev)
             runs = torch.empty((MAX_RUNS, n_rays), dtype=torch.int64, device=dev)
-            B.call("nfa_traverse_runs", C.byref(a), B.ptr(bricks), B.ptr(coarse), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
+            B.call("nfa_traverse_runs", C.byref(a), B.ptr(bits), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
                    B.ptr(meta[2:3]), float("nan") if near_hint is None else near_hint, None, B.stream())
             iv_packed = _cumsum_packed(iv_cnts, meta[0:1])
             sm_packed = _cumsum_packed(sm_cnts, meta[1:2])
@@ -281,6 +281,28 @@ def _get_bricks(binaries: Tensor):
     return bricks, coarse
 
 
+WALK_MAX_RES = 512  # cells per axis the run-length walk's packed step counters cover (csrc/walk.hip)
+
+
+def _get_walk_bits(binaries: Tensor) -> Tensor:
+    """1-bit-per-cell copy of ``binaries`` for the run-length walk, with zero padding on both sides so that the bit of a
+    cell one step outside the grid can be loaded unconditionally (derived cache keyed on the tensor's version counter,
+    never serialised)."""
+    cached = getattr(binaries, "_nfa_walk_bits", None)
+    if cached is not None and cached[0] == binaries._version:
+        return cached[1]
+    res = (C.c_int32 * 3)(*binaries.shape[1:])
+    pad = C.c_int32(0)
+    words = int(B.load().nfa_walk_bits_words(binaries.shape[0], res, C.byref(pad)))
+    bits = torch.zeros(words, dtype=torch.int32, device=binaries.device)
+    B.call("nfa_pack_bits", B.ptr(binaries), binaries.numel(), bits.data_ptr() + 4 * (pad.value // 32), B.stream())
+    try:
+        binaries._nfa_walk_bits = (binaries._version, bits)
+    except Exception:  # pragma: no cover
+        pass
+    return bits
+
+
 _SIDE_STREAMS: dict = {}
 
 
@@ -314,7 +336,7 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
     rays get no samples, every other ray at most ``traverse_steps_limit``.
     """
     limit = -1 if traverse_steps_limit is None else int(traverse_steps_limit)
-    use_runs = float(step_size) > 0.0 and float(cone_angle) == 0.0
+    use_runs = float(step_size) > 0.0 and float(cone_angle) == 0.0 and max(binaries.shape[1:]) <= WALK_MAX_RES
     # distance-dependent steps: run records from the count pass + a coalesced expansion instead of a second walk
     use_cone_runs = CONE_RUNS and float(step_size) > 0.0 and float(cone_angle) > 0.0
     if not use_runs and (rays_mask is not None or limit > 0):
@@ -339,7 +361,7 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
         a.sm_cnts = B.ptr(sm_cnts)
         a.terminate_planes = B.ptr(terminate)
         if use_runs:
-            bricks, coarse = _get_bricks(binaries)
+            bits = _get_walk_bits(binaries)
             run_cnts = torch.empty(n_rays, dtype=torch.int32, device=dev)
             runs = torch.empty((MAX_RUNS, n_rays), dtype=torch.int64, device=dev)  # slot-major run records
             order = None
@@ -350,7 +372,7 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
                 B.call("nfa_bin_rays", B.ptr(rays_o), B.ptr(rays_d), n_rays, B.ptr(aabbs[-1]), B.ptr(order), B.ptr(scratch),
                        B.stream())
             # near_hint: the scalar near plane when the caller built near_planes from one (accelerator only)
-            B.call("nfa_traverse_runs", C.byref(a), B.ptr(bricks), B.ptr(coarse), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
+            B.call("nfa_traverse_runs", C.byref(a), B.ptr(bits), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
                    B.ptr(meta[3:4]), float("nan") if near_hint is None else float(near_hint), B.ptr(order), B.stream())
         elif use_cone_runs:
             _get_bricks(binaries)
