@@ -132,9 +132,8 @@ int nfa_traverse_grids(const nfa_traverse_args *args, nfa_stream_t stream);
 /* Run-length traversal used by the sampler and by traverse_grids when step_size > 0 and cone_angle == 0 (same
  * results as nfa_traverse_grids, one DDA walk instead of the reference's count + fill passes, ref: cuda/csrc/grid.cu:
  * 405-471; coalesced output):
- *   nfa_walk_bits_words  size (uint32 words) of the 1-bit-per-cell grid copy the walk reads: the cells of all levels in
- *                      the order of `binaries`, *pad_bits zero bits in front of cell 0 and behind the last cell
- *                      (a multiple of 32: nfa_pack_bits(binaries, n_cells, bits + *pad_bits / 32) fills a zeroed buffer).
+ *   nfa_pack_walk_bits 1-bit-per-cell copy of the torch.bool grid in the walk's own cell order (the coordinate bits of
+ *                      x, y, z interleaved: a 128-byte line is a 16 x 8 x 8 block of cells); nfa_walk_bits_words() uint32.
  *   nfa_traverse_runs  per ray: sample count (args->sm_cnts), edge count (args->iv_cnts, optional), terminate plane,
  *                      run count and up to max_runs (<= 32) run records {t_first:f32 | k_start:31, continues_previous:1}
  *                      in runs[max_runs][n_rays] (slot-major: record i of ray r at runs[i * n_rays + r]); rays with
@@ -152,7 +151,8 @@ int nfa_traverse_grids(const nfa_traverse_args *args, nfa_stream_t stream);
 int64_t nfa_bricks_words(int32_t n_grids, const int32_t *res);
 int nfa_pack_bricks(const uint8_t *binaries, int32_t n_grids, const int32_t *res, uint64_t *bricks,
                     uint32_t *coarse, nfa_stream_t stream);
-int64_t nfa_walk_bits_words(int32_t n_grids, const int32_t *res, int32_t *pad_bits);
+int64_t nfa_walk_bits_words(int32_t n_grids, const int32_t *res);
+int nfa_pack_walk_bits(const uint8_t *binaries, int32_t n_grids, const int32_t *res, uint32_t *bits, nfa_stream_t stream);
 int nfa_traverse_runs(const nfa_traverse_args *args, const uint32_t *bits, int32_t *run_cnts, uint64_t *runs,
                       int32_t max_runs, int32_t *overflow_count, float near_hint, const int32_t *ray_order,
                       nfa_stream_t stream);

@@ -54,7 +54,8 @@ _SIGS = {
     "nfa_traverse_grids": [C.POINTER(TraverseArgs), _vp],
     "nfa_bricks_words": [_i32, C.POINTER(_i32)],
     "nfa_pack_bricks": [_vp, _i32, C.POINTER(_i32), _vp, _vp, _vp],
-    "nfa_walk_bits_words": [_i32, C.POINTER(_i32), C.POINTER(_i32)],
+    "nfa_walk_bits_words": [_i32, C.POINTER(_i32)],
+    "nfa_pack_walk_bits": [_vp, _i32, C.POINTER(_i32), _vp, _vp],
     "nfa_traverse_runs": [C.POINTER(TraverseArgs), _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp],
     "nfa_bin_rays": [_vp, _vp, _i64, _vp, _vp, _vp, _vp],
     "nfa_expand_runs": [_i64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],

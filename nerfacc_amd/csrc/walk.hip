@@ -25,14 +25,93 @@
 
 namespace nfa {
 
-constexpr int WK_EV = 16;                  // list slots per ray: 16 KiB of LDS per 256 rays -> 8 workgroups per CU
+#ifndef NFA_WK_EV
+#define NFA_WK_EV 16
+#endif
+constexpr int WK_EV = NFA_WK_EV;           // list slots per ray: 16 KiB of LDS per 256 rays -> 8 workgroups per CU
+#ifndef NFA_WALK_WAVES
+#define NFA_WALK_WAVES 0
+#endif
+#if NFA_WALK_WAVES > 0
+#define NFA_WALK_OCC __attribute__((amdgpu_waves_per_eu(NFA_WALK_WAVES, NFA_WALK_WAVES)))
+#else
+#define NFA_WALK_OCC
+#endif
+static_assert(NFA_WK_EV == 16, "the list-full test is bit 14 of the slot address: 16 slots of 1 KiB");
+constexpr uint32_t WK_FULL = (uint32_t)WK_EV << 10;  // slot address bit that says "the open entry sits in slot WK_EV"
 constexpr uint32_t WK_GUARD = (1u << 9) | (1u << 19) | (1u << 29);
 constexpr int WK_MAX_RES = 512;            // 9-bit step counters
 
+// Cell (x, y, z) of level l sits at bit  l << bits | dep(x, mask[0]) | dep(y, mask[1]) | dep(z, mask[2])  of the grid copy
+// (dep = deposit the coordinate's bits at the mask's positions): z0 x0 y0 in bits 0..2, then the remaining coordinate
+// bits interleaved.  A 128-byte line is a 16 x 8 x 8 block of cells (z, x, y) whatever the ray directions are: with the
+// reference's z-fastest order every lane of a wave of neighbouring rays sits in a line of its own, none of which
+// survives in the 32 KiB L1 (measured: +100 us at 128^3, +330 us at 256^3 on 1 M rays); blocked, the walk runs from L1.
+struct WalkLayout {
+    uint32_t mask[3];
+    int32_t bits;                // index bits per level
+};
+
+__host__ __device__ inline WalkLayout walk_layout(const int32_t res[3])
+{
+    WalkLayout L;
+    int nb[3];
+    for (int ax = 0; ax < 3; ++ax) {
+        nb[ax] = 0;
+        while ((1 << nb[ax]) < res[ax]) nb[ax]++;
+        L.mask[ax] = 0u;
+    }
+    // bits 0, 1, 2 belong to z, x, y (an axis of one cell leaves its bit unused), so that the lowest bit of an axis' mask is
+    // mask & 7; the higher coordinate bits follow in the same rotation, exhausted axes skipped
+    const int order[3] = {2, 0, 1};
+    int pos = 0;
+    for (int round = 0; round < 10; ++round)
+        for (int i = 0; i < 3; ++i) {
+            const int ax = order[i];
+            if (round < nb[ax]) L.mask[ax] |= 1u << pos;
+            if (round == 0 || round < nb[ax]) pos++;
+        }
+    L.bits = pos < 5 ? 5 : pos;   // a level is a whole number of 32-bit words
+    return L;
+}
+
+__host__ __device__ inline uint32_t bit_deposit(uint32_t v, uint32_t mask)
+{
+    uint32_t out = 0u;
+    for (uint32_t m = mask; m != 0u; m &= m - 1u, v >>= 1) out |= (v & 1u) ? (m & (0u - m)) : 0u;
+    return out;
+}
+__host__ __device__ inline uint32_t bit_extract(uint32_t v, uint32_t mask)
+{
+    uint32_t out = 0u, k = 0u;
+    for (uint32_t m = mask; m != 0u; m &= m - 1u, ++k) out |= (v & (m & (0u - m))) ? (1u << k) : 0u;
+    return out;
+}
+
+// one thread per 32-bit word of the grid copy
+__global__ __launch_bounds__(256) void pack_walk_bits_kernel(const uint8_t *__restrict__ binaries, int32_t n_grids, int32_t rx, int32_t ry,
+                                                             int32_t rz, WalkLayout L, uint32_t *__restrict__ bits)
+{
+    const int64_t n_words = ((int64_t)n_grids << L.bits) >> 5;
+    for (int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; wi < n_words; wi += (int64_t)blockDim.x * gridDim.x) {
+        const uint32_t base = (uint32_t)(wi << 5);
+        const uint32_t lvl = base >> L.bits, in_lvl = base & ((1u << L.bits) - 1u);
+        uint32_t w = 0u;
+        for (uint32_t b = 0; b < 32u; ++b) {
+            const uint32_t pidx = in_lvl | b;
+            const uint32_t x = bit_extract(pidx, L.mask[0]), y = bit_extract(pidx, L.mask[1]), z = bit_extract(pidx, L.mask[2]);
+            const uint32_t rest = pidx & ~(L.mask[0] | L.mask[1] | L.mask[2]);
+            if (rest == 0u && x < (uint32_t)rx && y < (uint32_t)ry && z < (uint32_t)rz &&
+                binaries[(((int64_t)lvl * rx + x) * ry + y) * rz + z])
+                w |= 1u << b;
+        }
+        bits[wi] = w;
+    }
+}
+
 struct WalkParams {
-    const uint32_t *bits;        // 1 bit per cell, `pad` zero bits in front of cell 0 and behind the last cell
-    int32_t pad;                 // multiple of 32, >= the largest index stride (one step outside the grid stays inside the buffer)
-    int32_t cells_per_level;
+    const uint32_t *bits;        // 1 bit per cell in the bit-interleaved order of WalkLayout (nfa_pack_walk_bits)
+    WalkLayout lay;
     int32_t *run_cnts;           // [n_rays]
     unsigned long long *runs;    // [max_runs, n_rays] slot-major
     int64_t n_rays;
@@ -173,7 +252,7 @@ __device__ __forceinline__ void marcher_general(Marcher &s, float thr, int type,
 }
 
 // Phase 2: the closed entries [0, cnt) of this lane's list.  ev_span bit k: slots k, k + 1 hold (this_tmin, this_tmax) of a
-// span start; bit 16 + k: kind of the cell entry in slot k when it is the first one of its span.
+// span start; bit 16 + k: kind of the first cell entry of that span (slot k + 2).
 __device__ __forceinline__ void marcher_run(Marcher &s, const char *col /* LDS column of this lane */, int32_t cnt, uint32_t ev_span,
                                             float dt, int32_t limit, const WalkParams &p, int64_t tid)
 {
@@ -189,7 +268,7 @@ __device__ __forceinline__ void marcher_run(Marcher &s, const char *col /* LDS c
             if ((ev_span >> k) & 1u) {
                 s.span_tmax = *reinterpret_cast<const float *>(col + ((k + 1) << 10));
                 thr = v0; type = WK_SPAN; adv = 2;
-                next_ptype = (int)((ev_span >> (16 + k + 2)) & 1u);
+                next_ptype = (int)((ev_span >> (16 + k)) & 1u);
             } else {
                 thr = vmin_f32(v0, s.span_tmax);
                 type = s.ptype; adv = 1;
@@ -210,9 +289,10 @@ __device__ __forceinline__ void marcher_run(Marcher &s, const char *col /* LDS c
 // DDA state of the span being walked
 struct WalkSpan {
     float tx, ty, tz, dx, dy, dz;
-    int32_t sx, sy, sz;       // index stride of a step along each axis
+    uint32_t mx, my, mz;      // bits of each axis in the interleaved cell index (0: the ray does not move along the axis)
     uint32_t rem;             // steps left per axis (9 bits + guard each)
-    int32_t idx;              // padded bit index of the current cell
+    uint32_t widx;            // interleaved index of the current cell, every axis counted in the ray's direction of travel
+    uint32_t flip;            // widx ^ flip = bit index in the grid copy (axes walked downwards reflected, level bits)
 };
 
 // setup_traversal (include/utils_grid.cuh:58-114) in the reference's operation order
@@ -255,17 +335,74 @@ __device__ __forceinline__ void walk_span_setup(const nfa_traverse_args &a, cons
     }
     sp.tx = tdist[0]; sp.ty = tdist[1]; sp.tz = tdist[2];
     sp.dx = delta[0]; sp.dy = delta[1]; sp.dz = delta[2];
-    const int32_t ryz = a.res[1] * a.res[2];
-    sp.sx = stepi[0] * ryz; sp.sy = stepi[1] * a.res[2]; sp.sz = stepi[2];
     sp.rem = (uint32_t)(nst[0] - 1) | ((uint32_t)(nst[1] - 1) << 10) | ((uint32_t)(nst[2] - 1) << 20) | WK_GUARD;
-    sp.idx = p.pad + level * p.cells_per_level + cur[0] * ryz + cur[1] * a.res[2] + cur[2];
+    // an axis walked downwards counts its reflected coordinate (2^nb - 1 - c = c ^ (2^nb - 1)) upwards: every step is "+1"
+    uint32_t widx = 0u, flip = (uint32_t)level << p.lay.bits, mk[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const uint32_t M = p.lay.mask[ax];
+        const uint32_t dep = bit_deposit((uint32_t)cur[ax], M);
+        widx |= stepi[ax] < 0 ? (dep ^ M) : dep;
+        flip |= stepi[ax] < 0 ? M : 0u;
+        mk[ax] = stepi[ax] != 0 ? M : 0u;
+    }
+    sp.mx = mk[0]; sp.my = mk[1]; sp.mz = mk[2];
+    sp.widx = widx; sp.flip = flip;
+}
+
+// One cell of the walk: `cur` is the occupancy of the cell the ray is in, `open` the kind of the ray's open list entry.
+// Closes that entry when the occupancy flips, records the cell's exit distance in the open entry's slot, steps the DDA and
+// returns the occupancy of the next cell (loaded from the 1-bit grid copy).
+__device__ __forceinline__ int32_t walk_cell(float dx, float dy, float dz, uint32_t mx, uint32_t my, uint32_t mz, uint32_t flip, float &tx,
+                                             float &ty, float &tz, uint32_t &rem, uint32_t &widx, uint32_t &ev_addr, float &m_out,
+                                             int32_t cur, int32_t open, const uint32_t *__restrict__ bits, char *ev_lds)
+{
+    const uint32_t changed = (uint32_t)(cur ^ open);
+    ev_addr += changed << 10;                 // the open entry is complete when the occupancy flips
+    const float n = vmin_f32(ty, tz);
+    const float m = vmin_f32(tx, n);          // exit distance of this cell (clamped to this_tmax by phase 2)
+    *reinterpret_cast<float *>(ev_lds + ev_addr) = m;
+    m_out = m;
+    // single_traversal (include/utils_grid.cuh:116-142): x if tx < ty && tx < tz, else y if ty < tz, else z.
+    // The chosen axis' distance IS m, so its update is m + delta.
+    const bool s0 = tx < n;
+    const bool s1 = ty < tz;
+    const float dsel = s0 ? dx : (s1 ? dy : dz);
+    const float nm = m + dsel;
+    const float ty1 = s1 ? nm : ty, tz1 = s1 ? tz : nm;
+    tx = s0 ? nm : tx;
+    ty = s0 ? ty : ty1;
+    tz = s0 ? tz : tz1;
+    rem -= s0 ? 1u : (s1 ? (1u << 10) : (1u << 20));
+    // +1 on the chosen axis' bits of the interleaved index: fill the other bits with ones so that the carry runs through
+    // them, add the axis' lowest bit, keep the axis' bits of the sum (a carry out of the top bit is dropped: one step
+    // outside the grid wraps to a valid cell, which is never used)
+    const uint32_t M = s0 ? mx : (s1 ? my : mz);
+    const uint32_t filled = widx | ~M;
+    widx = ((filled + (M & 7u)) & M) | (widx & ~M);                            // v_bfi_b32
+    const uint32_t idx = widx ^ flip;
+#if defined(NFA_WALK_EXP) && NFA_WALK_EXP == 1   /* timing experiment: no load at all */
+    return (int32_t)((idx >> 7) & 1u);
+#elif defined(NFA_WALK_EXP) && NFA_WALK_EXP == 2  /* timing experiment: every load hits one 128-byte line */
+    const uint32_t w = bits[(idx >> 5) & 31u];
+    return (int32_t)__builtin_amdgcn_ubfe(w, idx, 1u);
+#else
+    const uint32_t w = bits[idx >> 5];
+    return (int32_t)__builtin_amdgcn_ubfe(w, idx, 1u);  // bit (idx & 31)
+#endif
+}
+// stop when a step counter has run out (a guard bit is gone: the span ends) or the open entry sits in the last slot
+__device__ __forceinline__ bool walk_stop(uint32_t rem, uint32_t ev_addr)
+{
+    return ((rem & WK_GUARD) | (ev_addr & WK_FULL)) != WK_GUARD;
 }
 
 template <bool FUSED>
-__global__ __launch_bounds__(256) void walk_kernel(const nfa_traverse_args a, const WalkParams p)
+NFA_WALK_OCC __global__ __launch_bounds__(256) void walk_kernel(const nfa_traverse_args a, const WalkParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) char ev_lds[];   // [WK_EV][256] floats
-    char *const col = ev_lds + 4 * threadIdx.x;
+    __shared__ __attribute__((aligned(16))) char ev_lds[(WK_EV + 1) * 1024];   // [WK_EV + 1][256] floats
+    const uint32_t lane_off = 4u * threadIdx.x;
+    char *const col = ev_lds + lane_off;
     const float dt = a.step_size;
     const int32_t limit = a.traverse_steps_limit;
     const uint32_t *__restrict__ bits = p.bits;
@@ -311,12 +448,11 @@ __global__ __launch_bounds__(256) void walk_kernel(const nfa_traverse_args a, co
         int32_t next_i = 0;  // next entry of the event walk over the sorted intersections (non-fused)
 
         WalkSpan sp;
-        sp.tx = sp.ty = sp.tz = sp.dx = sp.dy = sp.dz = 0.f; sp.sx = sp.sy = sp.sz = 0; sp.rem = 0u; sp.idx = p.pad;
+        sp.tx = sp.ty = sp.tz = sp.dx = sp.dy = sp.dz = 0.f; sp.mx = sp.my = sp.mz = 0u; sp.rem = 0u; sp.widx = 0u; sp.flip = 0u;
         int32_t in_span = 0, has_open = 0, open_type = 0, type = 0;
-        uint32_t ev_addr = 0u;      // byte offset of the open entry's slot in this lane's column
+        uint32_t ev_addr = lane_off;  // byte offset of the open entry's slot: slot << 10 | lane offset
         uint32_t ev_span = 0u;
         float m_last = 0.f;
-        const uint32_t ev_last = (uint32_t)(WK_EV - 1) << 10;
 
         for (;;) {
             // ---------------- phase 1
@@ -324,7 +460,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const nfa_traverse_args a, co
             for (;;) {
                 if (!in_span) {
                     const uint32_t used = (ev_addr >> 10) + (uint32_t)has_open;
-                    if (used > (uint32_t)(WK_EV - 3)) break;  // a span start needs two slots and one for its first entry: flush first
+                    if (used > (uint32_t)(WK_EV - 2)) break;  // a span start needs two slots and one for its first entry: flush first
                     float this_tmin = 0.f, this_tmax = 0.f;
                     int32_t level = 0;
                     bool found = false;
@@ -358,53 +494,42 @@ __global__ __launch_bounds__(256) void walk_kernel(const nfa_traverse_args a, co
                     *reinterpret_cast<float *>(col + ((kk + 1u) << 10)) = this_tmax;
                     ev_span |= 1u << kk;
                     walk_span_setup(a, p, o, d, level, this_tmin, this_tmax, sp);
-                    const uint32_t w0 = bits[(uint32_t)sp.idx >> 5];
-                    type = (int32_t)((w0 >> (sp.idx & 31)) & 1u);
-                    ev_span |= (uint32_t)type << (16u + kk + 2u);
+                    const uint32_t idx0 = sp.widx ^ sp.flip;
+                    type = (int32_t)((bits[idx0 >> 5] >> (idx0 & 31u)) & 1u);
+                    ev_span |= (uint32_t)type << (16u + kk);
                     open_type = type;
-                    ev_addr = (kk + 2u) << 10;
+                    ev_addr = ((kk + 2u) << 10) | lane_off;
                     has_open = 1;
                     in_span = 1;
                 }
-                // the reference's cell loop (grid.cu:184-272) reduced to the DDA
+                // the reference's cell loop (grid.cu:184-272) reduced to the DDA; two cells per trip so that the kinds of
+                // the current / previous / next cell rotate through registers without moves
                 float tx = sp.tx, ty = sp.ty, tz = sp.tz;
+                const float dx = sp.dx, dy = sp.dy, dz = sp.dz;
+                const uint32_t mx = sp.mx, my = sp.my, mz = sp.mz, flip = sp.flip;
                 uint32_t rem = sp.rem;
-                int32_t idx = sp.idx;
-                do {
-                    const uint32_t changed = (uint32_t)(type ^ open_type);
-                    ev_addr += changed << 10;                 // the open entry is complete when the occupancy flips
-                    open_type = type;
-                    const float n = vmin_f32(ty, tz);
-                    const float m = vmin_f32(tx, n);          // exit distance of this cell (clamped to this_tmax by phase 2)
-                    *reinterpret_cast<float *>(col + ev_addr) = m;
-                    m_last = m;
-                    // single_traversal (include/utils_grid.cuh:116-142): x if tx < ty && tx < tz, else y if ty < tz, else z.
-                    // The chosen axis' distance IS m, so its update is m + delta.
-                    const bool s0 = tx < n;
-                    const bool s1 = ty < tz;
-                    const float dsel = s0 ? sp.dx : (s1 ? sp.dy : sp.dz);
-                    const float nm = m + dsel;
-                    const float ty1 = s1 ? nm : ty, tz1 = s1 ? tz : nm;
-                    tx = s0 ? nm : tx;
-                    ty = s0 ? ty : ty1;
-                    tz = s0 ? tz : tz1;
-                    idx += s0 ? sp.sx : (s1 ? sp.sy : sp.sz);
-                    rem -= s0 ? 1u : (s1 ? (1u << 10) : (1u << 20));
-                    const uint32_t w = bits[(uint32_t)idx >> 5];   // one step outside the grid stays inside the padding
-                    type = (int32_t)__builtin_amdgcn_ubfe(w, (uint32_t)idx, 1u);  // bit (idx & 31)
-                } while ((rem & WK_GUARD) == WK_GUARD && ev_addr < ev_last);
-                sp.tx = tx; sp.ty = ty; sp.tz = tz; sp.rem = rem; sp.idx = idx;
+                uint32_t widx = sp.widx;
+                for (;;) {
+                    const int32_t t1 = walk_cell(dx, dy, dz, mx, my, mz, flip, tx, ty, tz, rem, widx, ev_addr, m_last, type, open_type, bits, ev_lds);
+                    if (walk_stop(rem, ev_addr)) { open_type = type; type = t1; break; }
+                    const int32_t t2 = walk_cell(dx, dy, dz, mx, my, mz, flip, tx, ty, tz, rem, widx, ev_addr, m_last, t1, type, bits, ev_lds);
+                    open_type = t1; type = t2;
+                    if (walk_stop(rem, ev_addr)) break;
+                }
+                sp.tx = tx; sp.ty = ty; sp.tz = tz; sp.rem = rem; sp.widx = widx;
                 if ((rem & WK_GUARD) != WK_GUARD) in_span = 0;
                 else break;  // list full
             }
             // ---------------- phase 2
             int32_t cnt = (int32_t)(ev_addr >> 10);
             if (finished && has_open) { cnt += 1; has_open = 0; }
+#ifndef NFA_WALK_NO_PHASE2
             marcher_run(s, col, cnt, ev_span, dt, limit, p, tid);
+#endif
             if (finished || (limit > 0 && s.n_samples >= limit)) break;
             // the open entry moves to slot 0
             ev_span = 0u;
-            ev_addr = 0u;
+            ev_addr = lane_off;
             if (has_open) *reinterpret_cast<float *>(col) = m_last;
         }
         if (a.terminate_planes) a.terminate_planes[tid] = s.t_last;
@@ -424,13 +549,24 @@ using namespace nfa;
 
 extern "C" {
 
-int64_t nfa_walk_bits_words(int32_t n_grids, const int32_t *res, int32_t *pad_out)
+int64_t nfa_walk_bits_words(int32_t n_grids, const int32_t *res)
 {
-    const int64_t cells = (int64_t)n_grids * res[0] * res[1] * res[2];
-    const int64_t stride = (int64_t)res[1] * res[2];
-    const int64_t pad = ((stride + 31) / 32) * 32 + 32;
-    if (pad_out) *pad_out = (int32_t)pad;
-    return pad / 32 + (cells + 31) / 32 + pad / 32 + 1;
+    const WalkLayout L = walk_layout(res);
+    return (((int64_t)n_grids << L.bits) + 31) / 32;
+}
+
+int nfa_pack_walk_bits(const uint8_t *binaries, int32_t n_grids, const int32_t *res, uint32_t *bits, nfa_stream_t stream)
+{
+    NFA_REQUIRE(binaries && res && bits && n_grids >= 1, "pack_walk_bits: bad arguments");
+    NFA_REQUIRE(res[0] > 0 && res[1] > 0 && res[2] > 0 && res[0] <= WK_MAX_RES && res[1] <= WK_MAX_RES && res[2] <= WK_MAX_RES,
+                "pack_walk_bits: 1..512 cells per axis");
+    const WalkLayout L = walk_layout(res);
+    NFA_REQUIRE(L.bits >= 5 && ((int64_t)n_grids << L.bits) < ((int64_t)1 << 31), "pack_walk_bits: grid too large");
+    const int64_t n_words = ((int64_t)n_grids << L.bits) >> 5;
+    hipLaunchKernelGGL(pack_walk_bits_kernel, dim3(grid_1d(n_words, 256)), dim3(256), 0, as_stream(stream), binaries, n_grids, res[0],
+                       res[1], res[2], L, bits);
+    NFA_CHECK_LAUNCH("pack_walk_bits");
+    return NFA_OK;
 }
 
 int nfa_traverse_runs(const nfa_traverse_args *pa, const uint32_t *bits, int32_t *run_cnts, uint64_t *runs, int32_t max_runs,
@@ -457,11 +593,8 @@ int nfa_traverse_runs(const nfa_traverse_args *pa, const uint32_t *bits, int32_t
     NFA_REQUIRE(!fused || a.n_grids == 1, "traverse_runs: in-kernel intersection supports one grid");
     WalkParams p;
     p.bits = bits;
-    int32_t pad = 0;
-    const int64_t words = nfa_walk_bits_words(a.n_grids, a.res, &pad);
-    NFA_REQUIRE(words < ((int64_t)1 << 26), "traverse_runs: grid too large");  // bit indices stay below 2^31
-    p.pad = pad;
-    p.cells_per_level = a.res[0] * a.res[1] * a.res[2];
+    p.lay = walk_layout(a.res);
+    NFA_REQUIRE(p.lay.bits >= 5 && ((int64_t)a.n_grids << p.lay.bits) < ((int64_t)1 << 31), "traverse_runs: grid too large");
     p.run_cnts = run_cnts;
     p.runs = reinterpret_cast<unsigned long long *>(runs);
     p.max_runs = max_runs;
@@ -472,7 +605,7 @@ int nfa_traverse_runs(const nfa_traverse_args *pa, const uint32_t *bits, int32_t
     // differs bit-wise simply do not use the table.
     if (near_hint == near_hint) approach_table_build(p.approach, near_hint, a.step_size);
     else p.approach.n = 0;
-    const size_t shmem = (size_t)WK_EV * 256 * 4;
+    const size_t shmem = 0;  // the lists are static LDS
     const unsigned grid = grid_1d(a.n_rays, 256, 1 << 20);
     if (fused) hipLaunchKernelGGL((walk_kernel<true>), dim3(grid), dim3(256), shmem, s, a, p);
     else       hipLaunchKernelGGL((walk_kernel<false>), dim3(grid), dim3(256), shmem, s, a, p);

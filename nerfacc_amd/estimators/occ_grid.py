@@ -106,7 +106,8 @@ class OccGridEstimator(AbstractEstimator):
 
     def _occs_mean(self) -> float:
         """``self.occs.mean().item()`` (ref :183) cached until ``occs`` changes."""
-        key = (self.occs.data_ptr(), self.occs._version)
+        # the tensor object itself is part of the key: a re-assigned buffer may reuse the address of the old one at version 0
+        key = (id(self.occs), self.occs.data_ptr(), self.occs._version)
         if self._occs_mean_cache is None or self._occs_mean_cache[0] != key:
             self._occs_mean_cache = (key, float(self.occs.mean().item()))
         return self._occs_mean_cache[1]
@@ -124,6 +125,14 @@ class OccGridEstimator(AbstractEstimator):
             use_bins = self._walk_stats.get("max_over_mean", 1.0) > 5.0 and rays_o.shape[0] >= 65536  # image order: 1.6-2.5, random rays: ~12
         return _traverse_samples(rays_o, rays_d, self.binaries, self.aabbs, near_planes, far_planes, render_step_size,
                                  cone_angle, near_hint=near_plane, bin_rays=bool(use_bins), stats_sink=self._walk_stats)
+
+    def _traversal_key(self, rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified, cone_angle):
+        """Identity of everything the geometric half of ``sampling`` reads: tensors by (address, shape, version counter)
+        -- rays rewritten in place after a prefetch (the usual double-buffer pattern) no longer match."""
+        def tid(t):
+            return None if t is None else (t.data_ptr(), tuple(t.shape), t._version)
+        return (tid(rays_o), tid(rays_d), tid(t_min), tid(t_max), float(near_plane), float(far_plane),
+                float(render_step_size), bool(stratified), float(cone_angle), tid(self.binaries))
 
     @torch.no_grad()
     def prefetch_traversal(
@@ -164,8 +173,7 @@ class OccGridEstimator(AbstractEstimator):
                                  cone_angle)
             event = torch.cuda.Event()
             event.record(side)
-        key = (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], float(near_plane), float(far_plane),
-               float(render_step_size), float(cone_angle), self.binaries.data_ptr(), self.binaries._version)
+        key = self._traversal_key(rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified, cone_angle)
         return TraversalHandle(out, event, key)
 
     @torch.no_grad()
@@ -194,10 +202,10 @@ class OccGridEstimator(AbstractEstimator):
         ``(N,)``; when given (and a threshold is active) invisible samples are dropped.
         """
         if traversal is not None:
-            key = (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], float(near_plane), float(far_plane),
-                   float(render_step_size), float(cone_angle), self.binaries.data_ptr(), self.binaries._version)
+            key = self._traversal_key(rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified, cone_angle)
             if traversal.key != key:
-                raise ValueError("nerfacc_amd: the prefetched traversal was made for other rays / planes / step / grid")
+                raise ValueError("nerfacc_amd: the prefetched traversal was made for other rays / planes / step / grid "
+                                 "(or the ray / plane tensors were modified in place since)")
             ray_indices, t_starts, t_ends, packed_info = traversal.consume(torch.cuda.current_stream(rays_o.device))
         else:
             ray_indices, t_starts, t_ends, packed_info = self._traverse(

@@ -285,17 +285,15 @@ WALK_MAX_RES = 512  # cells per axis the run-length walk's packed step counters 
 
 
 def _get_walk_bits(binaries: Tensor) -> Tensor:
-    """1-bit-per-cell copy of ``binaries`` for the run-length walk, with zero padding on both sides so that the bit of a
-    cell one step outside the grid can be loaded unconditionally (derived cache keyed on the tensor's version counter,
-    never serialised)."""
+    """1-bit-per-cell copy of ``binaries`` in the run-length walk's blocked cell order (derived cache keyed on the
+    tensor's version counter, never serialised)."""
     cached = getattr(binaries, "_nfa_walk_bits", None)
     if cached is not None and cached[0] == binaries._version:
         return cached[1]
     res = (C.c_int32 * 3)(*binaries.shape[1:])
-    pad = C.c_int32(0)
-    words = int(B.load().nfa_walk_bits_words(binaries.shape[0], res, C.byref(pad)))
-    bits = torch.zeros(words, dtype=torch.int32, device=binaries.device)
-    B.call("nfa_pack_bits", B.ptr(binaries), binaries.numel(), bits.data_ptr() + 4 * (pad.value // 32), B.stream())
+    words = int(B.load().nfa_walk_bits_words(binaries.shape[0], res))
+    bits = torch.empty(words, dtype=torch.int32, device=binaries.device)
+    B.call("nfa_pack_walk_bits", B.ptr(binaries), binaries.shape[0], res, B.ptr(bits), B.stream())
     try:
         binaries._nfa_walk_bits = (binaries._version, bits)
     except Exception:  # pragma: no cover

@@ -956,6 +956,20 @@ def test_prefetched_traversal_is_the_same_sampling(dev):
         est.sampling(ro, rd, traversal=h, **dict(kw, near_plane=0.2))
     with pytest.raises(AssertionError):
         got = est.sampling(ro, rd, traversal=h, **kw); est.sampling(ro, rd, traversal=h, **kw)
+    # the double-buffer pattern: rays rewritten IN PLACE after the prefetch must not be served the old traversal; nor may
+    # per-ray planes or the stratified flag differ between prefetch and sampling
+    h = est.prefetch_traversal(ro, rd, near_plane=0.1, render_step_size=0.004)
+    torch.cuda.synchronize()
+    ro.add_(0.01)
+    with pytest.raises(ValueError):
+        est.sampling(ro, rd, traversal=h, **kw)
+    h = est.prefetch_traversal(ro, rd, near_plane=0.1, render_step_size=0.004)
+    with pytest.raises(ValueError):
+        est.sampling(ro, rd, traversal=h, t_min=torch.full((ro.shape[0],), 0.3, device=dev), **kw)
+    h = est.prefetch_traversal(ro, rd, near_plane=0.1, render_step_size=0.004)
+    with pytest.raises(ValueError):
+        est.sampling(ro, rd, traversal=h, stratified=True, **kw)
+    ref = est.sampling(ro, rd, **kw)
     # with a cone angle (run records + recurrence expansion, overflow rays on a nested side stream)
     est.binaries = T(np.indices((64, 64, 64)).sum(0)[None] % 2 == 0, dev)       # checkerboard: rays with > 32 chains
     kwc = dict(kw, cone_angle=0.01)
