@@ -122,6 +122,7 @@ struct WalkParams {
 };
 
 enum { WK_EMPTY = 0, WK_OCC = 1, WK_SPAN = 2 };
+__device__ __forceinline__ bool is_span_entry(uint32_t ev_span, int32_t k) { return (ev_span >> k) & 1u; }
 
 // Marcher state of one ray (phase 2)
 struct Marcher {
@@ -156,7 +157,7 @@ __device__ __forceinline__ void marcher_refresh(Marcher &s, float dt)
             if (f != 0.5f) {                         // an exact tie depends on t's parity: general path
                 s.fq = (uint32_t)k + (f > 0.5f ? 1u : 0u);
                 s.fstep = ldexpf((float)s.fq, (int)e - 150);  // q ulps, exact
-                s.frcp = 1.0f / s.fstep;
+                s.frcp = NFA_RCP(s.fstep);   // for estimates only
             }
         }
     }
@@ -179,43 +180,87 @@ __device__ __forceinline__ void marcher_emit(Marcher &s, float t0, float inc, ui
     s.continuous = 1;
 }
 
-// One list entry in straight-line code: t_last stays inside its binade and the stable increment is known.
-// Returns false (nothing changed) when the general path has to do it.
-__device__ __forceinline__ bool marcher_fast(Marcher &s, float thr, int type, float half, int32_t limit, const WalkParams &p,
-                                             int64_t tid)
+// The approach table (march.h) staged in LDS: a per-lane index into a kernel argument would be a waterfall of scalar loads
+struct ApproachLds {
+    float T[APPROACH_MAX];
+    uint32_t q[APPROACH_MAX];
+};
+// approach_table_apply without the stepper: moves t to the furthest tabulated point of the common sequence near, near + dt, ...
+// that the serial loop passes on its way to thr
+__device__ __forceinline__ void marcher_approach(const WalkParams &p, const ApproachLds &tb, float &t, float half, float thr)
 {
-    if (s.at_near) return false;
-    const float t = s.t_last;
-    if (!(t + half < thr)) {  // the serial loop would not take a step
-        if (type == WK_EMPTY) s.continuous = 0;
-        return true;
+    const uint32_t n = p.approach.n, e_lo = p.approach.e_lo;
+    if (n == 0u || f32_bits(t) != p.approach.near_bits) return;
+    const float c = thr - half;
+    if (!(c > 0.0f)) return;
+    uint32_t ec = f32_bits(c) >> 23;
+    if (ec > e_lo + n - 1u) ec = e_lo + n - 1u;
+    for (int d = 0; d < 2; ++d) {
+        const uint32_t e = ec - (uint32_t)d;
+        if (e < e_lo || e > ec) return;
+        const uint32_t i = e - e_lo;
+        const float T = tb.T[i];
+        if (tb.q[i] != 0u && T > t && T + half < thr) { t = T; return; }
     }
-    const uint32_t bt = f32_bits(t);
-    if ((bt >> 23) != s.fe || s.fq == 0u) return false;
-    const uint32_t q = s.fq;
-    const float est = ((thr - half) - t) * s.frcp;        // steps until the condition fails: an estimate, probed below
-    if (!(est < 4194304.0f)) return false;
-    const uint32_t c = (uint32_t)fmaxf(est, 1.0f);
-    const uint32_t a = c - 1u;
-    const uint32_t room = (bt | 0x7FFFFFu) - bt;          // bit patterns left in the binade
-    // (a + 3) q <= room, exactly: products below 2^24 are exact in fp32, larger ones exceed room < 2^23 anyway
-    if (!((float)(a + 3u) * (float)q <= (float)room)) return false;
-    // cond(j) = fl(t_j + half) < thr is non-increasing in j; cond(0) holds
-    const uint32_t b0 = mad_u24(a, q, bt);
-    const bool f0 = bits_f32(b0) + half < thr;
-    const bool f1 = bits_f32(b0 + q) + half < thr;
-    const bool f2 = bits_f32(b0 + 2u * q) + half < thr;
-    const bool f3 = bits_f32(b0 + 3u * q) + half < thr;
-    if (!f0 || f3) return false;                          // the estimate was off by more than the window
-    uint32_t J = a + 1u + (f1 ? 1u : 0u) + (f2 ? 1u : 0u);  // cond(J - 1) true, cond(J) false
-    if (type == WK_OCC) {
-        if (limit > 0) J = min(J, (uint32_t)(limit - s.n_samples));
-        marcher_emit(s, t, s.fstep, J, p, tid);
-    } else if (type == WK_EMPTY) {
-        s.continuous = 0;
+}
+
+// The marcher's way across the end of a binade, for a lane the lock-step loop could not serve: the first march of the
+// ray (the way from the near plane is tabulated), a stale stable increment, a march that reaches the end of the binade.
+// Straight-line code; afterwards the lock-step loop looks at the same list entry again (an entry is "march until the
+// threshold", so progress never has to be remembered).  Returns 2: progress was made (call again if the loop declines the
+// entry again), 1: nothing to do here (if the loop declines again, the general path is next), 0: march.h's general stepper
+// has to do the entry.
+__device__ __forceinline__ int marcher_cross(Marcher &s, float thr, int type, float dt, float half, int32_t limit, const WalkParams &p,
+                                             const ApproachLds &tb, int64_t tid)
+{
+    int progress = 0;
+    if (s.at_near) {
+        s.at_near = 0;
+        progress = 1;
+        if (type != WK_OCC) marcher_approach(p, tb, s.t_last, half, thr);
     }
-    s.t_last = bits_f32(bt + J * q);
-    return true;
+#pragma unroll 1
+    for (int round = 0; round < 4; ++round) {   // (a march across several binades: rays that start near t = 0)
+        const uint32_t fe_before = s.fe;
+        marcher_refresh(s, dt);
+        if (s.fe != fe_before) progress = 1;
+        if (s.fq == 0u) return 0;
+        const float t = s.t_last;
+        if (!(t + half < thr)) break;
+        const uint32_t bt = f32_bits(t), q = s.fq;
+        const uint32_t room = (bt | 0x7FFFFFu) - bt;          // bit patterns left in the binade
+        uint32_t budget = 0xFFFFFFFFu;
+        if (type == WK_OCC && limit > 0) {
+            if (s.n_samples >= limit) break;
+            budget = (uint32_t)(limit - s.n_samples);
+        }
+        if (q <= room) {
+            // all the steps that stay inside the binade, if the condition holds for every one of them
+            uint32_t n_b = (uint32_t)((float)room * NFA_RCP((float)q));   // floor(room / q): estimate (both < 2^23), then corrected
+            if (n_b * q > room) n_b--;
+            if (n_b * q > room) n_b--;
+            if ((n_b + 1u) * q <= room) n_b++;
+            if ((n_b + 1u) * q <= room) n_b++;
+            if (n_b == 0u || n_b * q > room || (n_b + 1u) * q <= room) return 0;
+            if (!(bits_f32(bt + (n_b - 1u) * q) + half < thr)) break;      // it stops inside this binade: the lock-step loop's case
+            n_b = min(n_b, budget);
+            if (type == WK_OCC) marcher_emit(s, t, s.fstep, n_b, p, tid);
+            s.t_last = bits_f32(bt + n_b * q);
+            progress = 1;
+            if (n_b == budget) break;
+            budget -= n_b;
+        }
+        // the step across the end of the binade: its increment is its own
+        const float t1 = s.t_last;
+        if (!(t1 + half < thr)) break;
+        const float tn = t1 + dt;
+        if (tn == t1 || (f32_bits(tn) >> 23) == (f32_bits(t1) >> 23)) return 0;
+        if (type == WK_OCC) marcher_emit(s, t1, tn - t1, 1u, p, tid);
+        s.t_last = tn;
+        progress = 1;
+    }
+    marcher_refresh(s, dt);
+    return progress ? 2 : 1;
 }
 
 // The same entry through march.h's stepper: binade boundaries, exact ties, the way from the near plane (tabulated),
@@ -226,10 +271,6 @@ __device__ __forceinline__ void marcher_general(Marcher &s, float thr, int type,
     Stepper stp;
     stepper_init(stp);
     const bool emit = type == WK_OCC;
-    if (s.at_near) {
-        s.at_near = 0;
-        if (!emit) approach_table_apply(p.approach, stp, s.t_last, half, thr);
-    }
     for (;;) {
         if (!(s.t_last + half < thr)) break;
         uint32_t budget = 0xFFFFFFFFu;
@@ -253,35 +294,82 @@ __device__ __forceinline__ void marcher_general(Marcher &s, float thr, int type,
 
 // Phase 2: the closed entries [0, cnt) of this lane's list.  ev_span bit k: slots k, k + 1 hold (this_tmin, this_tmax) of a
 // span start; bit 16 + k: kind of the first cell entry of that span (slot k + 2).
+//
+// The lock-step loop serves every entry whose march stays inside the binade of t_last: the steps until the condition
+// t + dt/2 < thr fails are estimated in fp32 and the estimate is PROBED on the actual floats (four consecutive step
+// counts; the condition is monotone), so the result is the serial loop's.  One code path for the three kinds of entries,
+// flags as integers, the only branches are the run-record store and the loop itself.  A lane that cannot be served
+// (binade end, first march, no stable increment) stops consuming entries; when no lane can go on, those lanes cross
+// together (marcher_cross, or march.h's general stepper) and the loop resumes.
 __device__ __forceinline__ void marcher_run(Marcher &s, const char *col /* LDS column of this lane */, int32_t cnt, uint32_t ev_span,
-                                            float dt, int32_t limit, const WalkParams &p, int64_t tid)
+                                            float dt, int32_t limit, const WalkParams &p, const ApproachLds &tb, int64_t tid)
 {
     const float half = dt * 0.5f;
     int32_t k = 0;
+    int32_t tried = 0;   // marcher_cross has been run for entry k and the loop declined it again: the general path is next
     for (;;) {
-        bool slow = false;
+        int32_t blocked = 0;
         float thr = 0.f;
-        int type = 0, adv = 1, next_ptype = 0;
-        while (k < cnt) {
+        int32_t type = 0, adv = 1, next_ptype = 0;
+        while (k < cnt && !blocked) {
             if (limit > 0 && s.n_samples >= limit) { k = cnt; break; }  // grid.cu:184: nothing moves once the limit is hit
             const float v0 = *reinterpret_cast<const float *>(col + (k << 10));
-            if ((ev_span >> k) & 1u) {
-                s.span_tmax = *reinterpret_cast<const float *>(col + ((k + 1) << 10));
-                thr = v0; type = WK_SPAN; adv = 2;
-                next_ptype = (int)((ev_span >> (16 + k)) & 1u);
-            } else {
-                thr = vmin_f32(v0, s.span_tmax);
-                type = s.ptype; adv = 1;
-                next_ptype = s.ptype ^ 1;
-            }
-            if (type == WK_SPAN && s.continuous) { k += adv; s.ptype = next_ptype; continue; }  // grid.cu:153: `if (!continuous)`
-            if (!marcher_fast(s, thr, type, half, limit, p, tid)) { slow = true; break; }
-            k += adv; s.ptype = next_ptype;
+            const float v1 = *reinterpret_cast<const float *>(col + ((k + 1) << 10));   // (slot k + 1 <= WK_EV exists)
+            const int32_t is_span = (int32_t)((ev_span >> k) & 1u);
+            const float tmax_k = is_span ? v1 : s.span_tmax;
+            thr = is_span ? v0 : vmin_f32(v0, tmax_k);
+            type = is_span ? WK_SPAN : s.ptype;
+            adv = 1 + is_span;
+            next_ptype = is_span ? (int32_t)((ev_span >> (16 + k)) & 1u) : (s.ptype ^ 1);
+            const int32_t skip = (type == WK_SPAN) & s.continuous;           // grid.cu:153: `if (!continuous)`
+            const float t = s.t_last;
+            const int32_t stepping = (int32_t)(t + half < thr) & (skip ^ 1);   // the serial loop would take a step
+            // steps until the condition fails: estimate, window of four probes
+            const uint32_t bt = f32_bits(t), q = s.fq;
+            const float est = ((thr - half) - t) * s.frcp;
+            const uint32_t c = (uint32_t)fminf(fmaxf(est, 1.0f), 4194304.0f);  // (NaN -> 1)
+            const uint32_t a = c - 1u;
+            const uint32_t room = (bt | 0x7FFFFFu) - bt;                      // bit patterns left in the binade
+            // (a + 3) q <= room, exactly: products below 2^24 are exact in fp32, larger ones exceed room < 2^23 anyway
+            const int32_t fits = (int32_t)((float)(a + 3u) * (float)q <= (float)room) & (int32_t)((bt >> 23) == s.fe) &
+                                 (int32_t)(q != 0u) & (s.at_near ^ 1);
+            const uint32_t b0 = mad_u24(a, q, bt);                            // (garbage when !fits: unused)
+            const int32_t f0 = bits_f32(b0) + half < thr, f1 = bits_f32(b0 + q) + half < thr;
+            const int32_t f2 = bits_f32(b0 + 2u * q) + half < thr, f3 = bits_f32(b0 + 3u * q) + half < thr;
+            const int32_t ok = fits & f0 & (f3 ^ 1);                          // cond(a) true, cond(a + 3) false: the window holds the answer
+            blocked = stepping & (ok ^ 1);
+            const int32_t go = stepping & ok;                                 // this lane marches J steps now
+            uint32_t J = a + 1u + (uint32_t)f1 + (uint32_t)f2;                // cond(J - 1) true, cond(J) false
+            const int32_t emit = go & (int32_t)(type == WK_OCC);
+            if (limit > 0 && emit) J = min(J, (uint32_t)(limit - s.n_samples));
+            // run records: a new one unless the samples continue the open run (same increment, no gap)
+            const int32_t new_run = emit & ((s.continuous & (int32_t)(s.fstep == s.run_inc)) ^ 1);
+            if (new_run && s.n_runs < p.max_runs)
+                p.runs[(int64_t)s.n_runs * p.n_rays + tid] =
+                    (unsigned long long)bt | ((unsigned long long)((uint32_t)s.n_samples | ((uint32_t)s.continuous << 31)) << 32);
+            s.n_runs += new_run;
+            s.n_chains += new_run & (s.continuous ^ 1);
+            s.run_inc = new_run ? s.fstep : s.run_inc;
+            s.n_samples += emit ? (int32_t)J : 0;
+            s.t_last = go ? bits_f32(bt + J * q) : t;
+            const int32_t commit = blocked ^ 1;
+            // continuous: set by emitted samples, cleared by an EMPTY entry (whether or not it marched)
+            s.continuous = emit ? 1 : ((commit & (int32_t)(type == WK_EMPTY) & (skip ^ 1)) ? 0 : s.continuous);
+            k += commit ? adv : 0;
+            s.ptype = commit ? next_ptype : s.ptype;
+            s.span_tmax = commit ? tmax_k : s.span_tmax;
+            tried = commit ? 0 : tried;
         }
-        if (!__any(slow)) break;
-        if (slow) {
-            marcher_general(s, thr, type, dt, half, limit, p, tid);
-            k += adv; s.ptype = next_ptype;
+        if (!__any(blocked)) break;
+        if (blocked) {
+            int r = 0;
+            if (!tried) r = marcher_cross(s, thr, type, dt, half, limit, p, tb, tid);
+            tried = r == 1;
+            if (r == 0) {
+                marcher_general(s, thr, type, dt, half, limit, p, tid);
+                if (is_span_entry(ev_span, k)) s.span_tmax = *reinterpret_cast<const float *>(col + ((k + 1) << 10));
+                k += adv; s.ptype = next_ptype;
+            }
         }
     }
 }
@@ -401,6 +489,15 @@ template <bool FUSED>
 NFA_WALK_OCC __global__ __launch_bounds__(256) void walk_kernel(const nfa_traverse_args a, const WalkParams p)
 {
     __shared__ __attribute__((aligned(16))) char ev_lds[(WK_EV + 1) * 1024];   // [WK_EV + 1][256] floats
+    __shared__ ApproachLds tb;
+    {   // read the table from the kernel-argument segment as memory (indexed by thread: as an argument in registers it would
+        // occupy 80 scalar registers and be selected entry by entry)
+        const char *ka = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
+        constexpr size_t p_off = (sizeof(nfa_traverse_args) + alignof(WalkParams) - 1) / alignof(WalkParams) * alignof(WalkParams);
+        const WalkParams *pk = reinterpret_cast<const WalkParams *>(ka + p_off);
+        if (threadIdx.x < APPROACH_MAX) { tb.T[threadIdx.x] = pk->approach.T[threadIdx.x]; tb.q[threadIdx.x] = pk->approach.q[threadIdx.x]; }
+        __syncthreads();
+    }
     const uint32_t lane_off = 4u * threadIdx.x;
     char *const col = ev_lds + lane_off;
     const float dt = a.step_size;
@@ -524,7 +621,7 @@ NFA_WALK_OCC __global__ __launch_bounds__(256) void walk_kernel(const nfa_traver
             int32_t cnt = (int32_t)(ev_addr >> 10);
             if (finished && has_open) { cnt += 1; has_open = 0; }
 #ifndef NFA_WALK_NO_PHASE2
-            marcher_run(s, col, cnt, ev_span, dt, limit, p, tid);
+            marcher_run(s, col, cnt, ev_span, dt, limit, p, tb, tid);
 #endif
             if (finished || (limit > 0 && s.n_samples >= limit)) break;
             // the open entry moves to slot 0
