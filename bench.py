@@ -66,12 +66,13 @@ class NativeField:
     Same function as `torch_field`, evaluated by bench_csrc/field.hip: one kernel per callback and one
     for the backward to the two parameters, so the step is dominated by the hot path it measures."""
 
-    def __init__(self, params: torch.Tensor):
+    def __init__(self, params: torch.Tensor, sigma_scale: float = 1.0):
         import ctypes
         self.params = params
+        self.sigma_scale = float(sigma_scale)   # density scale of the sampler's no-grad callback (= the initial p0)
         self.lib = ctypes.CDLL(build_field())
         vp, i64 = ctypes.c_void_p, ctypes.c_int64
-        self.lib.bf_field_sigma.argtypes = [vp, vp, i64, vp, vp]
+        self.lib.bf_field_sigma.argtypes = [vp, vp, i64, ctypes.c_float, vp, vp]
         self.lib.bf_field_fwd.argtypes = [vp, vp, i64, vp, vp, vp, vp]
         self.lib.bf_field_bwd.argtypes = [vp, vp, vp, vp, i64, vp, vp]
         self.blocks = int(self.lib.bf_grid_blocks())
@@ -103,7 +104,7 @@ class NativeField:
     def sigma_fn(self, ts, te, ri):                          # used inside sampling (no grad)
         ts, te = ts.contiguous(), te.contiguous()
         out = torch.empty_like(ts)
-        assert self.lib.bf_field_sigma(ts.data_ptr(), te.data_ptr(), ts.numel(), out.data_ptr(),
+        assert self.lib.bf_field_sigma(ts.data_ptr(), te.data_ptr(), ts.numel(), self.sigma_scale, out.data_ptr(),
                                        torch.cuda.current_stream().cuda_stream) == 0
         return out
 
@@ -114,15 +115,16 @@ class NativeField:
 class TorchField:
     """The same field with torch elementwise ops (~25 launches, 1.3 ms per step on 32 M samples)."""
 
-    def __init__(self, params: torch.Tensor):
+    def __init__(self, params: torch.Tensor, sigma_scale: float = 1.0):
         self.params = params
+        self.sigma_scale = float(sigma_scale)
 
     @staticmethod
     def base_sigma(ts, te):
         return 4.0 * (0.5 + 0.5 * torch.sin(20.0 * (ts + te)))
 
     def sigma_fn(self, ts, te, ri):
-        return self.base_sigma(ts, te)
+        return self.base_sigma(ts, te) * self.sigma_scale
 
     def rgb_sigma_fn(self, ts, te, ri):
         rgbs = (ts * self.params[1])[:, None].expand(-1, 3)  # grey ramp; made contiguous by rendering()
@@ -166,22 +168,42 @@ def make_rays(n_rays: int, variant: str, rank: int = 0, seed: int = 42):
 
 
 def make_workload(dev, n_rays: int = 1024 * 1024, res: int = 128, grid: str = "shell10", rays: str = "image",
-                  rank: int = 0, field: str = "native"):
+                  rank: int = 0, field: str = "native", sigma_scale: float = 1.0, binaries: torch.Tensor = None):
+    """``binaries``: a (1, res, res, res) bool tensor already on the device (the shared grid of a multi-GPU run, broadcast
+    from rank 0); otherwise the grid is built here from ``grid`` / seed 42."""
     import nerfacc_amd as na
-    b = make_grid(res, grid)
     o, d = make_rays(n_rays, rays, rank)
     est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=res, levels=1).to(dev)
-    est.binaries = torch.from_numpy(b).to(dev)
-    est.occs = torch.from_numpy(b.reshape(-1).astype(np.float32)).to(dev)
+    if binaries is None:
+        b = make_grid(res, grid)
+        binaries = torch.from_numpy(b).to(dev)
+    else:
+        b = None
+    est.binaries = binaries
+    est.occs = binaries.reshape(-1).float()
     step = 2 * math.sqrt(3) / 1024                          # <= 1024 samples per ray
     # two scalar parameters (density scale, colour scale): the "network" of this synthetic step
-    params = torch.nn.Parameter(torch.tensor([1.0, 1.0], device=dev))
-    fld = NativeField(params) if field == "native" else TorchField(params)
+    params = torch.nn.Parameter(torch.tensor([float(sigma_scale), 1.0], device=dev))
+    fld = NativeField(params, sigma_scale) if field == "native" else TorchField(params, sigma_scale)
     sigma_fn, rgb_sigma_fn = fld.sigma_fn, fld.rgb_sigma_fn
 
     return dict(estimator=est, rays_o=torch.from_numpy(o).to(dev), rays_d=torch.from_numpy(d).to(dev),
                 binaries_np=b, rays_np=(o, d), step=step, params=params, sigma_fn=sigma_fn, rgb_sigma_fn=rgb_sigma_fn,
-                n_rays=n_rays, res=res)
+                n_rays=n_rays, res=res, sigma_scale=float(sigma_scale))
+
+
+def shared_grid(dev, res: int, grid: str, rank: int, world: int) -> torch.Tensor:
+    """BASELINE cfg 4: ONE occupancy grid for all ranks.  Rank 0 builds it and broadcasts it once, bit-packed (res^3 / 8
+    bytes over RCCL), every rank unpacks it into the torch.bool layout the estimator keeps."""
+    n = res ** 3
+    packed = torch.empty((n + 7) // 8, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        packed.copy_(torch.from_numpy(np.packbits(make_grid(res, grid).reshape(-1))).to(dev))
+    if world > 1 or _group_live():
+        torch.distributed.broadcast(packed, src=0)
+    shifts = torch.arange(7, -1, -1, device=dev, dtype=torch.uint8)
+    bits = ((packed[:, None] >> shifts) & 1).reshape(-1)[:n]
+    return bits.bool().reshape(1, res, res, res)
 
 
 def run_step(w, world_size: int = 1, handle=None, prefetch: bool = False):
@@ -199,6 +221,7 @@ def run_step(w, world_size: int = 1, handle=None, prefetch: bool = False):
     nxt = None
     if prefetch:
         nxt = est.prefetch_traversal(w["rays_o"], w["rays_d"], render_step_size=w["step"], wait_for_inputs=False)
+    w["last"] = (ri, ts, te, colors)                        # kept for the parity check that follows the timed loops
     return ri.numel(), loss, nxt
 
 
@@ -301,7 +324,9 @@ def algorithmic_bytes(R, M, Mv, res, G=1):
         "nfa_traverse_grids[mode=0]": R * (24 + 8) + grid + R * 8,                 # rays + planes, grid, counts
         "nfa_traverse_grids[mode=1]": R * (24 + 8) + grid + M * (4 + 4 + 8) + R * 16,  # + samples, packed_info
         "nfa_traverse_runs": R * (24 + 8) + grid + R * 8,                            # one DDA walk: rays, grid, counts
+        "nfa_traverse_cone_runs": R * (24 + 8) + grid + R * 8,
         "nfa_expand_runs": M * (4 + 4 + 8) + R * 16,                                 # the sampler's output, once
+        "nfa_expand_cone_runs": M * (4 + 4 + 8) + R * 16,
         "nfa_render_visibility": M * (4 + 4 + 4) + R * 16 + M * 1 + R * 8,
         "nfa_compact_samples": M * (1 + 4 + 4) + R * 24 + Mv * 16,
         "nfa_render_from_density_fwd": Mv * (12 + 12) + R * 16,
@@ -315,42 +340,246 @@ def algorithmic_bytes(R, M, Mv, res, G=1):
     }
 
 
-# ----------------------------------------------------------------------------- CPU baseline (oracle, bounded sample)
-def cpu_baseline(w, min_seconds: float = 12.0, max_reps: int = 40):
-    """The CPU restatement (oracle/) on the SAME batch: sampling + rendering forward + analytic
-    backward of the step, repeated until about `min_seconds` of CPU work have been timed, on all host
-    cores (C/OpenMP traversal and scans, numpy elementwise)."""
+#: what bounds each native call: the walk is bound by instruction issue, everything else streams
+KERNEL_BOUND = {"nfa_traverse_runs": "issue", "nfa_traverse_cone_runs": "issue", "nfa_traverse_grids[mode=0]": "issue",
+                "nfa_traverse_grids[mode=1]": "issue"}
+
+
+def kernel_table(ksum, ab):
+    kernels = {}
+    for k, v in ksum.items():
+        entry = dict(v)
+        if k in ab:
+            per_launch = ab[k] / max(v["launches_per_step"], 1e-9)
+            entry["algorithmic_bytes_per_launch"] = per_launch
+            entry["achieved_GBps"] = per_launch / (v["ms_per_launch"] * 1e-3) / 1e9
+            entry["frac_of_hbm_peak"] = entry["achieved_GBps"] / HBM_PEAK_GBPS
+            entry["bound"] = KERNEL_BOUND.get(k, "hbm")
+        kernels[k] = entry
+    return kernels
+
+
+def timed_steps(fn, steps, warmup, with_kernels=True):
+    """(seconds per step, per-native-call HIP-event table) of `fn` -- used for the secondary configurations; the headline
+    loop in main() is timed without the per-call events."""
+    for _ in range(warmup):
+        out = fn()
+    gc.collect(); gc.disable()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    gc.enable()
+    ks = {}
+    if with_kernels:
+        timer = KernelTimer(); timer.install()
+        try:
+            for _ in range(steps):
+                out = fn()
+            ks = timer.summary(steps)
+        finally:
+            timer.uninstall()
+    return dt, ks, out
+
+
+# ----------------------------------------------------------------------------- secondary configurations (extra keys)
+def extra_cfg2_variant(dev, args, **kw):
+    """cfg 2 with one thing changed: `sigma_scale=16` makes early termination bite (T < 1e-4 inside the shell), so the
+    visibility mask drops samples and nfa_compact_samples runs in the step; `rays="random"` is a training-style batch of
+    unrelated rays."""
+    w = make_workload(dev, args.rays, args.res, args.grid, kw.get("rays", args.ray_variant), 0, args.field,
+                      sigma_scale=kw.get("sigma_scale", 1.0))
+    est = w["estimator"]
+    ri, ts, te, pi = __import__("nerfacc_amd").grid._traverse_samples(
+        w["rays_o"], w["rays_d"], est.binaries, est.aabbs, torch.zeros(args.rays, device=dev),
+        torch.full((args.rays,), 1e10, device=dev), w["step"], 0.0)
+    M = int(ri.numel())
+    del ri, ts, te, pi
+    dt, ks, _ = timed_steps(lambda: run_step(w, 1)[0], max(3, args.steps // 2), 3)
+    Mv = int(w["last"][0].numel())
+    kernels = kernel_table(ks, algorithmic_bytes(args.rays, M, Mv, args.res))
+    out = {"ms_per_step": dt * 1e3, "rays_per_s": args.rays / dt, "samples_before_compaction": M,
+           "samples_after_compaction": Mv, "kernels": {k: {kk: vv for kk, vv in v.items() if kk != "launches_per_step"}
+                                                       for k, v in kernels.items()}}
+    if "nfa_compact_samples" in kernels:
+        c = kernels["nfa_compact_samples"]
+        out["compaction"] = {"us_per_launch": c["ms_per_launch"] * 1e3, "achieved_GBps": c.get("achieved_GBps"),
+                             "kept_fraction": Mv / max(M, 1)}
+    return out
+
+
+def extra_cfg3(dev, R, steps):
+    """BASELINE cfg 3: PropNetEstimator, 2 proposal levels 64 -> 64 -> 16, uniform, fwd + proposal-loss backward."""
+    import nerfacc_amd as na
+    p = torch.nn.Parameter(torch.tensor([3.0, 4.0], device=dev))
+    est = na.PropNetEstimator(optimizer=torch.optim.SGD([p], lr=1e-3)).to(dev)
+    prop = lambda ts, te: torch.exp(-((ts + te) * 0.5 - p[1]) ** 2) * p[0]          # proposal density, 2 parameters
+    fine = lambda ts, te: torch.exp(-((ts + te) * 0.5 - 4.0) ** 2 * 2.0) * 5.0
+
+    def step():
+        ts, te = est.sampling([prop, prop], [64, 64], 16, R, 2.0, 6.0, sampling_type="uniform", stratified=False,
+                              requires_grad=True)
+        trans, _ = na.render_transmittance_from_density(ts, te, fine(ts, te))
+        return est.update_every_n_steps(trans, requires_grad=True)
+
+    dt, ks, loss = timed_steps(step, steps, 2)
+    # algorithmic bytes (SURVEY 8d): importance_sampling R (8 E_in + 4 (S + 1)); the fused s -> t variant also writes 2 S floats
+    ab = {"nfa_importance_sampling_t": R * ((8 * 2 + 4 * 65 + 8 * 64) + (8 * 65 + 4 * 65 + 8 * 64) + (8 * 65 + 4 * 17 + 8 * 16)),
+          "nfa_pdf_loss_fwd": R * (4 * (17 + 17 + 65 + 65) + 4 * 16 + 4 * 16) * 2,
+          "nfa_pdf_loss_bwd": R * (4 * (17 + 65) + 4 * 16 + 4 * 16 + 4 * 65) * 2}
+    kernels = {}
+    for k, v in ks.items():
+        e = {"ms_per_step": v["ms_per_step"], "ms_per_launch": v["ms_per_launch"], "launches_per_step": v["launches_per_step"]}
+        if k in ab:
+            e["algorithmic_bytes_per_step"] = ab[k]
+            e["achieved_GBps"] = ab[k] / (v["ms_per_step"] * 1e-3) / 1e9
+            e["frac_of_hbm_peak"] = e["achieved_GBps"] / HBM_PEAK_GBPS
+        kernels[k] = e
+    return {"workload": f"cfg3: PropNetEstimator 2 -> 64 -> 64 -> 16, R={R}, uniform, fwd + proposal-loss bwd",
+            "ms_per_step": dt * 1e3, "rays_per_s": R / dt, "loss": float(loss),
+            "native_ms_per_step": sum(v["ms_per_step"] for v in ks.values()), "kernels": kernels}
+
+
+def extra_cfg5(dev, R, steps, res=512, G=4):
+    """BASELINE cfg 5: G nested res^3 levels, R rays from inside the level-0 box, step 1e-3, cone 0.004, near 0.2,
+    alpha_thre 1e-2, early_stop_eps 1e-4: train-mode sampling + rendering fwd + bwd."""
+    import nerfacc_amd as na
+    rng = np.random.default_rng(5)
+    est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=res, levels=G).to(dev)
+    ax = (torch.arange(res, device=dev, dtype=torch.float32) + 0.5) / res * 2 - 1
+    r = torch.sqrt(ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :] ** 2)
+    shell = (r > 0.5) & (r < 0.66)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    b = torch.stack([shell | (torch.rand((res, res, res), device=dev, generator=g) < 0.02) for _ in range(G)])
+    est.binaries = b
+    est.occs = b.reshape(-1).float()
+    del r, shell
+    o = (rng.random((R, 3)).astype(np.float32) - 0.5)                               # inside the level-0 box
+    d = rng.standard_normal((R, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    rays_o, rays_d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    params = torch.nn.Parameter(torch.tensor([1.0, 1.0], device=dev))
+    fld = NativeField(params)
+    last = {}
+
+    def step():
+        ri, ts, te = est.sampling(rays_o, rays_d, sigma_fn=fld.sigma_fn, near_plane=0.2, render_step_size=1e-3,
+                                  cone_angle=0.004, alpha_thre=1e-2, early_stop_eps=1e-4)
+        colors, opac, depth, _ = na.rendering(ts, te, ri, n_rays=R, rgb_sigma_fn=fld.rgb_sigma_fn)
+        params.grad = None
+        colors.sum().backward()
+        last["m"] = ri.numel()
+        return ri.numel()
+
+    dt, ks, m = timed_steps(step, steps, 2)
+    ri, ts, te, pi = na.grid._traverse_samples(rays_o, rays_d, est.binaries, est.aabbs, torch.full((R,), 0.2, device=dev),
+                                               torch.full((R,), 1e10, device=dev), 1e-3, 0.004)
+    M = int(ri.numel())
+    del ri, ts, te, pi
+    kernels = kernel_table(ks, algorithmic_bytes(R, M, int(m), res, G))
+    return {"workload": f"cfg5: {G} nested {res}^3 levels, R={R} rays from inside, step 1e-3, cone 0.004, near 0.2, "
+                        f"alpha_thre 1e-2, sampling + rendering fwd + bwd",
+            "ms_per_step": dt * 1e3, "rays_per_s": R / dt, "samples_before_compaction": M, "samples_after_compaction": int(m),
+            "native_ms_per_step": sum(v["ms_per_step"] for v in ks.values()),
+            "kernels": {k: {kk: vv for kk, vv in v.items() if kk != "launches_per_step"} for k, v in kernels.items()}}
+
+
+# ----------------------------------------------------------------------------- CPU baseline (oracle, bounded sample) + parity
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _oracle_step(O, o, d, b, aabb, step, sigma_scale):
+    """The oracle's restatement of one step on a batch: sampling + rendering forward + analytic backward."""
+    def sig(ts, te, ri):
+        return (np.float32(sigma_scale) * (4.0 * (0.5 + 0.5 * np.sin(20.0 * (ts + te))))).astype(np.float32)
+
+    n = o.shape[0]
+    (ri, ts, te), full = O.occgrid_sampling(o, d, b, aabb, sigma_fn=sig, render_step_size=step, early_stop_eps=1e-4,
+                                            alpha_thre=0.0, occs_mean=float(b.mean()), return_all=True)
+    pi = O.pack_info(ri, n)
+    s = sig(ts, te, ri)
+    wts, tr, al = O.render_weight_from_density(ts, te, s, pi)
+    rgb = np.repeat(ts[:, None], 3, 1)
+    colors = O.accumulate_along_rays(wts, rgb, ri, n)
+    # backward of colors.sum(): g_w = sum_c rgb, then the reverse scan (vectorised restatement)
+    gw = rgb.sum(-1)
+    suffix = O.packed_scan("exclusive_sum", gw * wts, pi, backward=True)
+    gsig = (te - ts) * (gw * tr * (1 - al) - suffix)
+    return (ri, ts, te), full, colors, gsig, sig
+
+
+def cpu_baseline(w, min_seconds: float = 10.0, max_reps: int = 40):
+    """The CPU restatement (oracle/) on the SAME batch: sampling + rendering forward + analytic backward of the step,
+    repeated until about `min_seconds` of CPU work have been timed, on all host cores (C/OpenMP traversal and scans,
+    numpy elementwise); then a 1-thread figure on a 1/4 sample of the rays.  The last pass's outputs are the reference
+    the GPU results of the very same batch are checked against (parity_check)."""
     from oracle import oracle as O
     O.build()
     o, d = w["rays_np"]
-    b = w["binaries_np"]
+    b = w["estimator"].binaries.cpu().numpy()
     aabb = np.array([[-1, -1, -1, 1, 1, 1]], np.float32)
-
-    def sig(ts, te, ri):
-        return (4.0 * (0.5 + 0.5 * np.sin(20.0 * (ts + te)))).astype(np.float32)
-
     n = o.shape[0]
-    total, reps, samples = 0.0, 0, 0
+    total, reps = 0.0, 0
     while total < min_seconds and reps < max_reps:
         t0 = time.perf_counter()
-        ri, ts, te = O.occgrid_sampling(o, d, b, aabb, sigma_fn=sig, render_step_size=w["step"], early_stop_eps=1e-4,
-                                        alpha_thre=0.0, occs_mean=float(b.mean()))
-        pi = O.pack_info(ri, n)
-        s = sig(ts, te, ri)
-        wts, tr, al = O.render_weight_from_density(ts, te, s, pi)
-        rgb = np.repeat(ts[:, None], 3, 1)
-        colors = O.accumulate_along_rays(wts, rgb, ri, n)
-        # backward of colors.sum(): g_w = sum_c rgb, then the reverse scan (vectorised restatement)
-        gw = rgb.sum(-1)
-        suffix = O.packed_scan("exclusive_sum", gw * wts, pi, backward=True)
-        gsig = (te - ts) * (gw * tr * (1 - al) - suffix)
+        kept, full, colors, gsig, sig = _oracle_step(O, o, d, b, aabb, w["step"], w["sigma_scale"])
         total += time.perf_counter() - t0
         reps += 1
-        samples = int(ri.size)
-        del colors, gsig
-    return dict(value=n * reps / total, unit="rays/s", cores=O.max_threads(), kind="port",
-                sample=f"{reps} passes over the full {n}-ray batch ({samples} samples each), {total:.1f} s of CPU work, "
-                       f"C/OpenMP traversal + scans, numpy elementwise")
+    samples = int(kept[0].size)
+    out = dict(value=n * reps / total, unit="rays/s", cores=O.max_threads(), kind="port", cpu_model=cpu_model(),
+               sample=f"{reps} passes over the full {n}-ray batch ({samples} samples each), {total:.1f} s of CPU work, "
+                      f"C/OpenMP traversal + scans, numpy elementwise")
+    # 1 thread, every 4th ray (BASELINE.md 3: a 1-thread figure alongside)
+    try:
+        import ctypes
+        omp = ctypes.CDLL("libgomp.so.1")
+        n_thr = O.max_threads()
+        omp.omp_set_num_threads(1)
+        torch_thr = torch.get_num_threads()
+        torch.set_num_threads(1)
+        o1, d1 = np.ascontiguousarray(o[::4]), np.ascontiguousarray(d[::4])
+        t0 = time.perf_counter()
+        _oracle_step(O, o1, d1, b, aabb, w["step"], w["sigma_scale"])
+        t1 = time.perf_counter() - t0
+        omp.omp_set_num_threads(n_thr)
+        torch.set_num_threads(torch_thr)
+        out["single_thread"] = dict(value=o1.shape[0] / t1, unit="rays/s", cores=1,
+                                    sample=f"1 pass over every 4th ray ({o1.shape[0]} rays), {t1:.1f} s")
+    except Exception as e:  # pragma: no cover
+        out["single_thread"] = dict(error=repr(e))
+    return out, (kept, full, colors, sig)
+
+
+def parity_check(w, oracle_out):
+    """The product's results on the full batch of the timed loops against the oracle's: (ray_indices, t_starts, t_ends)
+    bit for bit (samples on the visibility threshold's guard band excepted, oracle/check.py), colours within 1e-5."""
+    from oracle import check as OC
+    from oracle import oracle as O
+    kept, full, colors, sig = oracle_out
+    ri, ts, te, col = w["last"]
+    got = (ri.cpu().numpy(), ts.cpu().numpy(), te.cpu().numpy())
+    fri, fts, fte, fpi = full
+    tr = al = None
+    if not (got[0].shape == kept[0].shape):
+        tr, al = O.render_transmittance_from_density(fts, fte, sig(fts, fte, fri), fpi)
+    ok, info = OC.compare_sampling(got, kept, (fri, fts, fte), tr, al, early_stop_eps=1e-4)
+    cg = col.detach().cpu().numpy()
+    scale = max(1.0, float(np.abs(colors).max()))
+    cerr = float(np.abs(cg - colors).max())
+    info["colors_max_abs_err"] = cerr
+    info["colors_tolerance"] = 1e-5 * scale
+    info["rays"] = int(cg.shape[0])
+    # colours are compared when the sample sets are identical (a sample on the guard band changes its ray's colour)
+    ok = ok and (cerr <= 1e-5 * scale or not info.get("identical", False))
+    return bool(ok), info
 
 
 # ----------------------------------------------------------------------------- main
@@ -360,7 +589,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rays", type=int, default=1024 * 1024)
-    ap.add_argument("--res", type=int, default=128)
+    ap.add_argument("--res", type=int, default=0,
+                    help="grid resolution; default: 128 on one GPU (BASELINE cfg 2), 256 (the shared grid of cfg 4) on several")
     ap.add_argument("--grid", default="shell10", choices=["shell10", "iid10"])
     ap.add_argument("--ray-variant", default="image", choices=["image", "random"])
     ap.add_argument("--field", default="native", choices=["native", "torch"],
@@ -370,19 +600,30 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the second (software-pipelined) timed loop")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary configurations (cfg2 variants, cfg3, cfg5)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and env_world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} must be launched with one rank per GPU: python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} "
+                         f"(WORLD_SIZE is {env_world})")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     world, rank, local_rank = init_distributed("nccl", dev)
     if world > 1:  # one process per GPU: the ranks share the host's cores (the step itself is single-threaded on the host)
         torch.set_num_threads(max(1, (os.cpu_count() or world) // (2 * world)))
-    assert world == max(1, args.gpus) or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+    if args.res <= 0:
+        args.res = 128 if world == 1 else 256
 
-    w = make_workload(dev, args.rays, args.res, args.grid, args.ray_variant, rank, args.field)
+    if world > 1:   # cfg 4: one grid for all ranks, broadcast once from rank 0
+        binaries = shared_grid(dev, args.res, args.grid, rank, world)
+        w = make_workload(dev, args.rays, args.res, args.grid, args.ray_variant, rank, args.field, binaries=binaries)
+    else:
+        w = make_workload(dev, args.rays, args.res, args.grid, args.ray_variant, rank, args.field)
     w["estimator"].bin_rays = {"auto": None, "on": True, "off": False}[args.bin_rays]
 
     def sync():
@@ -393,11 +634,8 @@ def main():
 
     for _ in range(args.warmup):
         run_step(w, world)
-    timer = None
-    if not args.no_kernel_timing and rank == 0:
-        timer = KernelTimer(); timer.install()
     # As timeit does: no cyclic garbage collection of the host interpreter inside the timed region.  A generation-2
-    # pass (about one per 60 steps here, ~35 ms with torch loaded) would otherwise land in one of the two 40 ms loops
+    # pass (about one per 60 steps here, ~35 ms with torch loaded) would otherwise land in one of the 40 ms loops
     # at random and double its time; everything the step allocates is reference-counted and freed as usual.
     gc.collect(); gc.disable()
     sync()
@@ -408,11 +646,24 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     gc.enable()
-    if timer is not None:
-        ksum = timer.summary(args.steps); timer.uninstall()
     dt = max_over_ranks(dt, world, dev)
 
-    # Second, separately timed loop: the same K steps software-pipelined (the geometry-only traversal of batch i+1
+    # Per-kernel HIP-event times: a separate loop of the same K steps (two event records per native call would otherwise
+    # sit inside `value`).
+    ksum = None
+    if not args.no_kernel_timing and rank == 0:
+        timer = KernelTimer(); timer.install()
+        try:
+            for _ in range(args.steps):
+                run_step(w, world)
+            ksum = timer.summary(args.steps)
+        finally:
+            timer.uninstall()
+    elif not args.no_kernel_timing:
+        for _ in range(args.steps):      # the other ranks take part in the collectives of rank 0's extra loop
+            run_step(w, world)
+
+    # Third, separately timed loop: the same K steps software-pipelined (the geometry-only traversal of batch i+1
     # runs on a side stream under the HBM-bound rendering / backward of batch i).  Reported beside `value`,
     # which stays the strictly sequential step the per-kernel numbers and the rocprof summaries refer to.
     dt_pipe, pipe_error = None, None
@@ -438,16 +689,19 @@ def main():
             if dt_pipe == float("inf"):
                 dt_pipe = None
 
+    rc = 0
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.rays / (dt / args.steps)
+        cfg = "cfg2" if world == 1 else "cfg4"
+        grid_note = f"{args.res}^3 {args.grid} occ grid (G=1" + (", shared: built on rank 0, broadcast bit-packed)" if world > 1 else ")")
         out = {
             "metric": "rays/sec (fwd+bwd) through 128^3 occ-grid, 1M-ray batch",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cfg2: {args.rays} {args.ray_variant} rays/GPU, {args.res}^3 {args.grid} occ grid "
-                                   f"(G=1), step 2*sqrt(3)/1024, sampling+rendering fwd+bwd",
+            "config": {"workload": f"{cfg}: {args.rays} {args.ray_variant} rays/GPU, {grid_note}, step 2*sqrt(3)/1024, "
+                                   f"sampling+rendering fwd+bwd" + (", all-reduce of the parameter gradient over RCCL" if world > 1 else ""),
                        "rays_per_gpu": args.rays, "resolution": args.res, "grid": args.grid,
                        "samples_after_compaction": int(m_last), "parallelism": f"ray-sharded x{world}",
                        "field": f"synthetic analytic field, {args.field} callbacks (see bench.py NativeField/TorchField)"},
@@ -460,22 +714,16 @@ def main():
                 "note": "same K steps, traversal of batch i+1 prefetched on a second stream "
                         "(OccGridEstimator.prefetch_traversal) under the rendering/backward of batch i; every step "
                         "still does one traversal and one rendering pass, results identical"}
-        if timer is not None:
+        if ksum is not None:
             # total samples before compaction: size of the traversal output, from the estimator
             import nerfacc_amd as na
             ri, ts, te, pi = na.grid._traverse_samples(
                 w["rays_o"], w["rays_d"], w["estimator"].binaries, w["estimator"].aabbs,
                 torch.zeros(args.rays, device=dev), torch.full((args.rays,), 1e10, device=dev), w["step"], 0.0)
             M = int(ri.numel())
+            del ri, ts, te, pi
             ab = algorithmic_bytes(args.rays, M, int(m_last), args.res)
-            kernels = {}
-            for k, v in ksum.items():
-                entry = dict(v)
-                if k in ab:
-                    per_launch = ab[k] / max(v["launches_per_step"], 1e-9)
-                    entry["algorithmic_bytes_per_launch"] = per_launch
-                    entry["achieved_GBps"] = per_launch / (v["ms_per_launch"] * 1e-3) / 1e9
-                kernels[k] = entry
+            kernels = kernel_table(ksum, ab)
             # Op-level view: one logical op of the reference API may be several launches here.
             groups = {
                 "traverse_grids (nfa_traverse_runs + nfa_expand_runs [+ nfa_traverse_grids fill of overflow rays])":
@@ -495,42 +743,54 @@ def main():
                 ks = [k for k in ks if k in kernels]
                 if not ks:
                     continue
-                ms = sum(kernels[k]["ms_per_step"] for k in ks)
+                t_ms = sum(kernels[k]["ms_per_step"] for k in ks)
                 nbytes = trav_bytes if name.startswith("traverse_grids") else sum(ab[k] for k in ks)
-                ops[name] = {"ms_per_step": ms, "launches": [k for k in ks], "algorithmic_bytes": nbytes,
-                             "achieved_GBps": nbytes / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                ops[name] = {"ms_per_step": t_ms, "launches": [k for k in ks], "algorithmic_bytes": nbytes,
+                             "achieved_GBps": nbytes / (t_ms * 1e-3) / 1e9, "frac_of_hbm_peak": nbytes / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
             # HBM traffic from the PMC passes committed under profiles/ (collected with
             # scripts/collect_profiles.sh in separate rocprofv3 --pmc runs; 2 x FETCH_SIZE + WRITE_SIZE)
-            traffic = {}
+            pmc, prof = {}, None
             try:
                 prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_hbm_traffic.json"))[-1]
                 pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
-                sym = {"nfa_traverse_runs": "nfa::runs_kernel", "nfa_expand_runs": "expand_runs_kernel",
-                       "nfa_render_from_density_fwd": "DensityFwdOp", "nfa_render_from_density_bwd": "DensityBwdOp",
-                       "nfa_render_accumulate_fwd": "RenderAccumOp", "nfa_render_accumulate_bwd": "RenderAccumBwdOp",
-                       "nfa_render_fused_fwd": "RenderFusedFwdOp", "nfa_render_fused_bwd": "RenderFusedBwdOp",
-                       "nfa_render_visibility": "VisibilityOp", "nfa_compact_samples": "CompactOp"}
-                for name, o in ops.items():
-                    tot, ok = 0.0, True
-                    for k in o["launches"]:
-                        pats = sym.get(k)
-                        if pats is None:
-                            continue
-                        for pat in ((pats,) if isinstance(pats, str) else pats):
-                            hit = [v for kk, v in pmc.items() if pat + "<" in kk or kk.endswith(pat)]
-                            ok = ok and bool(hit)
-                            tot += sum(h["hbm_bytes_per_launch"] for h in hit[:1])
-                    traffic[name] = tot if ok and tot > 0 else None
-                    o["hbm_traffic_bytes"] = traffic[name]
-                    o["hbm_traffic_source"] = "profiles/" + prof
             except Exception:
                 pass
-            dom = max(ops, key=lambda k: ops[k]["ms_per_step"])
-            a = ops[dom]["achieved_GBps"]
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": a / HBM_PEAK_GBPS, "traffic": traffic.get(dom),
-                               "ms_per_launch": ops[dom]["ms_per_step"],
-                               "algorithmic_bytes_per_launch": ops[dom]["algorithmic_bytes"]}
+            sym = {"nfa_traverse_runs": "walk_kernel", "nfa_expand_runs": "expand_runs_kernel",
+                   "nfa_render_from_density_fwd": "DensityFwdOp", "nfa_render_from_density_bwd": "DensityBwdOp",
+                   "nfa_render_accumulate_fwd": "RenderAccumOp", "nfa_render_accumulate_bwd": "RenderAccumBwdOp",
+                   "nfa_render_fused_fwd": "RenderFusedFwdOp", "nfa_render_fused_bwd": "RenderFusedBwdOp",
+                   "nfa_render_visibility": "VisibilityOp", "nfa_compact_samples": "CompactOp"}
+
+            def traffic_of(k):
+                pat = sym.get(k)
+                if pat is None:
+                    return None
+                hit = [v for kk, v in pmc.items() if pat in kk]
+                return hit[0]["hbm_bytes_per_launch"] if hit else None
+
+            for k, e in kernels.items():
+                t = traffic_of(k)
+                if t is not None:
+                    e["hbm_traffic_bytes"] = t
+                    e["hbm_traffic_source"] = "profiles/" + prof
+            for name, o in ops.items():
+                ts_ = [traffic_of(k) for k in o["launches"] if k in sym]
+                o["hbm_traffic_bytes"] = sum(ts_) if ts_ and all(t is not None for t in ts_) else None
+            # roofline: the dominant KERNEL of the step (longest launch); the op-level table and the kernel furthest below
+            # its roofline are given beside it
+            rated = {k: v for k, v in kernels.items() if "achieved_GBps" in v}
+            dom = max(rated, key=lambda k: rated[k]["ms_per_launch"])
+            weakest = min(rated, key=lambda k: rated[k]["frac_of_hbm_peak"])
+            a = rated[dom]["achieved_GBps"]
+            out["roofline"] = {"bound": rated[dom]["bound"] if rated[dom]["bound"] != "issue" else "hbm", "kernel": dom,
+                               "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a / HBM_PEAK_GBPS,
+                               "traffic": rated[dom].get("hbm_traffic_bytes"),
+                               "ms_per_launch": rated[dom]["ms_per_launch"],
+                               "algorithmic_bytes_per_launch": rated[dom]["algorithmic_bytes_per_launch"],
+                               "limiter": rated[dom]["bound"]}
+            out["weakest_kernel"] = {"kernel": weakest, "frac_of_hbm_peak": rated[weakest]["frac_of_hbm_peak"],
+                                     "ms_per_launch": rated[weakest]["ms_per_launch"], "limiter": rated[weakest]["bound"],
+                                     "note": "bound by instruction issue, not by HBM (DESIGN.md 4)" if rated[weakest]["bound"] == "issue" else ""}
             out["ops"] = ops
             # SURVEY 8(d) headline: (B_trav + B_rw_f + B_rw_b) / (t_trav + t_rw_f + t_rw_b)
             hk = [k for k in ops if k.startswith(("traverse_grids", "render_weight_from_density", "rendering "))]
@@ -542,10 +802,31 @@ def main():
             native_ms = sum(v["ms_per_step"] for v in ksum.values())
             out["native_ms_per_step"] = native_ms
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(w)
+            run_step(w, 1)                       # the batch the oracle is about to restate (w["last"])
+            base, oracle_out = cpu_baseline(w)
+            out["cpu_baseline"] = base
+            ok, info = parity_check(w, oracle_out)
+            out["parity_checked"] = ok
+            out["parity"] = info
+            if not ok:
+                rc = 3
+            del oracle_out
+        if not args.no_extras and world == 1:
+            w.pop("last", None)
+            for key, fn in (("cfg2_compacting", lambda: extra_cfg2_variant(dev, args, sigma_scale=16.0)),
+                            ("cfg2_random", lambda: extra_cfg2_variant(dev, args, rays="random")),
+                            ("cfg3", lambda: extra_cfg3(dev, 1 << 20, 5)),
+                            ("cfg5", lambda: extra_cfg5(dev, 1 << 21, 3))):
+                try:
+                    out[key] = fn()
+                except Exception as e:  # a secondary configuration must never cost the headline line
+                    out[key] = {"error": repr(e)}
+                torch.cuda.empty_cache()
         print(json.dumps(out))
     if _group_live():
         torch.distributed.destroy_process_group()
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

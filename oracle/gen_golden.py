@@ -416,8 +416,46 @@ def traversal_fixtures():
     save("traversal", **out)
 
 
+# ----------------------------------------------------------------------------- 6. proposal-network sampling
+def propnet_fixtures():
+    """The reference's own PropNetEstimator.sampling (estimators/prop_net.py:38-129) run on the CPU with its one native
+    call, importance_sampling, served by the oracle's restatement (itself pinned to _sample_from_weighted above): pins
+    oracle.propnet_sampling, i.e. the level loop, the s -> t mapping and cdfs = 1 - cat([T, 0])."""
+    from nerfacc.data_specs import RayIntervals as RefIntervals
+
+    def oracle_is(intervals, cdfs, n_intervals_per_ray, stratified=False):
+        assert not stratified
+        iv, sm = O.importance_sampling(intervals.vals.numpy(), cdfs.detach().numpy(), n_intervals_per_ray)
+        return RefIntervals(vals=T(iv)), None
+
+    saved = rprop.importance_sampling
+    rprop.importance_sampling = oracle_is
+    out = {}
+    try:
+        n_rays = 64
+        off = np.linspace(-0.6, 0.6, n_rays, dtype=np.float32)[:, None]
+        fn_np = lambda ts, te: (np.exp(-((ts + te) * np.float32(0.5) - np.float32(4.0) - off) ** 2 * np.float32(2.0))
+                                * np.float32(3.0) + np.float32(0.05)).astype(np.float32)
+        fn_t = lambda ts, te: T(fn_np(ts.numpy(), te.numpy()))
+        for tag, props, final, kind in (("u", [64], 16, "uniform"), ("l", [48, 24], 12, "lindisp")):
+            est = rprop.PropNetEstimator()
+            ts, te = est.sampling([fn_t] * len(props), props, final, n_rays, 2.0, 6.0, sampling_type=kind, requires_grad=True)
+            ots, ote, levels = O.propnet_sampling([fn_np] * len(props), props, final, n_rays, 2.0, 6.0, sampling_type=kind)
+            close(ots, ts.numpy(), atol=2e-6, what=f"propnet {tag} t_starts")
+            close(ote, te.numpy(), atol=2e-6, what=f"propnet {tag} t_ends")
+            for (iv, cdfs), (o_iv, o_cdfs) in zip(est.prop_cache[:-1], levels):
+                close(o_iv, iv.vals.numpy(), atol=1e-6, what=f"propnet {tag} intervals")
+                close(o_cdfs, cdfs.numpy(), atol=1e-6, what=f"propnet {tag} cdfs")
+            out.update({f"{tag}_props": np.array(props), f"{tag}_final": final, f"{tag}_t_starts": ts.numpy(),
+                        f"{tag}_t_ends": te.numpy(), f"{tag}_cdfs0": est.prop_cache[0][1].numpy()})
+        out["off"] = off
+    finally:
+        rprop.importance_sampling = saved
+    save("propnet", **out)
+
+
 if __name__ == "__main__":
-    for fn in (ragged_packed, batched_volrend, ray_aabb, pdf_fixtures, traversal_fixtures):
+    for fn in (ragged_packed, batched_volrend, ray_aabb, pdf_fixtures, traversal_fixtures, propnet_fixtures):
         print(fn.__name__)
         fn()
     print("oracle pinned against the reference; fixtures written to", OUT)

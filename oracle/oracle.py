@@ -433,3 +433,50 @@ def occgrid_sampling(rays_o, rays_d, binaries, aabbs, sigma_fn=None, alpha_fn=No
     if return_all:
         return (ray_indices, t_starts, t_ends), full
     return ray_indices, t_starts, t_ends
+
+
+# --------------------------------------------------------------------------- proposal-network sampling
+def transform_stot(transform_type, s_vals, t_min, t_max):
+    """nerfacc/estimators/prop_net.py:215-229, same fp32 operation order."""
+    s = _f32(s_vals)
+    one = np.float32(1.0)
+    t_min, t_max = np.float32(t_min), np.float32(t_max)
+    if transform_type == "uniform":
+        return (s * t_max + (one - s) * t_min).astype(np.float32)
+    if transform_type == "lindisp":
+        return (one / (s * (one / t_max) + (one - s) * (one / t_min))).astype(np.float32)
+    raise ValueError(f"Unknown transform_type: {transform_type}")
+
+
+def batched_transmittance_from_density(t_starts, t_ends, sigmas):
+    """nerfacc/volrend.py:245-264 with packed_info=None: exp(-exclusive_sum(sigma * dt)) along the last axis
+    (scan.py:84-91: cumsum of the row shifted by one)."""
+    sd = (_f32(sigmas) * (_f32(t_ends) - _f32(t_starts))).astype(np.float32)
+    excl = np.cumsum(np.concatenate([np.zeros_like(sd[..., :1]), sd[..., :-1]], -1), axis=-1, dtype=np.float32)
+    return np.exp(-excl).astype(np.float32)
+
+
+def propnet_sampling(prop_sigma_fns, prop_samples, num_samples, n_rays, near_plane, far_plane,
+                     sampling_type="lindisp", stratified=False, seed=0, offset=0):
+    """nerfacc/estimators/prop_net.py:38-129 (PropNetEstimator.sampling) on the oracle's importance_sampling:
+    the level loop  resample -> s->t -> proposal density -> transmittance -> cdfs = 1 - cat([T, 0]),  then the final
+    resampling.  Returns (t_starts, t_ends, levels) with levels = [(interval edges in s, cdfs)] per proposal network
+    (what the reference caches for the loss, :115-116).  `offset` advances by 4 per importance_sampling call as the
+    reference's generator does (pdf.cu:376-383)."""
+    assert len(prop_sigma_fns) == len(prop_samples)
+    cdfs = np.concatenate([np.zeros((n_rays, 1), np.float32), np.ones((n_rays, 1), np.float32)], -1)
+    vals = cdfs.copy()
+    levels = []
+    for level_fn, level_samples in zip(prop_sigma_fns, prop_samples):
+        vals, _ = importance_sampling(vals, cdfs, level_samples, stratified, seed=seed, offset=offset)
+        offset += 4
+        t_vals = transform_stot(sampling_type, vals, near_plane, far_plane)
+        t_starts, t_ends = t_vals[..., :-1], t_vals[..., 1:]
+        sigmas = _f32(level_fn(t_starts, t_ends))
+        assert sigmas.shape == t_starts.shape
+        trans = batched_transmittance_from_density(t_starts, t_ends, sigmas)
+        cdfs = (np.float32(1.0) - np.concatenate([trans, np.zeros_like(trans[:, :1])], -1)).astype(np.float32)
+        levels.append((vals, cdfs))
+    vals, _ = importance_sampling(vals, cdfs, num_samples, stratified, seed=seed, offset=offset)
+    t_vals = transform_stot(sampling_type, vals, near_plane, far_plane)
+    return t_vals[..., :-1], t_vals[..., 1:], levels

@@ -38,13 +38,17 @@ def _worker(rank, world, port, q):
     import bench
     w, r, lr = bench.init_distributed("gloo")
     assert (w, r) == (world, rank)
+    # BASELINE cfg 4: the occupancy grid is built on rank 0 only and broadcast bit-packed; every rank must end up with the
+    # same torch.bool grid (here 32^3; the bench uses 256^3)
+    shared = bench.shared_grid(torch.device("cpu"), 32, "shell10", rank, w)
+    grid_sha = __import__("hashlib").sha256(shared.numpy().tobytes()).hexdigest()
     g, n = _local_grad(rank)
     p = torch.nn.Parameter(torch.zeros(2, dtype=torch.float64))
     p.grad = torch.tensor([g, float(n)], dtype=torch.float64)
     bench.allreduce_grads([p], w)
     torch.distributed.barrier()
     dt = bench.max_over_ranks(0.1 * (rank + 1), w)
-    q.put((rank, p.grad.tolist(), dt))
+    q.put((rank, p.grad.tolist(), dt, grid_sha, tuple(shared.shape)))
     torch.distributed.destroy_process_group()
 
 
@@ -61,7 +65,11 @@ def test_two_rank_gradient_allreduce_matches_union_batch():
         assert p.exitcode == 0
     g0, n0 = _local_grad(0)
     g1, n1 = _local_grad(1)
-    for rank, grad, dt in res:
+    sys.path.insert(0, ROOT)
+    import bench
+    want = __import__("hashlib").sha256(bench.make_grid(32, "shell10").tobytes()).hexdigest()
+    for rank, grad, dt, grid_sha, shape in res:
+        assert grid_sha == want and shape == (1, 32, 32, 32)   # identical binaries on every rank (= rank 0's grid)
         assert abs(grad[0] - (g0 + g1)) < 1e-9 * max(1.0, abs(g0 + g1))
         assert grad[1] == n0 + n1
         assert abs(dt - 0.2) < 1e-12          # MAX over ranks of the per-rank times

@@ -914,6 +914,40 @@ def test_propnet_sampling_and_loss(dev):
     assert np.isfinite(loss) and len(est2.prop_cache) == 0 and float(p) != 3.0
 
 
+def test_propnet_sampling_vs_oracle(dev, oracle):
+    """PropNetEstimator.sampling (ref estimators/prop_net.py:38-129) against the oracle's restatement of the level loop at
+    the shape of BASELINE cfg 3 (2 -> 64 -> 16 edges per ray, and a two-proposal 64 -> 64 -> 16 variant): final
+    (t_starts, t_ends) and every cached (intervals, cdfs) level within 1e-5 of the distance range."""
+    n_rays = 4099
+    off = torch.linspace(-0.6, 0.6, n_rays, device=dev)[:, None]
+    fn_t = lambda ts, te: torch.exp(-((ts + te) * 0.5 - 4.0 - off) ** 2 * 2.0) * 3.0 + 0.05
+    off_np = off.cpu().numpy()
+    fn_np = lambda ts, te: (np.exp(-((ts + te) * np.float32(0.5) - np.float32(4.0) - off_np) ** 2 * np.float32(2.0)) * np.float32(3.0)
+                            + np.float32(0.05)).astype(np.float32)
+    for fns, props, final, kind in (([0], [64], 16, "uniform"), ([0, 0], [64, 64], 16, "uniform"), ([0], [64], 16, "lindisp"),
+                                     ([0], [33], 7, "lindisp")):
+        est = na.PropNetEstimator().to(dev)
+        ts, te = est.sampling([fn_t] * len(fns), props, final, n_rays, 2.0, 6.0, sampling_type=kind, requires_grad=True)
+        ots, ote, levels = oracle.propnet_sampling([fn_np] * len(fns), props, final, n_rays, 2.0, 6.0, sampling_type=kind)
+        assert ts.shape == (n_rays, final)
+        scale = 6.0
+        assert np.abs(ts.cpu().numpy() - ots).max() <= 1e-5 * scale and np.abs(te.cpu().numpy() - ote).max() <= 1e-5 * scale, kind
+        assert len(est.prop_cache) == len(props) + 1
+        for (iv, cdfs), (o_iv, o_cdfs) in zip(est.prop_cache[:-1], levels):
+            assert np.abs(iv.vals.cpu().numpy() - o_iv).max() <= 1e-5
+            assert np.abs(cdfs.detach().cpu().numpy() - o_cdfs).max() <= 1e-5
+        assert est.prop_cache[-1][1] is None
+    # and the reference's own outputs (fixture written by oracle/gen_golden.py from the reference's level loop)
+    g = load_golden("propnet")
+    offg = torch.from_numpy(g["off"]).to(dev)
+    fn_g = lambda ts, te: torch.exp(-((ts + te) * 0.5 - 4.0 - offg) ** 2 * 2.0) * 3.0 + 0.05
+    for tag, kind in (("u", "uniform"), ("l", "lindisp")):
+        props = [int(v) for v in g[f"{tag}_props"]]
+        ts, te = na.PropNetEstimator().to(dev).sampling([fn_g] * len(props), props, int(g[f"{tag}_final"]), offg.shape[0], 2.0, 6.0,
+                                                        sampling_type=kind)
+        assert np.abs(ts.cpu().numpy() - g[f"{tag}_t_starts"]).max() <= 6e-5 and np.abs(te.cpu().numpy() - g[f"{tag}_t_ends"]).max() <= 6e-5
+
+
 def test_bench_geometry_bit_exact_vs_oracle(dev, oracle):
     """The bench's geometry at 64x64 rays (pinhole camera 2.2 units from the box, 128^3 shell grid, step
     2 sqrt(3)/1024): every ray marches ~650 steps from the near plane before it meets the grid, the case the
@@ -1231,3 +1265,65 @@ def test_test_mode_marching_loop(dev, oracle, levels, cone, alpha_thre):
     assert_close(opa, oopa, atol=2e-5, rtol=1e-5); assert_close(rgb, orgb, atol=2e-5, rtol=1e-5)
     assert_close(dep, odep, atol=1e-4, rtol=1e-4)
     assert (opa.max() <= 1.0 + 1e-5) and (opa.min() >= 0)
+
+
+def test_full_size_bit_exact_vs_oracle(dev, oracle):
+    """BASELINE cfg 2 at FULL size (1024x1024 image rays, 128^3 shell10 grid, step 2 sqrt(3)/1024): the sampler's
+    (ray_indices, t_starts, t_ends) and packed_info bit for bit against the oracle, colours of rendering() within 1e-5.
+    The same comparison runs inside bench.py after the timed loops (`parity_checked`)."""
+    import bench
+    from oracle import check as OC
+    w = bench.make_workload(dev, n_rays=1024 * 1024, res=128)
+    n = w["n_rays"]
+    bench.run_step(w, 1)
+    ri, ts, te, colors = w["last"]
+    o, d = w["rays_np"]
+    b = w["estimator"].binaries.cpu().numpy()
+    aabb = np.array([[-1, -1, -1, 1, 1, 1]], np.float32)
+    kept, full, ocolors, _, sig = bench._oracle_step(oracle, o, d, b, aabb, w["step"], 1.0)
+    got = (ri.cpu().numpy(), ts.cpu().numpy(), te.cpu().numpy())
+    assert got[0].size > 30_000_000
+    tr, al = oracle.render_transmittance_from_density(full[1], full[2], sig(full[1], full[2], full[0]), full[3])
+    ok, info = OC.compare_sampling(got, kept, full[:3], tr, al, early_stop_eps=1e-4)
+    assert ok and info["identical"], info
+    assert (na.pack_info(ri, n).cpu().numpy() == oracle.pack_info(kept[0], n)).all()
+    assert np.abs(colors.detach().cpu().numpy() - ocolors).max() <= 1e-5 * max(1.0, float(np.abs(ocolors).max()))
+
+
+def test_cfg4_shared_256_grid(dev, oracle):
+    """BASELINE cfg 4's workload on one GPU: the shared 256^3 shell10 grid (built on rank 0 and unpacked from the
+    bit-packed broadcast buffer, bench.shared_grid), rank-seeded cameras.  64x64 rays bit-exact against the oracle (sampler
+    and the API's interval stream), size-independent properties on the full 1 M-ray batch."""
+    import bench
+    binaries = bench.shared_grid(dev, 256, "shell10", 0, 1)
+    b = bench.make_grid(256, "shell10")
+    assert (binaries.cpu().numpy() == b).all()
+    step = 2 * 3 ** 0.5 / 1024
+    est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=256).to(dev)
+    est.binaries = binaries
+    ab = est.aabbs.cpu().numpy()
+    for rank in (0, 5):
+        o, d = bench.make_rays(64 * 64, "image", rank=rank)
+        ri, ts, te = est.sampling(T(o, dev), T(d, dev), render_step_size=step)
+        ori, ots, ote = oracle.occgrid_sampling(o, d, b, ab, render_step_size=step)
+        assert ri.numel() > 50000
+        assert (ri.cpu().numpy() == ori).all() and (ts.cpu().numpy() == ots).all() and (te.cpu().numpy() == ote).all()
+    res = na.traverse_grids(T(o, dev), T(d, dev), binaries, T(ab, dev), step_size=step)
+    _cmp_traversal(res, oracle.traverse_grids(o, d, b, ab, step_size=step))
+    # full size: one step of the bench on this grid
+    w = bench.make_workload(dev, n_rays=1024 * 1024, res=256, rank=3, binaries=binaries)
+    bench.run_step(w, 1)
+    ri, ts, te, colors = w["last"]
+    n = w["n_rays"]
+    assert (ri[1:] >= ri[:-1]).all() and ri.min() >= 0 and ri.max() < n and (te > ts).all()
+    pi = na.pack_info(ri, n)
+    assert int(pi[:, 1].sum()) == ri.numel() and int(pi[:, 1].max()) <= 1024
+    same = ri[1:] == ri[:-1]
+    assert (ts[1:][same] >= te[:-1][same]).all()
+    # every sample's mid-point lies in an occupied cell (the reference's own traversal property, tests/test_grid.py:57-68)
+    mid = (ts + te) * 0.5
+    pos = w["rays_o"][ri] + w["rays_d"][ri] * mid[:, None]
+    cell = ((pos + 1.0) * 0.5 * 256).long().clamp(0, 255)
+    occ = binaries[0, cell[:, 0], cell[:, 1], cell[:, 2]]
+    assert occ.float().mean() > 0.9995   # (mid-points within rounding of a cell face may land in the neighbour)
+    assert torch.isfinite(colors).all()

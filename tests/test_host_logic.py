@@ -74,3 +74,27 @@ def test_transform_stot_and_schedule():
     fn = get_proposal_requires_grad_fn(target=5.0, num_steps=10)
     fires = [fn(s) for s in range(40)]
     assert fires[0] is False and sum(fires) > 3
+
+
+def test_guard_band_sampling_checker():
+    """oracle/check.py (used by smoke(), bench.py and the GPU tests): identical outputs pass; a sample on the visibility
+    threshold may fall on either side; any other difference fails."""
+    from oracle import check as OC
+    ri = np.array([0, 0, 0, 1, 1, 2], np.int64)
+    ts = np.array([0.1, 0.2, 0.3, 0.1, 0.2, 0.5], np.float32)
+    te = ts + np.float32(0.1)
+    trans = np.array([1.0, 0.5, 1e-4 + 2e-8, 1.0, 0.3, 1.0], np.float32)   # sample 2 sits on the 1e-4 threshold
+    vis = trans >= np.float32(1e-4)
+    kept = (ri[vis], ts[vis], te[vis])
+    full = (ri, ts, te)
+    ok, info = OC.compare_sampling(kept, kept, full, trans, None, early_stop_eps=1e-4)
+    assert ok and info["identical"]
+    drop2 = np.array([True, True, False, True, True, True])
+    ok, info = OC.compare_sampling((ri[drop2], ts[drop2], te[drop2]), kept, full, trans, None, early_stop_eps=1e-4)
+    assert ok and info["guarded"] == 1 and not info["identical"]
+    drop1 = np.array([True, False, True, True, True, True])                  # a sample far from the threshold is missing
+    ok, info = OC.compare_sampling((ri[drop1], ts[drop1], te[drop1]), kept, full, trans, None, early_stop_eps=1e-4)
+    assert not ok and info["missing"] == 1
+    te_bad = te.copy(); te_bad[4] += np.float32(1e-3)
+    ok, info = OC.compare_sampling((ri[drop2], ts[drop2], te_bad[drop2]), kept, full, trans, None, early_stop_eps=1e-4)
+    assert not ok

@@ -115,3 +115,22 @@ def test_traversal_golden(oracle):
         assert sha(sm["packed_info"]) == str(g[f"{tag}_sm_cnts_sha"])
         assert sha(iv["vals"]) == str(g[f"{tag}_iv_vals_sha"])
         assert sha(term) == str(g[f"{tag}_term_sha"])
+
+
+def _propnet_field(off):
+    return lambda ts, te: (np.exp(-((ts + te) * np.float32(0.5) - np.float32(4.0) - off) ** 2 * np.float32(2.0))
+                           * np.float32(3.0) + np.float32(0.05)).astype(np.float32)
+
+
+def test_propnet_sampling_vs_reference_fixture(oracle):
+    """oracle.propnet_sampling against the outputs of the reference's own PropNetEstimator.sampling loop
+    (estimators/prop_net.py:38-129; oracle/gen_golden.py: propnet_fixtures)."""
+    g = load_golden("propnet")
+    fn = _propnet_field(g["off"])
+    n = g["off"].shape[0]
+    for tag, kind in (("u", "uniform"), ("l", "lindisp")):
+        props = [int(v) for v in g[f"{tag}_props"]]
+        ts, te, levels = oracle.propnet_sampling([fn] * len(props), props, int(g[f"{tag}_final"]), n, 2.0, 6.0, sampling_type=kind)
+        assert_close(ts, g[f"{tag}_t_starts"], atol=2e-6)
+        assert_close(te, g[f"{tag}_t_ends"], atol=2e-6)
+        assert_close(levels[0][1], g[f"{tag}_cdfs0"], atol=1e-6)
