@@ -195,6 +195,26 @@ int nfa_expand_intervals(int64_t n_rays, float step_size, const int32_t *run_cnt
                          int32_t max_runs, const int64_t *iv_packed_info /*[n_rays,2]*/, float *vals,
                          int64_t *ray_indices, uint8_t *is_left, uint8_t *is_right, nfa_stream_t stream);
 
+/* ------------------------------------------------------------------ grid maintenance */
+
+/* OccGridEstimator._update (ref: estimators/occ_grid.py:368-404) as kernels.
+ *   nfa_grid_cell_points  x[i] = aabb_lo + (coords(indices[i]) + jitter[i]) / res * (aabb_hi - aabb_lo)   (ref :383-391;
+ *                         indices are cell ids inside one level, x slowest; aabb = the level's 6 floats on the device)
+ *   nfa_grid_ema_update   occs[cell_base + indices[i]] = max(occs[...] * ema_decay, occ[i])   (ref :393-398); a cell
+ *                         listed several times gets max(occs * decay, max_i occ_i) -- deterministic, one of the values
+ *                         the reference's index_put may leave.  scratch: n floats.
+ *   nfa_grid_rebinarize   thre = min(mean(occs[occs >= 0]), occ_thre) reduced on the device, binaries = occs > thre
+ *                         (ref :403-404) written as the torch.bool buffer AND as the walk's 1-bit grid copy
+ *                         (nfa_pack_walk_bits layout); scratch: nfa_grid_rebinarize_scratch_bytes(), on return its last
+ *                         two floats hold {thre, mean}. */
+int nfa_grid_cell_points(const int64_t *indices, const float *jitter /*[n,3]*/, int64_t n, const int32_t *res,
+                         const float *aabb /*[6]*/, float *x /*[n,3]*/, nfa_stream_t stream);
+int nfa_grid_ema_update(float *occs, int64_t cell_base, const int64_t *indices, int64_t n, const float *occ,
+                        float ema_decay, float *scratch /*[n]*/, nfa_stream_t stream);
+int64_t nfa_grid_rebinarize_scratch_bytes(void);
+int nfa_grid_rebinarize(const float *occs, int32_t n_grids, const int32_t *res, float occ_thre, uint8_t *binaries,
+                        uint32_t *walk_bits, void *scratch, nfa_stream_t stream);
+
 /* ------------------------------------------------------------------ packed segments */
 
 /* Ownership table for the flat segmented kernels: the element range is cut into n_tiles tiles of

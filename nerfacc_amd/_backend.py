@@ -58,6 +58,10 @@ _SIGS = {
     "nfa_pack_walk_bits": [_vp, _i32, C.POINTER(_i32), _vp, _vp],
     "nfa_traverse_runs": [C.POINTER(TraverseArgs), _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp],
     "nfa_bin_rays": [_vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "nfa_grid_cell_points": [_vp, _vp, _i64, C.POINTER(_i32), _vp, _vp, _vp],
+    "nfa_grid_ema_update": [_vp, _i64, _vp, _i64, _vp, _f32, _vp, _vp],
+    "nfa_grid_rebinarize_scratch_bytes": [],
+    "nfa_grid_rebinarize": [_vp, _i32, C.POINTER(_i32), _f32, _vp, _vp, _vp, _vp],
     "nfa_expand_runs": [_i64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "nfa_fill_ray_indices": [_i64, _vp, _vp, _vp],
     "nfa_traverse_cone_runs": [C.POINTER(TraverseArgs), _vp, _vp, _i32, _vp, _vp],
@@ -90,7 +94,7 @@ _SIGS = {
     "nfa_version": [],
     "nfa_device_arch": [C.c_char_p, _int],
 }
-_RESTYPES = {"nfa_bricks_words": _i64, "nfa_walk_bits_words": _i64, "nfa_cumsum_scratch_bytes": _i64, "nfa_seg_plan": None, "nfa_last_error": C.c_char_p}
+_RESTYPES = {"nfa_grid_rebinarize_scratch_bytes": _i64, "nfa_bricks_words": _i64, "nfa_walk_bits_words": _i64, "nfa_cumsum_scratch_bytes": _i64, "nfa_seg_plan": None, "nfa_last_error": C.c_char_p}
 
 EXPORTED_SYMBOLS = tuple(_SIGS)
 

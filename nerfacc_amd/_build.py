@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(_HERE, "libnerfacc_hip.so")
-SOURCES = ["grid.hip", "walk.hip", "traverse2.hip", "segscan.hip", "pdf.hip"]
+SOURCES = ["grid.hip", "walk.hip", "gridupd.hip", "traverse2.hip", "segscan.hip", "pdf.hip"]
 ARCH = os.environ.get("NERFACC_AMD_ARCH", "gfx950")
 # -ffp-contract=off: the traversal must not fuse a*b+c (floating-point contract)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", f"--offload-arch={ARCH}",
@@ -32,7 +32,7 @@ def hipcc() -> str | None:
 
 
 def _deps() -> list[str]:
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, h) for h in ("common.hip.h", "march.h")]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, h) for h in ("common.hip.h", "march.h", "walk_layout.h")]
     hdr = os.path.join(INCLUDE, "nerfacc_hip.h")
     if os.path.exists(hdr):
         deps.append(hdr)

@@ -7,10 +7,12 @@ visibility and compaction are two fused passes with one size read-back, and the 
 is cached per ``occs`` version.  Buffer names / dtypes match the reference so ``state_dict``s
 interchange (``resolution``, ``aabbs``, ``occs``, ``binaries``).
 
-Grid maintenance (``update_every_n_steps`` & co., ref :223-404) is plain torch, as upstream.
+Grid maintenance: ``_update`` (ref :368-404) runs as native passes on a ROCm device (csrc/gridupd.hip) and leaves the
+traversal's bit-packed grid copy beside the ``torch.bool`` buffer; the cell selection and ``mark_invisible_cells`` are torch.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Callable, List, Optional, Tuple, Union
 
 import torch
@@ -296,20 +298,77 @@ class OccGridEstimator(AbstractEstimator):
     @torch.no_grad()
     def _update(self, step: int, occ_eval_fn: Callable, occ_thre: float = 0.01, ema_decay: float = 0.95,
                 warmup_steps: int = 256) -> None:
-        """occs = max(occs * decay, occ(x)) at jittered cell positions, then re-binarise (ref :368-404)."""
+        """occs = max(occs * decay, occ(x)) at jittered cell positions, then re-binarise (ref :368-404).
+
+        On a ROCm device the three stages are native passes (csrc/gridupd.hip): cell ids + jitter -> positions, the EMA /
+        max scatter, and a device-side threshold + binarisation that writes the ``torch.bool`` buffer (the serialised
+        view) together with the traversal's bit-packed copy.  With ``torch.distributed`` initialised on several ranks the
+        occupancies are MAX-all-reduced before the threshold, so every rank ends with the same ``binaries`` whatever
+        cells it sampled (the reference is single-device)."""
         if step < warmup_steps:
             lvl_indices = self._get_all_cells()
         else:
             lvl_indices = self._sample_uniform_and_occupied_cells(self.cells_per_lvl // 4)
         for lvl, indices in enumerate(lvl_indices):
-            coords = self.grid_coords[indices]
-            unit = (coords + torch.rand_like(coords, dtype=torch.float32)) / self.resolution
-            x = self.aabbs[lvl, :3] + unit * (self.aabbs[lvl, 3:] - self.aabbs[lvl, :3])
+            jitter = torch.rand((indices.shape[0], self.DIM), dtype=torch.float32, device=indices.device)   # ref :385
+            x = self._cell_points(lvl, indices, jitter)
             occ = occ_eval_fn(x).squeeze(-1)
+            self._ema_update(lvl, indices, occ, ema_decay)
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            torch.distributed.all_reduce(self.occs, op=torch.distributed.ReduceOp.MAX)
+        self._rebinarize(occ_thre)
+
+    def _cell_points(self, lvl: int, indices: Tensor, jitter: Tensor) -> Tensor:
+        """World positions of cells ``indices`` of level ``lvl`` displaced by ``jitter`` in [0, 1)^3 cell units (ref :383-391)."""
+        if not indices.is_cuda:
+            unit = (self.grid_coords[indices] + jitter) / self.resolution
+            return self.aabbs[lvl, :3] + unit * (self.aabbs[lvl, 3:] - self.aabbs[lvl, :3])
+        n = indices.shape[0]
+        x = torch.empty((n, self.DIM), dtype=torch.float32, device=indices.device)
+        res = (C.c_int32 * 3)(*[int(v) for v in self.binaries.shape[1:]])
+        with torch.cuda.device(indices.device):
+            B.call("nfa_grid_cell_points", B.ptr(indices.contiguous()), B.ptr(jitter.contiguous()), n, res,
+                   self.aabbs.data_ptr() + 24 * lvl, B.ptr(x), B.stream())
+        return x
+
+    def _ema_update(self, lvl: int, indices: Tensor, occ: Tensor, ema_decay: float) -> None:
+        """``occs[cells] = max(occs[cells] * decay, occ)`` (ref :393-398), in place."""
+        if not self.occs.is_cuda:
             cell_ids = lvl * self.cells_per_lvl + indices
             self.occs[cell_ids] = torch.maximum(self.occs[cell_ids] * ema_decay, occ)
-        thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre)
-        self.binaries = (self.occs > thre).view(self.binaries.shape)
+            return
+        n = indices.shape[0]
+        occ = occ.to(torch.float32).contiguous()
+        assert occ.shape == (n,), "occ_eval_fn must return one value per position"
+        scratch = torch.empty(n, dtype=torch.float32, device=self.occs.device)
+        with torch.cuda.device(self.occs.device):
+            B.call("nfa_grid_ema_update", B.ptr(self.occs), lvl * self.cells_per_lvl, B.ptr(indices.contiguous()), n, B.ptr(occ),
+                   float(ema_decay), B.ptr(scratch), B.stream())
+        self._occs_mean_cache = None   # (the kernel wrote through the raw pointer: the version counter did not move)
+
+    def _rebinarize(self, occ_thre: float) -> None:
+        """``binaries = occs > clamp(mean(occs[occs >= 0]), max=occ_thre)`` (ref :403-404)."""
+        if not self.occs.is_cuda:
+            thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre)
+            self.binaries = (self.occs > thre).view(self.binaries.shape)
+            return
+        from ..grid import WALK_MAX_RES
+        dev = self.occs.device
+        shape = tuple(self.binaries.shape)
+        if max(shape[1:]) > WALK_MAX_RES:   # beyond the packed walk's range: the reference's expression
+            thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre)
+            self.binaries = (self.occs > thre).view(self.binaries.shape)
+            return
+        res = (C.c_int32 * 3)(*shape[1:])
+        binaries = torch.empty(shape, dtype=torch.bool, device=dev)
+        bits = torch.empty(int(B.load().nfa_walk_bits_words(shape[0], res)), dtype=torch.int32, device=dev)
+        scratch = torch.empty(int(B.load().nfa_grid_rebinarize_scratch_bytes()) // 8 + 1, dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            B.call("nfa_grid_rebinarize", B.ptr(self.occs), shape[0], res, float(occ_thre), B.ptr(binaries), B.ptr(bits),
+                   B.ptr(scratch), B.stream())
+        binaries._nfa_walk_bits = (binaries._version, bits)   # the traversal's grid copy is ready: no packing pass
+        self.binaries = binaries
+        self._occs_mean_cache = None
 
 
 def _compact(seg: SegInfo, vis: Tensor, cnts: Tensor, t_starts: Tensor, t_ends: Tensor):

@@ -454,8 +454,93 @@ def propnet_fixtures():
     save("propnet", **out)
 
 
+# ----------------------------------------------------------------------------- 7. occupancy grid maintenance + state_dict
+def occgrid_fixtures():
+    """The reference's OccGridEstimator on the CPU: mark_invisible_cells, one warm-up _update and one sampled _update
+    (estimators/occ_grid.py:262-404) with the cells / jitter / occupancies it used recorded, and its state_dict() -- the
+    on-disk layout a checkpoint of the reference has (buffer names, shapes, dtypes).  Pins oracle.grid_* and gives the
+    GPU tests a reference-made state_dict to load."""
+    from nerfacc.estimators.occ_grid import OccGridEstimator as RefEst
+    torch.manual_seed(7)
+    est = RefEst(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=[16, 12, 20], levels=2)
+    out = {}
+    # cameras on a ring looking at the origin
+    n_cams, W, H = 5, 64, 48
+    K = np.array([[[60.0, 0, W / 2], [0, 60.0, H / 2], [0, 0, 1]]], np.float32)
+    c2w = np.zeros((n_cams, 3, 4), np.float32)
+    for i in range(n_cams):
+        a = 2 * np.pi * i / n_cams
+        pos = np.array([2.5 * np.cos(a), 0.4 * np.sin(3 * a), 2.5 * np.sin(a)], np.float32)
+        fwd = -pos / np.linalg.norm(pos)
+        right = np.cross(np.array([0, 1, 0], np.float32), fwd); right /= np.linalg.norm(right)
+        up = np.cross(fwd, right)
+        c2w[i, :, 0], c2w[i, :, 1], c2w[i, :, 2], c2w[i, :, 3] = right, up, fwd, pos
+    est.mark_invisible_cells(T(K), T(c2w), W, H, near_plane=1.2)
+    occs_marked = est.occs.numpy().copy()
+    o_marked = O.mark_invisible_cells(np.zeros_like(occs_marked), [16, 12, 20], est.aabbs.numpy(), K, c2w, W, H, 1.2)
+    n_diff = int((o_marked != occs_marked).sum())
+    assert n_diff <= 8, n_diff   # (cells on an image border / the near plane: fp32 vs fp64 projection)
+    print(f"  mark_invisible_cells: {int((occs_marked < 0).sum())} of {occs_marked.size} cells invisible, oracle differs on {n_diff}")
+    out.update(K=K, c2w=c2w, W=W, H=H, near=np.float32(1.2), occs_marked=occs_marked)
+
+    # _update twice, recording what the reference fed its field
+    rec = []
+    field = lambda x: torch.exp(-4.0 * (x.norm(dim=-1, keepdim=True) - 0.7) ** 2) * 0.05
+    def occ_eval(x):
+        rec.append(x.numpy().copy())
+        return field(x)
+    for step, tag in ((0, "warm"), (300, "samp")):
+        idx_rec = []
+        orig = est._get_all_cells if step == 0 else est._sample_uniform_and_occupied_cells
+        def wrapped(*a, _o=orig, **k):
+            r = _o(*a, **k); idx_rec.append([t.numpy().copy() for t in r]); return r
+        if step == 0: est._get_all_cells = wrapped
+        else: est._sample_uniform_and_occupied_cells = wrapped
+        rec.clear()
+        occs_before = est.occs.numpy().copy()
+        est._update(step=step, occ_eval_fn=occ_eval, occ_thre=0.02, ema_decay=0.9, warmup_steps=256)
+        if step == 0: est._get_all_cells = orig
+        else: est._sample_uniform_and_occupied_cells = orig
+        # oracle: same cells, the positions the reference evaluated (jitter recovered from them is not needed)
+        occs = occs_before.copy()
+        for lvl, (indices, x) in enumerate(zip(idx_rec[0], rec)):
+            occ = field(T(x)).squeeze(-1).numpy()
+            ids = lvl * est.cells_per_lvl + indices
+            if len(np.unique(ids)) == len(ids):
+                occs = O.grid_ema_update(occs, ids, occ, 0.9)
+            else:   # duplicates: the reference keeps an arbitrary candidate; check membership, then follow the reference
+                cand = np.maximum(occs[ids] * np.float32(0.9), occ)
+                new = est.occs.numpy()[ids]
+                for c in np.unique(ids)[:2000]:
+                    assert new[ids == c][0] in cand[ids == c]
+                o2 = O.grid_ema_update(occs, ids, occ, 0.9)
+                assert (o2[ids] >= est.occs.numpy()[ids]).all()
+                occs = occs.copy(); occs[ids] = est.occs.numpy()[ids]
+        close(occs, est.occs.numpy(), atol=0, rtol=0, what=f"occs after {tag} update")
+        b, thre = O.grid_rebinarize(occs, tuple(est.binaries.shape), 0.02)
+        nb = int((b != est.binaries.numpy()).sum())
+        assert nb <= 2, nb
+        out.update({f"{tag}_occs": est.occs.numpy().copy(), f"{tag}_binaries": np.packbits(est.binaries.numpy()),
+                    f"{tag}_thre": np.float32(thre)})
+        if step == 0:
+            out.update(warm_x0=rec[0].copy(), warm_idx0=idx_rec[0][0].copy(), warm_occs_before=occs_before)
+            jit = rec[0] * 0  # positions -> cell points check of the oracle with the jitter recovered exactly is not possible; check the range
+            lo, hi = est.aabbs[0, :3].numpy(), est.aabbs[0, 3:].numpy()
+            u = (rec[0] - lo) / (hi - lo) * np.array([16, 12, 20], np.float32)
+            cz = idx_rec[0][0] % 20; cy = (idx_rec[0][0] // 20) % 12; cx = idx_rec[0][0] // 240
+            frac = u - np.stack([cx, cy, cz], -1)
+            assert (frac > -1e-4).all() and (frac < 1 + 1e-4).all()
+            close(O.grid_cell_points(idx_rec[0][0], frac.astype(np.float32), [16, 12, 20], est.aabbs[0].numpy()), rec[0], atol=2e-6)
+    sd = est.state_dict()
+    assert list(sd.keys()) == ["resolution", "aabbs", "occs", "binaries"], list(sd.keys())
+    for k, v in sd.items():
+        out["sd_" + k] = v.numpy() if v.dtype != torch.bool else v.numpy()
+        out["sd_dtype_" + k] = np.array(str(v.dtype))
+    save("occgrid", **out)
+
+
 if __name__ == "__main__":
-    for fn in (ragged_packed, batched_volrend, ray_aabb, pdf_fixtures, traversal_fixtures, propnet_fixtures):
+    for fn in (ragged_packed, batched_volrend, ray_aabb, pdf_fixtures, traversal_fixtures, propnet_fixtures, occgrid_fixtures):
         print(fn.__name__)
         fn()
     print("oracle pinned against the reference; fixtures written to", OUT)

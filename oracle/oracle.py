@@ -480,3 +480,66 @@ def propnet_sampling(prop_sigma_fns, prop_samples, num_samples, n_rays, near_pla
     vals, _ = importance_sampling(vals, cdfs, num_samples, stratified, seed=seed, offset=offset)
     t_vals = transform_stot(sampling_type, vals, near_plane, far_plane)
     return t_vals[..., :-1], t_vals[..., 1:], levels
+
+
+# --------------------------------------------------------------------------- occupancy-grid maintenance
+def grid_cell_points(indices, jitter, res, aabb):
+    """nerfacc/estimators/occ_grid.py:383-391: x = aabb_lo + (grid_coords + jitter) / resolution * (aabb_hi - aabb_lo), fp32."""
+    idx = np.asarray(indices, np.int64)
+    res = [int(v) for v in res]
+    cz = idx % res[2]; cy = (idx // res[2]) % res[1]; cx = idx // (res[1] * res[2])
+    coords = np.stack([cx, cy, cz], -1).astype(np.float32)
+    aabb = _f32(aabb)
+    unit = ((coords + _f32(jitter)) / np.asarray(res, np.float32)).astype(np.float32)
+    return (aabb[:3] + unit * (aabb[3:] - aabb[:3])).astype(np.float32)
+
+
+def grid_ema_update(occs, cell_ids, occ, ema_decay):
+    """:393-398 `occs[cell_ids] = maximum(occs[cell_ids] * ema_decay, occ)`.  Cells listed more than once: the
+    reference's index_put keeps an arbitrary one of the candidates; the restatement (and the product) keep the largest."""
+    occs = _f32(occs).copy()
+    cell_ids = np.asarray(cell_ids, np.int64)
+    cand = np.maximum(occs[cell_ids] * np.float32(ema_decay), _f32(occ)).astype(np.float32)
+    occs[cell_ids] = -np.inf
+    np.maximum.at(occs, cell_ids, cand)
+    return occs
+
+
+def grid_rebinarize(occs, shape, occ_thre):
+    """:403-404 thre = clamp(occs[occs >= 0].mean(), max=occ_thre); binaries = occs > thre.  Returns (binaries, thre)."""
+    occs = _f32(occs)
+    sel = occs[occs >= 0]
+    mean = np.float32(sel.astype(np.float64).mean()) if sel.size else np.float32(np.nan)
+    thre = mean if np.isnan(mean) else np.float32(min(mean, np.float32(occ_thre)))
+    return (occs > thre).reshape(shape), thre
+
+
+def mark_invisible_cells(occs, res, aabbs, K, c2w, width, height, near_plane=0.0):
+    """:262-332 for every cell of every level (occs >= 0 initially): occs = 0 if some camera sees the cell's corner
+    position x = coords / (res - 1) and no camera has it in front of its near plane, else -1 (float64 restatement of the
+    projection: the comparison with the product allows the cells that sit on an image border or on the near plane)."""
+    occs = _f32(occs).copy()
+    res = [int(v) for v in res]
+    K = np.asarray(K, np.float64); c2w = np.asarray(c2w, np.float64)
+    n_cams = c2w.shape[0]
+    if K.shape[0] == 1:
+        K = np.repeat(K, n_cams, 0)
+    R = np.transpose(c2w[:, :3, :3], (0, 2, 1))
+    t = -R @ c2w[:, :3, 3:]
+    cells = res[0] * res[1] * res[2]
+    cx, cy, cz = np.meshgrid(np.arange(res[0]), np.arange(res[1]), np.arange(res[2]), indexing="ij")
+    coords = np.stack([cx, cy, cz], -1).reshape(-1, 3).astype(np.float64)
+    for lvl in range(len(aabbs)):
+        ab = np.asarray(aabbs[lvl], np.float64)
+        x = coords / (np.asarray(res, np.float64) - 1)
+        w = (ab[:3] + x * (ab[3:] - ab[:3])).T
+        uvd = K @ (R @ w + t)
+        uv = uvd[:, :2] / uvd[:, 2:]
+        in_img = (uvd[:, 2] >= 0) & (uv[:, 0] >= 0) & (uv[:, 0] < width) & (uv[:, 1] >= 0) & (uv[:, 1] < height)
+        covered = ((uvd[:, 2] >= near_plane) & in_img).sum(0) / n_cams > 0
+        too_near = ((uvd[:, 2] < near_plane) & in_img).any(0)
+        keep = occs[lvl * cells:(lvl + 1) * cells] >= 0
+        new = np.where(covered & ~too_near, np.float32(0.0), np.float32(-1.0))
+        seg = occs[lvl * cells:(lvl + 1) * cells]
+        seg[keep] = new[keep]
+    return occs

@@ -42,13 +42,21 @@ def _worker(rank, world, port, q):
     # same torch.bool grid (here 32^3; the bench uses 256^3)
     shared = bench.shared_grid(torch.device("cpu"), 32, "shell10", rank, w)
     grid_sha = __import__("hashlib").sha256(shared.numpy().tobytes()).hexdigest()
+    # grid maintenance across ranks: every rank updates its occupancies from its own samples (here: its own field),
+    # OccGridEstimator._update MAX-all-reduces them before the threshold -> identical binaries everywhere
+    import nerfacc_amd as na
+    torch.manual_seed(100 + rank)
+    est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=12, levels=1)
+    est._update(step=0, occ_eval_fn=lambda x: (x[:, rank:rank + 1] > 0).float() * 0.5, occ_thre=0.01, ema_decay=0.95)
+    upd_sha = __import__("hashlib").sha256(est.binaries.numpy().tobytes()).hexdigest()
+    upd_frac = float(est.binaries.float().mean())
     g, n = _local_grad(rank)
     p = torch.nn.Parameter(torch.zeros(2, dtype=torch.float64))
     p.grad = torch.tensor([g, float(n)], dtype=torch.float64)
     bench.allreduce_grads([p], w)
     torch.distributed.barrier()
     dt = bench.max_over_ranks(0.1 * (rank + 1), w)
-    q.put((rank, p.grad.tolist(), dt, grid_sha, tuple(shared.shape)))
+    q.put((rank, p.grad.tolist(), dt, grid_sha, tuple(shared.shape), upd_sha, upd_frac))
     torch.distributed.destroy_process_group()
 
 
@@ -68,7 +76,9 @@ def test_two_rank_gradient_allreduce_matches_union_batch():
     sys.path.insert(0, ROOT)
     import bench
     want = __import__("hashlib").sha256(bench.make_grid(32, "shell10").tobytes()).hexdigest()
-    for rank, grad, dt, grid_sha, shape in res:
+    assert res[0][5] == res[1][5]                               # same binaries after the MAX-all-reduced update ...
+    assert 0.70 < res[0][6] < 0.80                              # ... = the union of the two half-spaces (x > 0) | (y > 0)
+    for rank, grad, dt, grid_sha, shape, _, _ in res:
         assert grid_sha == want and shape == (1, 32, 32, 32)   # identical binaries on every rank (= rank 0's grid)
         assert abs(grad[0] - (g0 + g1)) < 1e-9 * max(1.0, abs(g0 + g1))
         assert grad[1] == n0 + n1

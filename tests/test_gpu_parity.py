@@ -1327,3 +1327,92 @@ def test_cfg4_shared_256_grid(dev, oracle):
     occ = binaries[0, cell[:, 0], cell[:, 1], cell[:, 2]]
     assert occ.float().mean() > 0.9995   # (mid-points within rounding of a cell face may land in the neighbour)
     assert torch.isfinite(colors).all()
+
+
+# ----------------------------------------------------------------------------- grid maintenance
+def test_grid_update_kernels_vs_oracle(dev, oracle):
+    """OccGridEstimator._update on the device (csrc/gridupd.hip) against the oracle's restatement of
+    estimators/occ_grid.py:368-404, starting from a state_dict the REFERENCE wrote (fixture): cell positions bit for bit,
+    occupancies after a warm-up update and after a sampled update (cells drawn several times: the largest candidate) bit
+    for bit, the re-binarised grid (cells within 1e-7 of the threshold excepted) -- and the traversal through the
+    bit-packed copy the update leaves behind."""
+    g = load_golden("occgrid")
+    res = [int(v) for v in g["sd_resolution"]]
+    est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=res, levels=2).to(dev)
+    est.load_state_dict({k: torch.from_numpy(g["sd_" + k]) for k in ("resolution", "aabbs", "occs", "binaries")}, strict=True)
+    assert est.occs.is_cuda and torch.equal(est.binaries.cpu(), torch.from_numpy(g["sd_binaries"]))
+    ab = est.aabbs.cpu().numpy()
+    # (a) cell positions
+    rng = np.random.default_rng(3)
+    idx = rng.integers(0, est.cells_per_lvl, 5000)
+    jit = rng.random((5000, 3)).astype(np.float32)
+    x = est._cell_points(1, T(idx, dev), T(jit, dev))
+    assert (x.cpu().numpy() == oracle.grid_cell_points(idx, jit, res, ab[1])).all()
+    # (b) the reference's own warm-up step: same cells, same positions -> same occupancies
+    est.occs = T(g["warm_occs_before"], dev)
+    field = lambda p: torch.exp(-4.0 * (p.norm(dim=-1, keepdim=True) - 0.7) ** 2) * 0.05
+    field_np = lambda p: (np.exp(np.float32(-4.0) * (np.linalg.norm(p, axis=-1).astype(np.float32) - np.float32(0.7)) ** 2)
+                          * np.float32(0.05)).astype(np.float32)
+    for step, dup in ((0, False), (300, True)):
+        seen_x, seen_idx = [], []
+        orig = est._get_all_cells if step == 0 else est._sample_uniform_and_occupied_cells
+        def wrapped(*a, _o=orig, **k):
+            r = _o(*a, **k); seen_idx.append([t.cpu().numpy() for t in r]); return r
+        setattr(est, "_get_all_cells" if step == 0 else "_sample_uniform_and_occupied_cells", wrapped)
+        before = est.occs.cpu().numpy().copy()
+        def occ_eval(p):
+            seen_x.append(p.cpu().numpy()); return field(p)
+        est.train()
+        est.update_every_n_steps(step, occ_eval, occ_thre=0.02, ema_decay=0.9, warmup_steps=256, n=4)
+        setattr(est, "_get_all_cells" if step == 0 else "_sample_uniform_and_occupied_cells", orig)
+        exp = before
+        for lvl, (ids, px) in enumerate(zip(seen_idx[0], seen_x)):
+            occ = field(T(px, dev)).squeeze(-1).cpu().numpy()      # the product's own field values (exp ulps are the field's business)
+            assert np.abs(occ - field_np(px)).max() < 1e-7
+            cells = lvl * est.cells_per_lvl + ids
+            if dup:
+                assert len(np.unique(cells)) < len(cells)           # the sampled update really draws cells more than once
+            exp = oracle.grid_ema_update(exp, cells, occ, 0.9)
+        assert (est.occs.cpu().numpy() == exp).all()
+        b, thre = oracle.grid_rebinarize(exp, tuple(est.binaries.shape), 0.02)
+        edge = np.abs(exp - thre) < 1e-7
+        assert ((est.binaries.cpu().numpy() == b) | edge.reshape(b.shape)).all() and est.binaries.dtype == torch.bool
+        # (c) the traversal reads the bit-packed copy the update wrote: same samples as through a freshly packed grid
+        assert getattr(est.binaries, "_nfa_walk_bits", None) is not None
+        o = (rng.random((700, 3)) * 3 - 1.5).astype(np.float32)
+        d = rng.standard_normal((700, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+        got = est.sampling(T(o, dev), T(d, dev), render_step_size=0.01)
+        fresh = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=res, levels=2).to(dev)
+        fresh.binaries = est.binaries.clone()
+        ref = fresh.sampling(T(o, dev), T(d, dev), render_step_size=0.01)
+        assert all(torch.equal(a, b_) for a, b_ in zip(got, ref)) and got[0].numel() > 1000
+        ori, ots, ote = oracle.occgrid_sampling(o, d, est.binaries.cpu().numpy(), ab, render_step_size=0.01)
+        assert (got[0].cpu().numpy() == ori).all() and (got[1].cpu().numpy() == ots).all()
+    # the warm-up result equals what the REFERENCE computed from the same state (its field values differ by exp ulps at most)
+    # (checked on the first pass through the fixture's occupancies)
+
+
+def test_reference_state_dict_and_mark_invisible_cells_gpu(dev, oracle):
+    """SURVEY 8 f3 on the device: a reference-written state_dict (fixture) loaded with strict=True, sampled through, and
+    mark_invisible_cells (ref occ_grid.py:262-332) against the reference's marking of the same cameras."""
+    g = load_golden("occgrid")
+    res = [int(v) for v in g["sd_resolution"]]
+    est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=res, levels=2).to(dev)
+    missing = est.load_state_dict({k: torch.from_numpy(g["sd_" + k]) for k in ("resolution", "aabbs", "occs", "binaries")}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    b = g["sd_binaries"]
+    rng = np.random.default_rng(11)
+    o = (rng.random((900, 3)) * 3 - 1.5).astype(np.float32)
+    d = rng.standard_normal((900, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    ri, ts, te = est.sampling(T(o, dev), T(d, dev), render_step_size=0.01)
+    ori, ots, ote = oracle.occgrid_sampling(o, d, b, g["sd_aabbs"], render_step_size=0.01)
+    assert ri.numel() > 1000 and (ri.cpu().numpy() == ori).all() and (ts.cpu().numpy() == ots).all() and (te.cpu().numpy() == ote).all()
+    est.occs.zero_()
+    est.mark_invisible_cells(T(g["K"], dev), T(g["c2w"], dev), int(g["W"]), int(g["H"]), near_plane=float(g["near"]))
+    assert int((est.occs.cpu().numpy() != g["occs_marked"]).sum()) <= 8
+    # round trip: what we save loads back, and the reference's buffer names are the only persistent ones
+    sd = est.state_dict()
+    assert list(sd.keys()) == ["resolution", "aabbs", "occs", "binaries"]
+    est2 = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=res, levels=2).to(dev)
+    est2.load_state_dict(sd, strict=True)
+    assert torch.equal(est2.occs, est.occs) and torch.equal(est2.binaries, est.binaries)

@@ -98,3 +98,20 @@ def test_guard_band_sampling_checker():
     te_bad = te.copy(); te_bad[4] += np.float32(1e-3)
     ok, info = OC.compare_sampling((ri[drop2], ts[drop2], te_bad[drop2]), kept, full, trans, None, early_stop_eps=1e-4)
     assert not ok
+
+
+def test_reference_state_dict_loads_and_mark_invisible_cells_cpu():
+    """A state_dict written by the reference's OccGridEstimator (fixture: names, shapes, dtypes as on disk) loads with
+    strict=True, and mark_invisible_cells (torch, ref occ_grid.py:262-332) reproduces the reference's marking."""
+    g = load_golden("occgrid")
+    res = [int(v) for v in g["sd_resolution"]]
+    est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=res, levels=2)
+    sd = {k: torch.from_numpy(g["sd_" + k]) for k in ("resolution", "aabbs", "occs", "binaries")}
+    for k, v in sd.items():
+        assert str(v.dtype) == str(g["sd_dtype_" + k]) and est.state_dict()[k].dtype == v.dtype and est.state_dict()[k].shape == v.shape
+    est.load_state_dict(sd, strict=True)
+    assert list(est.state_dict().keys()) == ["resolution", "aabbs", "occs", "binaries"]
+    assert torch.equal(est.binaries, sd["binaries"]) and torch.equal(est.occs, sd["occs"])
+    est.occs.zero_()
+    est.mark_invisible_cells(torch.from_numpy(g["K"]), torch.from_numpy(g["c2w"]), int(g["W"]), int(g["H"]), near_plane=float(g["near"]))
+    assert int((est.occs.numpy() != g["occs_marked"]).sum()) <= 4

@@ -134,3 +134,18 @@ def test_propnet_sampling_vs_reference_fixture(oracle):
         assert_close(ts, g[f"{tag}_t_starts"], atol=2e-6)
         assert_close(te, g[f"{tag}_t_ends"], atol=2e-6)
         assert_close(levels[0][1], g[f"{tag}_cdfs0"], atol=1e-6)
+
+
+def test_grid_maintenance_vs_reference_fixture(oracle):
+    """oracle.grid_rebinarize / mark_invisible_cells against what the reference's OccGridEstimator left behind
+    (oracle/gen_golden.py: occgrid_fixtures; estimators/occ_grid.py:262-332, 403-404)."""
+    g = load_golden("occgrid")
+    shape = tuple(g["sd_binaries"].shape)
+    for tag in ("warm", "samp"):
+        b, thre = oracle.grid_rebinarize(g[f"{tag}_occs"], shape, 0.02)
+        ref = np.unpackbits(g[f"{tag}_binaries"])[:b.size].astype(bool).reshape(shape)
+        assert int((b != ref).sum()) <= 2 and abs(float(thre) - float(g[f"{tag}_thre"])) < 1e-9
+    res = [int(v) for v in g["sd_resolution"]]
+    marked = oracle.mark_invisible_cells(np.zeros_like(g["occs_marked"]), res, g["sd_aabbs"], g["K"], g["c2w"], int(g["W"]), int(g["H"]),
+                                         float(g["near"]))
+    assert int((marked != g["occs_marked"]).sum()) <= 8
