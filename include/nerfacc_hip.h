@@ -339,7 +339,8 @@ int nfa_render_step_accumulate(const float *t_starts, const float *t_ends, const
 
 /* ------------------------------------------------------------------ pdf */
 
-/* ref: cuda/csrc/pdf.cu:359-421 (int overload): S samples + S+1 edges per ray, batched outputs.
+/* ref: cuda/csrc/pdf.cu:359-421 (int overload): S >= 1 samples + S+1 edges per ray, batched outputs (S == 1, which reads
+ * out of bounds upstream (:211), is defined here: the single interval is the ray's whole range).
  * Input segments batched (in_packed_info NULL, n_edges_per_ray each) or packed.
  * stratified: one Philox4x32-10 uniform per ray, subsequence = ray id (pdf.cu:139-144). */
 int nfa_importance_sampling(const float *in_vals, const float *cdfs, const int64_t *in_packed_info,
@@ -356,6 +357,16 @@ int nfa_importance_sampling_t(const float *in_vals, const float *cdfs, const int
                               int64_t n_edges_per_ray, int64_t n_samples, int stratified, uint64_t seed,
                               uint64_t offset, float *out_intervals, float *out_samples, int transform, float t_a,
                               float t_b, float *out_t_starts, float *out_t_ends, nfa_stream_t stream);
+/* The Tensor-count overload (ref: cuda/csrc/pdf.cu:294-355, non-functional upstream: :324 allocates zero samples): ray r is
+ * resampled into sm_packed_info[r].count samples and count + 1 edges (none when count == 0), PACKED at the starts given by
+ * sm_packed_info / iv_packed_info ({exclusive cumsum, count} rows made by the caller: iv count = (count + 1) * (count > 0),
+ * :341-342).  Per-sample arithmetic of the int overload with n = count; a single sample's interval is the ray's whole
+ * range.  iv_is_left / iv_is_right as compute_intervels_kernel sets them (:205-238). */
+int nfa_importance_sampling_packed(const float *in_vals, const float *cdfs, const int64_t *in_packed_info, int64_t n_rays,
+                                   int64_t n_edges_per_ray, const int64_t *sm_packed_info, const int64_t *iv_packed_info,
+                                   int stratified, uint64_t seed, uint64_t offset, float *sm_vals, int64_t *sm_ray_indices,
+                                   float *iv_vals, int64_t *iv_ray_indices, uint8_t *iv_is_left, uint8_t *iv_is_right,
+                                   nfa_stream_t stream);
 /* ref: cuda/csrc/pdf.cu:245-286,426-456. Batched query => ray-relative ids. */
 int nfa_searchsorted(const float *q_vals, const int64_t *q_packed_info, const int64_t *q_ray_indices,
                      int64_t q_n_rays, int64_t q_per_ray, int64_t q_total,

@@ -88,6 +88,7 @@ _SIGS = {
     "nfa_render_step_accumulate": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _vp, _vp],
     "nfa_importance_sampling": [_vp, _vp, _vp, _i64, _i64, _i64, _int, _u64, _u64, _vp, _vp, _vp],
     "nfa_importance_sampling_t": [_vp, _vp, _vp, _i64, _i64, _i64, _int, _u64, _u64, _vp, _vp, _int, _f32, _f32, _vp, _vp, _vp],
+    "nfa_importance_sampling_packed": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "nfa_searchsorted": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp],
     "nfa_cumsum_scratch_bytes": [_i64],
     "nfa_last_error": [],

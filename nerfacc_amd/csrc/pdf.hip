@@ -147,7 +147,10 @@ __global__ __launch_bounds__(256) void importance_sampling_kernel(
             if (gl == 0) t_prev = t_carry;
             const float t_next = __shfl_down(t, 1, L);
             if (ok) {
-                if (sid == 0) {
+                if (S == 1) {  // one sample: its interval is the ray's whole range (the reference reads t_1 out of bounds, pdf.cu:211)
+                    emit_edge(ray, 0, t_min);
+                    emit_edge(ray, 1, t_max);
+                } else if (sid == 0) {
                     const float half_width = (t_next - t) * 0.5f;  // S >= 2 and L >= 2 guarantee lane 1 holds t_1
                     emit_edge(ray, 0, fmaxf(t - half_width, t_min));
                 } else {
@@ -159,6 +162,87 @@ __global__ __launch_bounds__(256) void importance_sampling_kernel(
                 }
             }
             t_carry = __shfl(t, L - 1, L);
+        }
+    }
+}
+
+// Per-ray sample counts (the reference's Tensor overload, pdf.cu:294-355, which allocates zero samples upstream --
+// memalloc_data(false, false) at :324 -- and therefore never worked): ray r is resampled into cnt[r] samples and
+// cnt[r] + 1 edges (0 edges when cnt[r] == 0), written PACKED: sample j of ray r at sm_starts[r] + j, edge j at
+// sm_starts[r] + r' + j with r' = number of non-empty rays before r (= iv_starts[r]).  Same arithmetic per sample as the
+// batched kernel with n = cnt[r]; one 16-lane group per ray, neighbours by shuffle.  is_left / is_right as
+// compute_intervels_kernel (:205-238) sets them: every edge but a ray's last is a left edge, every edge but its first a
+// right edge.  cnt[r] == 1: the single interval is the ray's whole range.
+constexpr int ISP_L = 16;
+__global__ __launch_bounds__(256) void importance_sampling_packed_kernel(
+    const float *__restrict__ in_vals, const float *__restrict__ cdfs, const int64_t *__restrict__ in_packed,
+    int64_t n_rays, int64_t n_edges_per_ray, const int64_t *__restrict__ sm_packed /*[n_rays,2]*/,
+    const int64_t *__restrict__ iv_packed /*[n_rays,2]*/, int stratified, uint64_t seed, uint64_t offset,
+    float *__restrict__ sm_vals, int64_t *__restrict__ sm_ray_indices, float *__restrict__ iv_vals,
+    int64_t *__restrict__ iv_ray_indices, uint8_t *__restrict__ iv_left, uint8_t *__restrict__ iv_right)
+{
+    const int lane = lane_id(), gl = lane & (ISP_L - 1);
+    const int64_t group = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * (64 / ISP_L) + lane / ISP_L;
+    const int64_t n_groups = (((int64_t)gridDim.x * blockDim.x) >> 6) * (64 / ISP_L);
+    const int64_t n_iter = ceil_div64(n_rays, n_groups);
+    for (int64_t it = 0; it < n_iter; ++it) {   // (uniform trip count: the shuffles below need every lane of the wave)
+        const int64_t ray = group + it * n_groups;
+        const bool ray_ok = ray < n_rays;
+        int64_t base = 0, last = 0, S = 0, o_sm = 0, o_iv = 0;
+        if (ray_ok) {
+            if (in_packed) { base = in_packed[2 * ray]; last = base + in_packed[2 * ray + 1] - 1; }
+            else { base = ray * n_edges_per_ray; last = base + n_edges_per_ray - 1; }
+            o_sm = sm_packed[2 * ray]; S = sm_packed[2 * ray + 1];
+            o_iv = iv_packed[2 * ray];
+        }
+        const bool has = ray_ok && S > 0 && last >= base;
+        float u_floor = 0.f, u_step = 0.f, bias = 0.5f, t_min = 0.f, t_max = 0.f;
+        if (has) {
+            u_floor = cdfs[base];
+            u_step = (cdfs[last] - u_floor) / S;
+            if (stratified) bias = philox_uniform(seed, (uint64_t)ray, offset);
+            t_min = in_vals[base]; t_max = in_vals[last];
+        }
+        // the groups of a wave loop together over the longest of their rays
+        int64_t S_max = has ? S : 0;
+#pragma unroll
+        for (int off = ISP_L; off < 64; off <<= 1) S_max = max(S_max, (int64_t)__shfl_xor(S_max, off, 64));
+        float t_carry = 0.f;
+        for (int64_t s0 = 0; s0 < S_max; s0 += ISP_L) {
+            const int64_t sid = s0 + gl;
+            const bool ok = has && sid < S;
+            float t = 0.f;
+            if (ok) {  // pdf.cu:133-166
+                const float u = u_floor + (sid + bias) * u_step;
+                const int64_t p = upper_bound_f(cdfs, base, last, u);
+                const int64_t p0 = clamp64(p - 1, base, last), p1 = clamp64(p, base, last);
+                const float u_lower = cdfs[p0], u_upper = cdfs[p1], t_lower = in_vals[p0], t_upper = in_vals[p1];
+                if (u_upper - u_lower < 1e-10f) t = (t_lower + t_upper) * 0.5f;
+                else {
+                    const float scaling = (t_upper - t_lower) / (u_upper - u_lower);
+                    t = (u - u_lower) * scaling + t_lower;
+                }
+                sm_vals[o_sm + sid] = t;
+                sm_ray_indices[o_sm + sid] = ray;
+            }
+            float t_prev = __shfl_up(t, 1, ISP_L);
+            if (gl == 0) t_prev = t_carry;
+            const float t_next = __shfl_down(t, 1, ISP_L);   // (sid 0 with S >= 2: lane 1 of the same block holds t_1)
+            if (ok) {
+                auto edge = [&](int64_t j, float e) {
+                    iv_vals[o_iv + j] = e;
+                    iv_ray_indices[o_iv + j] = ray;
+                    iv_left[o_iv + j] = j < S ? 1 : 0;
+                    iv_right[o_iv + j] = j > 0 ? 1 : 0;
+                };
+                if (S == 1) { edge(0, t_min); edge(1, t_max); }
+                else if (sid == 0) edge(0, fmaxf(t - (t_next - t) * 0.5f, t_min));
+                else {
+                    edge(sid, (t + t_prev) * 0.5f);
+                    if (sid == S - 1) edge(sid + 1, fminf(t + (t - t_prev) * 0.5f, t_max));
+                }
+            }
+            t_carry = __shfl(t, ISP_L - 1, ISP_L);
         }
     }
 }
@@ -323,7 +407,7 @@ static int launch_importance_sampling(const float *in_vals, const float *cdfs, c
                                       float t_b, float *out_ts, float *out_te, nfa_stream_t stream)
 {
     NFA_REQUIRE(n_rays >= 0, "importance_sampling: negative n_rays");
-    NFA_REQUIRE(n_samples >= 2, "importance_sampling: n_intervals_per_ray must be >= 2 (the reference reads out of bounds for 1, pdf.cu:211)");
+    NFA_REQUIRE(n_samples >= 1, "importance_sampling: n_intervals_per_ray must be >= 1");
     if (n_rays == 0) return NFA_OK;
     NFA_REQUIRE(in_vals && cdfs && out_intervals, "importance_sampling: null pointer");
     NFA_REQUIRE(in_packed_info || n_edges_per_ray >= 1, "importance_sampling: need packed_info or n_edges_per_ray >= 1");
@@ -362,6 +446,26 @@ int nfa_importance_sampling_t(const float *in_vals, const float *cdfs, const int
     NFA_REQUIRE(transform == 1 || transform == 2, "importance_sampling_t: transform must be 1 (uniform) or 2 (lindisp)");
     return launch_importance_sampling(in_vals, cdfs, in_packed_info, n_rays, n_edges_per_ray, n_samples, stratified, seed,
                                       offset, out_intervals, out_samples, transform, t_a, t_b, out_t_starts, out_t_ends, stream);
+}
+
+int nfa_importance_sampling_packed(const float *in_vals, const float *cdfs, const int64_t *in_packed_info, int64_t n_rays,
+                                   int64_t n_edges_per_ray, const int64_t *sm_packed_info, const int64_t *iv_packed_info,
+                                   int stratified, uint64_t seed, uint64_t offset, float *sm_vals, int64_t *sm_ray_indices,
+                                   float *iv_vals, int64_t *iv_ray_indices, uint8_t *iv_is_left, uint8_t *iv_is_right,
+                                   nfa_stream_t stream)
+{
+    NFA_REQUIRE(n_rays >= 0, "importance_sampling_packed: negative n_rays");
+    if (n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(in_vals && cdfs && sm_packed_info && iv_packed_info, "importance_sampling_packed: null pointer");
+    NFA_REQUIRE(in_packed_info || n_edges_per_ray >= 1, "importance_sampling_packed: need packed_info or n_edges_per_ray >= 1");
+    // (output pointers may be NULL only when every count is zero, which the caller knows from the totals)
+    const int64_t n_waves = ceil_div64(n_rays, 64 / ISP_L);
+    const unsigned grid = grid_1d(n_waves * 64, 256, 1 << 16);
+    hipLaunchKernelGGL(importance_sampling_packed_kernel, dim3(grid), dim3(256), 0, as_stream(stream), in_vals, cdfs, in_packed_info,
+                       n_rays, n_edges_per_ray, sm_packed_info, iv_packed_info, stratified, seed, offset, sm_vals, sm_ray_indices,
+                       iv_vals, iv_ray_indices, iv_is_left, iv_is_right);
+    NFA_CHECK_LAUNCH("importance_sampling_packed");
+    return NFA_OK;
 }
 
 int nfa_searchsorted(const float *q_vals, const int64_t *q_packed_info, const int64_t *q_ray_indices, int64_t q_n_rays,

@@ -72,9 +72,13 @@ def importance_sampling(
     reference's tensor expression (estimators/prop_net.py:215-229), operation for operation.  ``need_samples=False``
     skips the sample centres (``None`` is returned in their place).
 
-    With an int count the outputs are batched: ``intervals.vals`` (n_rays, n+1) and
-    ``samples.vals`` (n_rays, n).  A per-ray Tensor count (packed outputs) is not functional in
-    the reference either (pdf.cu:324 allocates zero samples) and is not implemented here.
+    With an int count the outputs are batched: ``intervals.vals`` (n_rays, n+1) and ``samples.vals`` (n_rays, n);
+    ``n == 1`` (out of bounds upstream, pdf.cu:211) yields the ray's whole range as its single interval.  With a per-ray
+    Tensor count the outputs are PACKED as the reference documents (pdf.py:92-105): ``samples.vals`` (all_samples,) with
+    ``packed_info`` / ``ray_indices``, ``intervals.vals`` (all_edges,) with ``packed_info`` / ``ray_indices`` /
+    ``is_left`` / ``is_right``; ray r gets ``n[r]`` samples and ``n[r] + 1`` edges (none for ``n[r] == 0``).  (The
+    reference's own Tensor overload allocates zero samples, pdf.cu:324, and never worked; the semantics here are what its
+    kernels compute once the allocation is right.)
 
     >>> iv = RayIntervals(vals=tensor([0., 1., 0., 1., 2.]), packed_info=tensor([[0, 2], [2, 3]]))
     >>> out_iv, out_sm = importance_sampling(iv, tensor([0., .5, 0., .5, 1.]), 2)
@@ -82,12 +86,11 @@ def importance_sampling(
     (tensor([[0., .5, 1.], [0., 1., 2.]]), tensor([[.25, .75], [.5, 1.5]]))
     """
     if isinstance(n_intervals_per_ray, Tensor):
-        raise NotImplementedError(
-            "importance_sampling with a per-ray Tensor count returns no samples in the reference "
-            "(cuda/csrc/pdf.cu:324,344); pass an int.")
+        assert transform is None, "the fused s -> t mapping is for batched outputs"
+        return _importance_sampling_packed(intervals, cdfs, n_intervals_per_ray, stratified)
     S = int(n_intervals_per_ray)
-    if S < 2:
-        raise ValueError("n_intervals_per_ray must be >= 2 (the reference reads out of bounds for 1, pdf.cu:211)")
+    if S < 1:
+        raise ValueError("n_intervals_per_ray must be >= 1")
     spec = intervals._to_spec()
     vals = spec["vals"].float().contiguous()
     cdfs = cdfs.float().contiguous()
@@ -122,3 +125,41 @@ def importance_sampling(
                int(bool(stratified)), seed, offset, B.ptr(out_iv), B.ptr(out_sm), code, t_a, t_b, B.ptr(t_starts),
                B.ptr(t_ends), B.stream())
     return RayIntervals(vals=out_iv), (RaySamples(vals=out_sm) if need_samples else None), t_starts, t_ends
+
+
+def _importance_sampling_packed(intervals: RayIntervals, cdfs: Tensor, counts: Tensor, stratified: bool):
+    """Per-ray counts -> packed outputs (ref: cuda/csrc/pdf.cu:294-355 as intended; see :func:`importance_sampling`)."""
+    from .grid import _cumsum_packed
+    spec = intervals._to_spec()
+    vals = spec["vals"].float().contiguous()
+    cdfs = cdfs.float().contiguous()
+    assert cdfs.numel() == vals.numel()  # pdf.cu:305
+    dev = B.require_device(vals, cdfs, counts)
+    if vals.dim() > 1:
+        n_rays, per, pi = int(torch.Size(vals.shape[:-1]).numel()), vals.shape[-1], None
+    else:
+        pi = spec["packed_info"]
+        assert pi is not None, "flattened intervals need packed_info"
+        n_rays, per = pi.shape[0], 0
+    counts = counts.reshape(-1).to(torch.int64).contiguous()
+    assert counts.shape[0] == n_rays, "n_intervals_per_ray must have one entry per ray"
+    with torch.cuda.device(dev):
+        totals = torch.empty(2, dtype=torch.int64, device=dev)
+        iv_counts = (counts + 1) * (counts > 0)                     # pdf.cu:341-342
+        sm_packed = _cumsum_packed(counts, totals[0:1])
+        iv_packed = _cumsum_packed(iv_counts, totals[1:2])
+        n_sm, n_iv = (int(v) for v in totals.tolist())             # the one device->host read (data_spec.hpp:91)
+        assert int(counts.min()) >= 0 if n_rays else True, "negative sample count"
+        sm_vals = torch.empty(n_sm, dtype=torch.float32, device=dev)
+        sm_ri = torch.empty(n_sm, dtype=torch.int64, device=dev)
+        iv_vals = torch.empty(n_iv, dtype=torch.float32, device=dev)
+        iv_ri = torch.empty(n_iv, dtype=torch.int64, device=dev)
+        iv_l = torch.empty(n_iv, dtype=torch.bool, device=dev)
+        iv_r = torch.empty(n_iv, dtype=torch.bool, device=dev)
+        seed, offset = _philox_seed_offset(dev) if stratified else (0, 0)
+        if n_sm > 0:
+            B.call("nfa_importance_sampling_packed", B.ptr(vals), B.ptr(cdfs), B.ptr(pi), n_rays, per, B.ptr(sm_packed),
+                   B.ptr(iv_packed), int(bool(stratified)), seed, offset, B.ptr(sm_vals), B.ptr(sm_ri), B.ptr(iv_vals),
+                   B.ptr(iv_ri), B.ptr(iv_l), B.ptr(iv_r), B.stream())
+    return (RayIntervals(vals=iv_vals, packed_info=iv_packed, ray_indices=iv_ri, is_left=iv_l, is_right=iv_r),
+            RaySamples(vals=sm_vals, packed_info=sm_packed, ray_indices=sm_ri))

@@ -543,3 +543,60 @@ def mark_invisible_cells(occs, res, aabbs, K, c2w, width, height, near_plane=0.0
         seg = occs[lvl * cells:(lvl + 1) * cells]
         seg[keep] = new[keep]
     return occs
+
+
+# --------------------------------------------------------------------------- packed (per-ray count) resampling, packed loss
+def importance_sampling_packed(vals, cdfs, counts, packed_info=None):
+    """The Tensor-count overload of importance_sampling as its kernels define it (cuda/csrc/pdf.cu:98-241 with
+    samples.chunk_cnts = counts; the host code at :324 allocates nothing upstream): ray r -> counts[r] samples and
+    counts[r] + 1 edges, packed.  A single sample's interval is the ray's whole range (our definition; :211 reads out of
+    bounds).  Returns dicts like traverse_grids' (vals, packed_info, ray_indices[, is_left, is_right])."""
+    vals, cdfs = _f32(vals), _f32(cdfs)
+    counts = np.asarray(counts, np.int64).reshape(-1)
+    R = counts.shape[0]
+    if packed_info is None:
+        v2, c2 = vals.reshape(R, -1), cdfs.reshape(R, -1)
+        rows = [(v2[r], c2[r]) for r in range(R)]
+    else:
+        pi = _i64(packed_info)
+        rows = [(vals[pi[r, 0]:pi[r, 0] + pi[r, 1]], cdfs[pi[r, 0]:pi[r, 0] + pi[r, 1]]) for r in range(R)]
+    sm_v, sm_r, iv_v, iv_r, iv_l, iv_rt = [], [], [], [], [], []
+    for r in range(R):
+        S = int(counts[r])
+        v, c = rows[r]
+        if S == 0 or v.size == 0:
+            continue
+        if S == 1:
+            u = c[0] + (np.float32(0) + np.float32(0.5)) * ((c[-1] - c[0]) / np.float32(1))   # pdf.cu:133-145, n = 1
+            p = int(np.searchsorted(c[:-1], u, side="right"))
+            p0, p1 = min(max(p - 1, 0), v.size - 1), min(max(p, 0), v.size - 1)
+            if c[p1] - c[p0] < np.float32(1e-10):
+                t = (v[p0] + v[p1]) * np.float32(0.5)
+            else:
+                t = (u - c[p0]) * ((v[p1] - v[p0]) / (c[p1] - c[p0])) + v[p0]
+            sm, iv = np.array([t], np.float32), np.array([v[0], v[-1]], np.float32)
+        else:
+            iv, sm = importance_sampling(v[None], c[None], S)
+            iv, sm = iv[0], sm[0]
+        sm_v.append(sm); sm_r.append(np.full(S, r, np.int64))
+        iv_v.append(iv); iv_r.append(np.full(S + 1, r, np.int64))
+        l = np.ones(S + 1, bool); l[-1] = False
+        rt = np.ones(S + 1, bool); rt[0] = False
+        iv_l.append(l); iv_rt.append(rt)
+    cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
+    has = np.array([rows[r][0].size > 0 for r in range(R)])
+    sm_c = counts * has
+    iv_c = (counts + 1) * (counts > 0) * has
+    return (dict(vals=cat(iv_v, np.float32), ray_indices=cat(iv_r, np.int64), is_left=cat(iv_l, bool), is_right=cat(iv_rt, bool),
+                 packed_info=np.stack([np.cumsum(iv_c) - iv_c, iv_c], -1)),
+            dict(vals=cat(sm_v, np.float32), ray_indices=cat(sm_r, np.int64), packed_info=np.stack([np.cumsum(sm_c) - sm_c, sm_c], -1)))
+
+
+def pdf_loss_packed(q_vals, q_cdfs, q_packed_info, q_is_left, q_is_right, k_vals, k_cdfs, k_packed_info, eps=1e-7):
+    """nerfacc/estimators/prop_net.py:244-256, the flattened branch: w = cdf[is_right] - cdf[is_left] of the query,
+    w_outer from the key CDF at the searchsorted ids, loss = clip(w - w_outer, 0)^2 / (w + eps)."""
+    il, ir = searchsorted(k_vals, q_vals, key_packed_info=k_packed_info, query_packed_info=q_packed_info)
+    q_cdfs, k_cdfs = _f32(q_cdfs), _f32(k_cdfs)
+    w = q_cdfs[q_is_right] - q_cdfs[q_is_left]
+    w_outer = k_cdfs[ir[q_is_right]] - k_cdfs[il[q_is_left]]
+    return (np.clip(w - w_outer, 0, None) ** 2 / (w + np.float32(eps))).astype(np.float32)

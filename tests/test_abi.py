@@ -31,5 +31,5 @@ def test_argument_errors_are_reported():
     a.mode = 7
     rc = lib.nfa_traverse_grids(C.byref(a), None)
     assert rc != 0 and b"mode" in lib.nfa_last_error()
-    rc = lib.nfa_importance_sampling(None, None, None, 4, 3, 1, 0, 0, 0, None, None, None)
-    assert rc != 0 and b">= 2" in lib.nfa_last_error()
+    rc = lib.nfa_importance_sampling(None, None, None, 4, 3, 0, 0, 0, 0, None, None, None)
+    assert rc != 0 and b">= 1" in lib.nfa_last_error()

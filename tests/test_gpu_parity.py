@@ -887,9 +887,7 @@ def test_importance_sampling_and_searchsorted(dev, oracle):
     with pytest.raises(ValueError):
         na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), 4, transform=("log", 1.0, 2.0))
     with pytest.raises(ValueError):
-        na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), 1)
-    with pytest.raises(NotImplementedError):
-        na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), torch.tensor([3] * 33, device=dev))
+        na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), 0)
 
 
 def test_propnet_sampling_and_loss(dev):
@@ -1416,3 +1414,85 @@ def test_reference_state_dict_and_mark_invisible_cells_gpu(dev, oracle):
     est2 = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=res, levels=2).to(dev)
     est2.load_state_dict(sd, strict=True)
     assert torch.equal(est2.occs, est.occs) and torch.equal(est2.binaries, est.binaries)
+
+
+# ----------------------------------------------------------------------------- packed resampling / packed loss
+def test_importance_sampling_per_ray_counts_packed(dev, oracle):
+    """importance_sampling(Tensor n_intervals_per_ray): packed outputs (ref pdf.py:92-105; the reference's host code
+    allocates zero samples, pdf.cu:324) against the oracle's per-ray restatement of the reference's two kernels -- batched
+    and packed inputs, counts of 0 and 1, masks / ray_indices / packed_info -- and against the int overload when every
+    count is the same."""
+    rng = np.random.default_rng(21)
+    R, E = 300, 33
+    v = np.sort(rng.uniform(0, 1, (R, E)).astype(np.float32), -1)
+    c = np.sort(rng.uniform(0, 1, (R, E)).astype(np.float32), -1)
+    counts = rng.integers(0, 41, R)
+    counts[:5] = [0, 1, 2, 40, 1]
+    iv, sm = na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), T(counts, dev))
+    oiv, osm = oracle.importance_sampling_packed(v, c, counts)
+    assert sm.vals.shape == (int(counts.sum()),) and iv.vals.shape == (int(((counts + 1) * (counts > 0)).sum()),)
+    assert_close(sm.vals, osm["vals"], atol=1e-6)
+    assert_close(iv.vals, oiv["vals"], atol=1e-6)
+    assert (sm.ray_indices.cpu().numpy() == osm["ray_indices"]).all() and (iv.ray_indices.cpu().numpy() == oiv["ray_indices"]).all()
+    assert (sm.packed_info.cpu().numpy() == osm["packed_info"]).all() and (iv.packed_info.cpu().numpy() == oiv["packed_info"]).all()
+    assert (iv.is_left.cpu().numpy() == oiv["is_left"]).all() and (iv.is_right.cpu().numpy() == oiv["is_right"]).all()
+    assert iv.is_left.dtype == torch.bool and sm.ray_indices.dtype == torch.int64
+    # flattened input segments of different lengths
+    lens = rng.integers(2, 50, R)
+    pi = np.stack([np.cumsum(lens) - lens, lens], -1)
+    fv = np.concatenate([np.sort(rng.uniform(0, 1, n).astype(np.float32)) for n in lens])
+    fc = np.concatenate([np.sort(rng.uniform(0, 1, n).astype(np.float32)) for n in lens])
+    iv2, sm2 = na.importance_sampling(na.RayIntervals(vals=T(fv, dev), packed_info=T(pi, dev)), T(fc, dev), T(counts, dev))
+    oiv2, osm2 = oracle.importance_sampling_packed(fv, fc, counts, packed_info=pi)
+    assert_close(sm2.vals, osm2["vals"], atol=1e-6); assert_close(iv2.vals, oiv2["vals"], atol=1e-6)
+    assert (iv2.is_left.cpu().numpy() == oiv2["is_left"]).all() and (iv2.packed_info.cpu().numpy() == oiv2["packed_info"]).all()
+    # equal counts == the int overload
+    same = torch.full((R,), 16, dtype=torch.int64, device=dev)
+    iv3, sm3 = na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), same)
+    iv4, sm4 = na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), 16)
+    assert torch.equal(sm3.vals.view(R, 16), sm4.vals) and torch.equal(iv3.vals.view(R, 17), iv4.vals)
+    # one sample per ray, int overload: the ray's whole range (defined here; out of bounds upstream)
+    iv5, sm5 = na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), 1)
+    assert iv5.vals.shape == (R, 2) and torch.equal(iv5.vals[:, 0], T(v, dev)[:, 0]) and torch.equal(iv5.vals[:, 1], T(v, dev)[:, -1])
+    o1iv, o1sm = oracle.importance_sampling_packed(v, c, np.ones(R, np.int64))
+    assert_close(sm5.vals.reshape(-1), o1sm["vals"], atol=1e-6)
+    # stratified draws stay inside their strata; nothing for all-zero counts
+    ivs, sms = na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), T(counts, dev), stratified=True)
+    assert sms.vals.shape == sm.vals.shape and torch.isfinite(sms.vals).all()
+    iv0, sm0 = na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), torch.zeros(R, dtype=torch.int64, device=dev))
+    assert sm0.vals.numel() == 0 and iv0.vals.numel() == 0
+
+
+def test_pdf_loss_packed_branch(dev, oracle):
+    """_pdf_loss with flattened query / key intervals (ref estimators/prop_net.py:244-253, "TODO: not tested" upstream)
+    against the oracle's restatement, and against the batched branch on equal-length chunks."""
+    from nerfacc_amd.estimators.prop_net import _pdf_loss
+    rng = np.random.default_rng(22)
+    R = 120
+    v = np.sort(rng.uniform(0, 1, (R, 40)).astype(np.float32), -1)
+    c = np.sort(rng.uniform(0, 1, (R, 40)).astype(np.float32), -1)
+    c[:, 0] = 0; c[:, -1] = 1
+    key = na.RayIntervals(vals=T(v, dev))
+    q_counts = rng.integers(1, 12, R)
+    q_iv, _ = na.importance_sampling(key, T(c, dev), T(q_counts, dev))
+    # query CDF per ray: 0 .. 1 over its edges (w sums to one per ray); the key mass is scaled down so that the loss bites
+    qpi = q_iv.packed_info.cpu().numpy()
+    q_cdfs_np = np.concatenate([np.sort(np.concatenate([[0.0], rng.uniform(0, 1, n - 2), [1.0]])) for n in qpi[:, 1]]).astype(np.float32)
+    q_cdfs = T(q_cdfs_np, dev)
+    c = (c * np.float32(0.3)).astype(np.float32)
+    k_pi = np.stack([np.arange(R) * 40, np.full(R, 40)], -1)
+    key_flat = na.RayIntervals(vals=T(v.reshape(-1), dev), packed_info=T(k_pi, dev))
+    kc = T(c.reshape(-1), dev).clone().requires_grad_(True)
+    loss = _pdf_loss(q_iv, q_cdfs, key_flat, kc)
+    ref = oracle.pdf_loss_packed(q_iv.vals.cpu().numpy(), q_cdfs.cpu().numpy(), q_iv.packed_info.cpu().numpy(),
+                                 q_iv.is_left.cpu().numpy(), q_iv.is_right.cpu().numpy(), v.reshape(-1), c.reshape(-1), k_pi)
+    assert loss.shape == (int(q_counts.sum()),)
+    assert_close(loss, ref, atol=1e-6, rtol=1e-5)
+    loss.sum().backward()
+    assert kc.grad is not None and torch.isfinite(kc.grad).all() and kc.grad.abs().sum() > 0
+    # equal counts: the packed branch == the batched (fused) branch
+    q2, _ = na.importance_sampling(key, T(c, dev), torch.full((R,), 9, dtype=torch.int64, device=dev))
+    qc2 = torch.sort(torch.rand((R, 10), device=dev))[0]
+    packed = _pdf_loss(q2, qc2.reshape(-1), key_flat, T(c.reshape(-1), dev))
+    batched = _pdf_loss(na.RayIntervals(vals=q2.vals.view(R, 10)), qc2, key, T(c, dev))
+    assert_close(packed.view(R, 9), batched, atol=1e-6, rtol=1e-5)
