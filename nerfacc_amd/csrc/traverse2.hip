@@ -16,7 +16,10 @@
 namespace nfa {
 
 constexpr int EXP_RPW = 32;        // rays per wave batch in the expansion
-constexpr int EXP_QMAX = 1024;     // runs staged per batch (EXP_RPW * max_runs)
+#ifndef NFA_EXP_QMAX
+#define NFA_EXP_QMAX 1024
+#endif
+constexpr int EXP_QMAX = NFA_EXP_QMAX;  // runs staged per batch (EXP_RPW * max_runs)
 #ifndef NFA_EXP_WPB
 #define NFA_EXP_WPB 2  /* measured on cfg 2: 1 wave 176 us, 2 waves 160 us, 4 waves 175 us */
 #endif

@@ -162,6 +162,11 @@ def importance_sampling(ray_segments: RaySegmentsSpec, cdfs: Tensor, n_intervels
     out_iv, out_sm = _pdf.importance_sampling(_intervals_from_spec(ray_segments), cdfs, n_intervels_per_ray, stratified)
     iv, sm = RaySegmentsSpec(), RaySegmentsSpec()
     iv.vals, sm.vals = out_iv.vals, out_sm.vals
+    if out_iv.packed_info is not None:   # Tensor counts: packed outputs (chunk_starts / chunk_cnts, ray_indices, masks)
+        iv.chunk_starts, iv.chunk_cnts = out_iv.packed_info[:, 0].contiguous(), out_iv.packed_info[:, 1].contiguous()
+        sm.chunk_starts, sm.chunk_cnts = out_sm.packed_info[:, 0].contiguous(), out_sm.packed_info[:, 1].contiguous()
+        iv.ray_indices, sm.ray_indices = out_iv.ray_indices, out_sm.ray_indices
+        iv.is_left, iv.is_right = out_iv.is_left, out_iv.is_right
     return [iv, sm]
 
 

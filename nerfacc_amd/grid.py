@@ -259,7 +259,7 @@ def traverse_grids(
     return intervals, samples, terminate
 
 
-MAX_RUNS = 32  # runs kept per ray by the run-length traversal (csrc/traverse2.hip)
+MAX_RUNS = int(os.environ.get("NERFACC_AMD_MAX_RUNS", "32"))  # runs kept per ray by the run-length traversal (csrc/walk.hip)
 
 
 def _get_bricks(binaries: Tensor):
