@@ -112,6 +112,52 @@ class NativeField:
         return self.Fn.apply(self.params, ts, te)
 
 
+class NativePropField:
+    """cfg 3's networks as harness kernels (bench_csrc/field.hip): proposal density p0 exp(-(mid - p1)^2) with a
+    gradient to (p0, p1), fine density 5 exp(-2 (mid - 4)^2).  The torch-lambda version of the same functions is ~40
+    elementwise launches over (R, 64) tensors per step, 4 ms -- more than the whole native path it feeds."""
+
+    def __init__(self, params: torch.Tensor):
+        import ctypes
+        self.params = params
+        lib = ctypes.CDLL(build_field())
+        vp, i64, f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float
+        lib.bf_prop_fwd.argtypes = [vp, vp, i64, vp, f32, f32, f32, vp, vp]
+        lib.bf_prop_bwd.argtypes = [vp, vp, vp, i64, vp, vp, vp]
+        self.lib = lib
+        blocks = int(lib.bf_grid_blocks())
+        st = lambda: torch.cuda.current_stream().cuda_stream
+
+        class Fn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, params, ts, te):
+                ts, te = ts.contiguous(), te.contiguous()
+                out = torch.empty_like(ts)
+                assert lib.bf_prop_fwd(ts.data_ptr(), te.data_ptr(), ts.numel(), params.data_ptr(), 0.0, 0.0, 0.0, out.data_ptr(), st()) == 0
+                ctx.save_for_backward(params, ts, te)
+                return out
+
+            @staticmethod
+            def backward(ctx, g):
+                params, ts, te = ctx.saved_tensors
+                partial = torch.empty((blocks, 2), dtype=torch.float32, device=ts.device)
+                assert lib.bf_prop_bwd(ts.data_ptr(), te.data_ptr(), g.contiguous().data_ptr(), ts.numel(), params.data_ptr(),
+                                       partial.data_ptr(), st()) == 0
+                return partial.sum(0), None, None
+
+        self.Fn = Fn
+
+    def prop(self, ts, te):
+        return self.Fn.apply(self.params, ts, te)
+
+    def fine(self, ts, te):
+        ts, te = ts.contiguous(), te.contiguous()
+        out = torch.empty_like(ts)
+        assert self.lib.bf_prop_fwd(ts.data_ptr(), te.data_ptr(), ts.numel(), None, 5.0, 2.0, 4.0, out.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream) == 0
+        return out
+
+
 class TorchField:
     """The same field with torch elementwise ops (~25 launches, 1.3 ms per step on 32 M samples)."""
 
@@ -410,13 +456,17 @@ def extra_cfg2_variant(dev, args, **kw):
     return out
 
 
-def extra_cfg3(dev, R, steps):
+def extra_cfg3(dev, R, steps, field="native"):
     """BASELINE cfg 3: PropNetEstimator, 2 proposal levels 64 -> 64 -> 16, uniform, fwd + proposal-loss backward."""
     import nerfacc_amd as na
     p = torch.nn.Parameter(torch.tensor([3.0, 4.0], device=dev))
     est = na.PropNetEstimator(optimizer=torch.optim.SGD([p], lr=1e-3)).to(dev)
-    prop = lambda ts, te: torch.exp(-((ts + te) * 0.5 - p[1]) ** 2) * p[0]          # proposal density, 2 parameters
-    fine = lambda ts, te: torch.exp(-((ts + te) * 0.5 - 4.0) ** 2 * 2.0) * 5.0
+    if field == "native":
+        fld = NativePropField(p)
+        prop, fine = fld.prop, fld.fine
+    else:
+        prop = lambda ts, te: torch.exp(-((ts + te) * 0.5 - p[1]) ** 2) * p[0]          # proposal density, 2 parameters
+        fine = lambda ts, te: torch.exp(-((ts + te) * 0.5 - 4.0) ** 2 * 2.0) * 5.0
 
     def step():
         ts, te = est.sampling([prop, prop], [64, 64], 16, R, 2.0, 6.0, sampling_type="uniform", stratified=False,
@@ -437,7 +487,8 @@ def extra_cfg3(dev, R, steps):
             e["achieved_GBps"] = ab[k] / (v["ms_per_step"] * 1e-3) / 1e9
             e["frac_of_hbm_peak"] = e["achieved_GBps"] / HBM_PEAK_GBPS
         kernels[k] = e
-    return {"workload": f"cfg3: PropNetEstimator 2 -> 64 -> 64 -> 16, R={R}, uniform, fwd + proposal-loss bwd",
+    return {"workload": f"cfg3: PropNetEstimator 2 -> 64 -> 64 -> 16, R={R}, uniform, fwd + proposal-loss bwd, {field} proposal / fine "
+                        f"density callbacks",
             "ms_per_step": dt * 1e3, "rays_per_s": R / dt, "loss": float(loss),
             "native_ms_per_step": sum(v["ms_per_step"] for v in ks.values()), "kernels": kernels}
 
@@ -815,7 +866,7 @@ def main():
             w.pop("last", None)
             for key, fn in (("cfg2_compacting", lambda: extra_cfg2_variant(dev, args, sigma_scale=16.0)),
                             ("cfg2_random", lambda: extra_cfg2_variant(dev, args, rays="random")),
-                            ("cfg3", lambda: extra_cfg3(dev, 1 << 20, 5)),
+                            ("cfg3", lambda: extra_cfg3(dev, 1 << 20, 5, args.field)),
                             ("cfg5", lambda: extra_cfg5(dev, 1 << 21, 3))):
                 try:
                     out[key] = fn()

@@ -84,9 +84,57 @@ __global__ __launch_bounds__(256) void field_bwd_kernel(const float *__restrict_
     if (threadIdx.x == 0) { partial[2 * blockIdx.x] = sh0[0]; partial[2 * blockIdx.x + 1] = sh1[0]; }
 }
 
+// ---- cfg 3 (PropNetEstimator): proposal density  sigma = p0 exp(-(mid - p1)^2), mid = (ts + te) / 2, two parameters;
+//      fine density 5 exp(-2 (mid - 4)^2) (no parameters).  Same role as the field above: the user's networks, kept cheap.
+__global__ __launch_bounds__(256) void prop_fwd_kernel(const float *__restrict__ ts, const float *__restrict__ te, int64_t n,
+                                                       const float *__restrict__ params, float a, float b, float c, float *__restrict__ sigma)
+{
+    // params != nullptr: sigma = params[0] * exp(-(mid - params[1])^2); else sigma = a * exp(-b (mid - c)^2)
+    const float p0 = params ? params[0] : a, p1 = params ? params[1] : c, k = params ? 1.0f : b;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float u = (ts[i] + te[i]) * 0.5f - p1;
+        sigma[i] = expf(-(u * u) * k) * p0;
+    }
+}
+__global__ __launch_bounds__(256) void prop_bwd_kernel(const float *__restrict__ ts, const float *__restrict__ te,
+                                                       const float *__restrict__ g, int64_t n, const float *__restrict__ params,
+                                                       float *__restrict__ partial /* [gridDim.x, 2] */)
+{
+    const float p0 = params[0], p1 = params[1];
+    float s0 = 0.f, s1 = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float u = (ts[i] + te[i]) * 0.5f - p1;
+        const float e = expf(-(u * u));
+        s0 += g[i] * e;                       // d sigma / d p0
+        s1 += g[i] * (p0 * e * 2.0f * u);     // d sigma / d p1
+    }
+    __shared__ float sh0[256], sh1[256];
+    sh0[threadIdx.x] = s0; sh1[threadIdx.x] = s1;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { sh0[threadIdx.x] += sh0[threadIdx.x + off]; sh1[threadIdx.x] += sh1[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = sh0[0]; partial[2 * blockIdx.x + 1] = sh1[0]; }
+}
+
 }  // namespace
 
 extern "C" {
+
+int bf_prop_fwd(const float *ts, const float *te, int64_t n, const float *params, float a, float b, float c, float *sigma, void *stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(prop_fwd_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, ts, te, n, params, a, b, c, sigma);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int bf_prop_bwd(const float *ts, const float *te, const float *g_sigma, int64_t n, const float *params, float *partial, void *stream)
+{
+    hipLaunchKernelGGL(prop_bwd_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, ts, te, g_sigma, n, params, partial);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 
 int bf_grid_blocks(void) { return 2048; }
 
