@@ -256,9 +256,11 @@ __device__ __forceinline__ void marcher_general(Marcher &s, float thr, int type,
 // flags as integers, the only branches are the run-record store and the loop itself.  A lane that cannot be served
 // (binade end, first march, no stable increment) stops consuming entries; when no lane can go on, those lanes cross
 // together (marcher_cross, or march.h's general stepper) and the loop resumes.
+template <bool HAS_LIMIT>
 __device__ __forceinline__ void marcher_run(Marcher &s, const char *col /* LDS column of this lane */, int32_t cnt, uint32_t ev_span,
-                                            float dt, int32_t limit, const WalkParams &p, const ApproachLds &tb, int64_t tid)
+                                            float dt, int32_t limit_arg, const WalkParams &p, const ApproachLds &tb, int64_t tid)
 {
+    const int32_t limit = HAS_LIMIT ? limit_arg : 0;   // (traverse_steps_limit: the test-mode loop only)
     const float half = dt * 0.5f;
     int32_t k = 0;
     int32_t tried = 0;   // marcher_cross has been run for entry k and the loop declined it again: the general path is next
@@ -300,7 +302,7 @@ __device__ __forceinline__ void marcher_run(Marcher &s, const char *col /* LDS c
             // run records: a new one unless the samples continue the open run (same increment, no gap)
             const int32_t new_run = emit & ((s.continuous & (int32_t)(s.fstep == s.run_inc)) ^ 1);
             if (new_run && s.n_runs < p.max_runs)
-                p.runs[(int64_t)s.n_runs * p.n_rays + tid] =
+                (p.runs + tid)[(int64_t)s.n_runs * p.n_rays] =
                     (unsigned long long)bt | ((unsigned long long)((uint32_t)s.n_samples | ((uint32_t)s.continuous << 31)) << 32);
             s.n_runs += new_run;
             s.n_chains += new_run & (s.continuous ^ 1);
@@ -440,7 +442,7 @@ __device__ __forceinline__ bool walk_stop(uint32_t rem, uint32_t ev_addr)
     return ((rem & WK_GUARD) | (ev_addr & WK_FULL)) != WK_GUARD;
 }
 
-template <bool FUSED>
+template <bool FUSED, bool HAS_LIMIT>
 NFA_WALK_OCC __global__ __launch_bounds__(256) void walk_kernel(const nfa_traverse_args a, const WalkParams p)
 {
     __shared__ __attribute__((aligned(16))) char ev_lds[(WK_EV + 1) * 1024];   // [WK_EV + 1][256] floats
@@ -456,7 +458,7 @@ NFA_WALK_OCC __global__ __launch_bounds__(256) void walk_kernel(const nfa_traver
     const uint32_t lane_off = 4u * threadIdx.x;
     char *const col = ev_lds + lane_off;
     const float dt = a.step_size;
-    const int32_t limit = a.traverse_steps_limit;
+    const int32_t limit = HAS_LIMIT ? a.traverse_steps_limit : 0;
     const uint32_t *__restrict__ bits = p.bits;
     for (int64_t slot_i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; slot_i < a.n_rays;
          slot_i += (int64_t)blockDim.x * gridDim.x) {
@@ -576,7 +578,7 @@ NFA_WALK_OCC __global__ __launch_bounds__(256) void walk_kernel(const nfa_traver
             int32_t cnt = (int32_t)(ev_addr >> 10);
             if (finished && has_open) { cnt += 1; has_open = 0; }
 #ifndef NFA_WALK_NO_PHASE2
-            marcher_run(s, col, cnt, ev_span, dt, limit, p, tb, tid);
+            marcher_run<HAS_LIMIT>(s, col, cnt, ev_span, dt, limit, p, tb, tid);
 #endif
             if (finished || (limit > 0 && s.n_samples >= limit)) break;
             // the open entry moves to slot 0
@@ -659,8 +661,11 @@ int nfa_traverse_runs(const nfa_traverse_args *pa, const uint32_t *bits, int32_t
     else p.approach.n = 0;
     const size_t shmem = 0;  // the lists are static LDS
     const unsigned grid = grid_1d(a.n_rays, 256, 1 << 20);
-    if (fused) hipLaunchKernelGGL((walk_kernel<true>), dim3(grid), dim3(256), shmem, s, a, p);
-    else       hipLaunchKernelGGL((walk_kernel<false>), dim3(grid), dim3(256), shmem, s, a, p);
+    const bool lim = a.traverse_steps_limit > 0;
+    if (fused && !lim)      hipLaunchKernelGGL((walk_kernel<true, false>), dim3(grid), dim3(256), shmem, s, a, p);
+    else if (fused)         hipLaunchKernelGGL((walk_kernel<true, true>), dim3(grid), dim3(256), shmem, s, a, p);
+    else if (!lim)          hipLaunchKernelGGL((walk_kernel<false, false>), dim3(grid), dim3(256), shmem, s, a, p);
+    else                    hipLaunchKernelGGL((walk_kernel<false, true>), dim3(grid), dim3(256), shmem, s, a, p);
     NFA_CHECK_LAUNCH("traverse_runs");
     return NFA_OK;
 }
