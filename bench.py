@@ -652,6 +652,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the second (software-pipelined) timed loop")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary configurations (cfg2 variants, cfg3, cfg5)")
+    ap.add_argument("--only", default="", choices=["", "cfg2_compacting", "cfg2_random", "cfg3", "cfg5"],
+                    help="run ONE secondary configuration alone and print its object (for rocprofv3 passes: profiles/<round>_<cfg>_*)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -669,8 +671,16 @@ def main():
         torch.set_num_threads(max(1, (os.cpu_count() or world) // (2 * world)))
     if args.res <= 0:
         args.res = 128 if world == 1 else 256
+    if args.only:
+        assert world == 1, "--only runs on one GPU"
+        fn = {"cfg2_compacting": lambda: extra_cfg2_variant(dev, args, sigma_scale=16.0),
+              "cfg2_random": lambda: extra_cfg2_variant(dev, args, rays="random"),
+              "cfg3": lambda: extra_cfg3(dev, 1 << 20, max(3, args.steps // 4), args.field),
+              "cfg5": lambda: extra_cfg5(dev, 1 << 21, max(2, args.steps // 6))}[args.only]
+        print(json.dumps({args.only: fn()}))
+        return
 
-    if world > 1:   # cfg 4: one grid for all ranks, broadcast once from rank 0
+    if world > 1 or _group_live():   # cfg 4: one grid for all ranks, broadcast once from rank 0 (also under torchrun with one rank)
         binaries = shared_grid(dev, args.res, args.grid, rank, world)
         w = make_workload(dev, args.rays, args.res, args.grid, args.ray_variant, rank, args.field, binaries=binaries)
     else:

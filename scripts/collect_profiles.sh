@@ -4,13 +4,17 @@
 # with trace domains other than kernel-trace).  Outputs land in gpurun_out/<tag>_*; summarise with
 # scripts/summarize_profiles.py, which writes the files committed under profiles/.
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-pipelined"
+CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-pipelined --no-extras"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- $CMD > $OUT/${TAG}_trace.log 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -- $CMD > $OUT/${TAG}_fetch.log 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -- $CMD > $OUT/${TAG}_write.log 2>&1
+# secondary configurations (bench.py --only): kernel-trace stats each
+for cfg in cfg2_compacting cfg2_random cfg3 cfg5; do
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_${cfg}_trace -- python $R/bench.py --only $cfg --steps 12 > $OUT/${TAG}_${cfg}_trace.log 2>&1
+done
 echo "profiles collected for $TAG"

@@ -60,3 +60,17 @@ json.dump(out, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1
 print(f"wrote profiles/{tag}_kernel_stats.csv and profiles/{tag}_hbm_traffic.json")
 for k, v in sorted(out.items(), key=lambda kv: -(kv[1]["avg_us"] or 0))[:12]:
     print(f"  {v['avg_us']:8.1f} us  {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB  {v['hbm_GBps']:8.1f} GB/s  {k[:70]}")
+
+# secondary configurations: kernel-trace stats only
+for cfg in ("cfg2_compacting", "cfg2_random", "cfg3", "cfg5"):
+    f = glob.glob(os.path.join(src, f"{tag}_{cfg}_trace/*/*_kernel_stats.csv"))
+    if not f:
+        continue
+    rows = list(csv.DictReader(open(f[0])))
+    with open(os.path.join(dst, f"{tag}_{cfg}_kernel_stats.csv"), "w", newline="") as fo:
+        w = csv.writer(fo)
+        w.writerow(["kernel", "calls", "avg_us", "min_us", "max_us", "total_ms", "percent"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], f"{float(r['AverageNs']) / 1e3:.2f}", f"{float(r['MinNs']) / 1e3:.2f}",
+                        f"{float(r['MaxNs']) / 1e3:.2f}", f"{float(r['TotalDurationNs']) / 1e6:.3f}", r["Percentage"]])
+    print(f"wrote profiles/{tag}_{cfg}_kernel_stats.csv")
