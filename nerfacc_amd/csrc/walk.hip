@@ -395,19 +395,18 @@ __device__ __forceinline__ void walk_span_setup(const nfa_traverse_args &a, cons
     sp.widx = widx; sp.flip = flip;
 }
 
-// One cell of the walk: `cur` is the occupancy of the cell the ray is in, `open` the kind of the ray's open list entry.
-// Closes that entry when the occupancy flips, records the cell's exit distance in the open entry's slot, steps the DDA and
-// returns the occupancy of the next cell (loaded from the 1-bit grid copy).
+// One cell of the walk.  (cur_w, cur_idx): the word of the grid copy that holds the occupancy bit of the cell the ray is
+// in, requested when the ray entered the cell; `open`: the kind of the ray's open list entry.  Steps the DDA, requests the
+// next cell's word (next_w, next_idx), and only then looks at the current cell's bit -- the load has had a whole cell's
+// worth of instructions to arrive (at 256^3 and beyond the grid copy no longer sits in L1): closes the open entry when the
+// occupancy flips and records the cell's exit distance in the open entry's slot.  Returns the current cell's occupancy.
 __device__ __forceinline__ int32_t walk_cell(float dx, float dy, float dz, uint32_t mx, uint32_t my, uint32_t mz, uint32_t flip, float &tx,
                                              float &ty, float &tz, uint32_t &rem, uint32_t &widx, uint32_t &ev_addr, float &m_out,
-                                             int32_t cur, int32_t open, const uint32_t *__restrict__ bits, char *ev_lds)
+                                             uint32_t cur_w, uint32_t cur_idx, int32_t open, uint32_t &next_w, uint32_t &next_idx,
+                                             const uint32_t *__restrict__ bits, char *ev_lds)
 {
-    const uint32_t changed = (uint32_t)(cur ^ open);
-    ev_addr += changed << 10;                 // the open entry is complete when the occupancy flips
     const float n = vmin_f32(ty, tz);
     const float m = vmin_f32(tx, n);          // exit distance of this cell (clamped to this_tmax by phase 2)
-    *reinterpret_cast<float *>(ev_lds + ev_addr) = m;
-    m_out = m;
     // single_traversal (include/utils_grid.cuh:116-142): x if tx < ty && tx < tz, else y if ty < tz, else z.
     // The chosen axis' distance IS m, so its update is m + delta.
     const bool s0 = tx < n;
@@ -426,15 +425,20 @@ __device__ __forceinline__ int32_t walk_cell(float dx, float dy, float dz, uint3
     const uint32_t filled = widx | ~M;
     widx = ((filled + (M & 7u)) & M) | (widx & ~M);                            // v_bfi_b32
     const uint32_t idx = widx ^ flip;
+    next_idx = idx;
 #if defined(NFA_WALK_EXP) && NFA_WALK_EXP == 1   /* timing experiment: no load at all */
-    return (int32_t)((idx >> 7) & 1u);
+    next_w = idx >> 2;
 #elif defined(NFA_WALK_EXP) && NFA_WALK_EXP == 2  /* timing experiment: every load hits one 128-byte line */
-    const uint32_t w = bits[(idx >> 5) & 31u];
-    return (int32_t)__builtin_amdgcn_ubfe(w, idx, 1u);
+    next_w = bits[(idx >> 5) & 31u];
 #else
-    const uint32_t w = bits[idx >> 5];
-    return (int32_t)__builtin_amdgcn_ubfe(w, idx, 1u);  // bit (idx & 31)
+    next_w = bits[idx >> 5];
 #endif
+    const int32_t cur = (int32_t)__builtin_amdgcn_ubfe(cur_w, cur_idx, 1u);   // bit (cur_idx & 31)
+    const uint32_t changed = (uint32_t)(cur ^ open);
+    ev_addr += changed << 10;                 // the open entry is complete when the occupancy flips
+    *reinterpret_cast<float *>(ev_lds + ev_addr) = m;
+    m_out = m;
+    return cur;
 }
 // stop when a step counter has run out (a guard bit is gone: the span ends) or the open entry sits in the last slot
 __device__ __forceinline__ bool walk_stop(uint32_t rem, uint32_t ev_addr)
@@ -503,7 +507,8 @@ NFA_WALK_OCC __global__ __launch_bounds__(256) void walk_kernel(const nfa_traver
 
         WalkSpan sp;
         sp.tx = sp.ty = sp.tz = sp.dx = sp.dy = sp.dz = 0.f; sp.mx = sp.my = sp.mz = 0u; sp.rem = 0u; sp.widx = 0u; sp.flip = 0u;
-        int32_t in_span = 0, has_open = 0, open_type = 0, type = 0;
+        int32_t in_span = 0, has_open = 0, open_type = 0;
+        uint32_t w_cur = 0u, i_cur = 0u;   // the word of the grid copy with the current cell's bit, and the bit's index
         uint32_t ev_addr = lane_off;  // byte offset of the open entry's slot: slot << 10 | lane offset
         uint32_t ev_span = 0u;
         float m_last = 0.f;
@@ -549,9 +554,9 @@ NFA_WALK_OCC __global__ __launch_bounds__(256) void walk_kernel(const nfa_traver
                     ev_span |= 1u << kk;
                     walk_span_setup(a, p, o, d, level, this_tmin, this_tmax, sp);
                     const uint32_t idx0 = sp.widx ^ sp.flip;
-                    type = (int32_t)((bits[idx0 >> 5] >> (idx0 & 31u)) & 1u);
-                    ev_span |= (uint32_t)type << (16u + kk);
-                    open_type = type;
+                    w_cur = bits[idx0 >> 5]; i_cur = idx0;
+                    open_type = (int32_t)((w_cur >> (idx0 & 31u)) & 1u);
+                    ev_span |= (uint32_t)open_type << (16u + kk);
                     ev_addr = ((kk + 2u) << 10) | lane_off;
                     has_open = 1;
                     in_span = 1;
@@ -564,10 +569,13 @@ NFA_WALK_OCC __global__ __launch_bounds__(256) void walk_kernel(const nfa_traver
                 uint32_t rem = sp.rem;
                 uint32_t widx = sp.widx;
                 for (;;) {
-                    const int32_t t1 = walk_cell(dx, dy, dz, mx, my, mz, flip, tx, ty, tz, rem, widx, ev_addr, m_last, type, open_type, bits, ev_lds);
-                    if (walk_stop(rem, ev_addr)) { open_type = type; type = t1; break; }
-                    const int32_t t2 = walk_cell(dx, dy, dz, mx, my, mz, flip, tx, ty, tz, rem, widx, ev_addr, m_last, t1, type, bits, ev_lds);
-                    open_type = t1; type = t2;
+                    uint32_t w1, i1, w2, i2;
+                    const int32_t c0 = walk_cell(dx, dy, dz, mx, my, mz, flip, tx, ty, tz, rem, widx, ev_addr, m_last, w_cur, i_cur, open_type,
+                                                 w1, i1, bits, ev_lds);
+                    if (walk_stop(rem, ev_addr)) { open_type = c0; w_cur = w1; i_cur = i1; break; }
+                    const int32_t c1 = walk_cell(dx, dy, dz, mx, my, mz, flip, tx, ty, tz, rem, widx, ev_addr, m_last, w1, i1, c0, w2, i2, bits,
+                                                 ev_lds);
+                    open_type = c1; w_cur = w2; i_cur = i2;
                     if (walk_stop(rem, ev_addr)) break;
                 }
                 sp.tx = tx; sp.ty = ty; sp.tz = tz; sp.rem = rem; sp.widx = widx;
