@@ -395,15 +395,13 @@ __device__ __forceinline__ void walk_span_setup(const nfa_traverse_args &a, cons
     sp.widx = widx; sp.flip = flip;
 }
 
-// One cell of the walk.  (cur_w, cur_idx): the word of the grid copy that holds the occupancy bit of the cell the ray is
-// in, requested when the ray entered the cell; `open`: the kind of the ray's open list entry.  Steps the DDA, requests the
-// next cell's word (next_w, next_idx), and only then looks at the current cell's bit -- the load has had a whole cell's
-// worth of instructions to arrive (at 256^3 and beyond the grid copy no longer sits in L1): closes the open entry when the
-// occupancy flips and records the cell's exit distance in the open entry's slot.  Returns the current cell's occupancy.
-__device__ __forceinline__ int32_t walk_cell(float dx, float dy, float dz, uint32_t mx, uint32_t my, uint32_t mz, uint32_t flip, float &tx,
-                                             float &ty, float &tz, uint32_t &rem, uint32_t &widx, uint32_t &ev_addr, float &m_out,
-                                             uint32_t cur_w, uint32_t cur_idx, int32_t open, uint32_t &next_w, uint32_t &next_idx,
-                                             const uint32_t *__restrict__ bits, char *ev_lds)
+// One cell of the walk.  (w_cur, i_cur): the word of the grid copy that holds the occupancy bit of the cell the ray is in
+// and the bit's index -- requested when the ray entered the cell, one cell's worth of instructions ago; `open`: the kind of
+// the ray's open list entry.  Steps the DDA, looks at the current cell's bit, requests the next cell's word into the same
+// registers, closes the open entry when the occupancy flips and records the cell's exit distance in the open entry's slot.
+__device__ __forceinline__ void walk_cell(float dx, float dy, float dz, uint32_t mx, uint32_t my, uint32_t mz, uint32_t flip, float &tx,
+                                          float &ty, float &tz, uint32_t &rem, uint32_t &widx, uint32_t &ev_addr, float &m_out,
+                                          uint32_t &w_cur, uint32_t &i_cur, int32_t &open, const uint32_t *__restrict__ bits, char *ev_lds)
 {
     const float n = vmin_f32(ty, tz);
     const float m = vmin_f32(tx, n);          // exit distance of this cell (clamped to this_tmax by phase 2)
@@ -424,21 +422,19 @@ __device__ __forceinline__ int32_t walk_cell(float dx, float dy, float dz, uint3
     const uint32_t M = s0 ? mx : (s1 ? my : mz);
     const uint32_t filled = widx | ~M;
     widx = ((filled + (M & 7u)) & M) | (widx & ~M);                            // v_bfi_b32
-    const uint32_t idx = widx ^ flip;
-    next_idx = idx;
+    const uint32_t changed = __builtin_amdgcn_ubfe(w_cur, i_cur, 1u) ^ (uint32_t)open;   // bit (i_cur & 31) of the current cell's word
+    i_cur = widx ^ flip;
 #if defined(NFA_WALK_EXP) && NFA_WALK_EXP == 1   /* timing experiment: no load at all */
-    next_w = idx >> 2;
+    w_cur = i_cur >> 2;
 #elif defined(NFA_WALK_EXP) && NFA_WALK_EXP == 2  /* timing experiment: every load hits one 128-byte line */
-    next_w = bits[(idx >> 5) & 31u];
+    w_cur = bits[(i_cur >> 5) & 31u];
 #else
-    next_w = bits[idx >> 5];
+    w_cur = bits[i_cur >> 5];
 #endif
-    const int32_t cur = (int32_t)__builtin_amdgcn_ubfe(cur_w, cur_idx, 1u);   // bit (cur_idx & 31)
-    const uint32_t changed = (uint32_t)(cur ^ open);
+    open ^= (int32_t)changed;                 // = the current cell's occupancy
     ev_addr += changed << 10;                 // the open entry is complete when the occupancy flips
     *reinterpret_cast<float *>(ev_lds + ev_addr) = m;
     m_out = m;
-    return cur;
 }
 // stop when a step counter has run out (a guard bit is gone: the span ends) or the open entry sits in the last slot
 __device__ __forceinline__ bool walk_stop(uint32_t rem, uint32_t ev_addr)
@@ -561,23 +557,15 @@ NFA_WALK_OCC __global__ __launch_bounds__(256) void walk_kernel(const nfa_traver
                     has_open = 1;
                     in_span = 1;
                 }
-                // the reference's cell loop (grid.cu:184-272) reduced to the DDA; two cells per trip so that the kinds of
-                // the current / previous / next cell rotate through registers without moves
+                // the reference's cell loop (grid.cu:184-272) reduced to the DDA
                 float tx = sp.tx, ty = sp.ty, tz = sp.tz;
                 const float dx = sp.dx, dy = sp.dy, dz = sp.dz;
                 const uint32_t mx = sp.mx, my = sp.my, mz = sp.mz, flip = sp.flip;
                 uint32_t rem = sp.rem;
                 uint32_t widx = sp.widx;
-                for (;;) {
-                    uint32_t w1, i1, w2, i2;
-                    const int32_t c0 = walk_cell(dx, dy, dz, mx, my, mz, flip, tx, ty, tz, rem, widx, ev_addr, m_last, w_cur, i_cur, open_type,
-                                                 w1, i1, bits, ev_lds);
-                    if (walk_stop(rem, ev_addr)) { open_type = c0; w_cur = w1; i_cur = i1; break; }
-                    const int32_t c1 = walk_cell(dx, dy, dz, mx, my, mz, flip, tx, ty, tz, rem, widx, ev_addr, m_last, w1, i1, c0, w2, i2, bits,
-                                                 ev_lds);
-                    open_type = c1; w_cur = w2; i_cur = i2;
-                    if (walk_stop(rem, ev_addr)) break;
-                }
+                do {
+                    walk_cell(dx, dy, dz, mx, my, mz, flip, tx, ty, tz, rem, widx, ev_addr, m_last, w_cur, i_cur, open_type, bits, ev_lds);
+                } while (!walk_stop(rem, ev_addr));
                 sp.tx = tx; sp.ty = ty; sp.tz = tz; sp.rem = rem; sp.widx = widx;
                 if ((rem & WK_GUARD) != WK_GUARD) in_span = 0;
                 else break;  // list full
