@@ -420,8 +420,10 @@ __device__ __forceinline__ void walk_cell(float dx, float dy, float dz, uint32_t
     // them, add the axis' lowest bit, keep the axis' bits of the sum (a carry out of the top bit is dropped: one step
     // outside the grid wraps to a valid cell, which is never used)
     const uint32_t M = s0 ? mx : (s1 ? my : mz);
-    const uint32_t filled = widx | ~M;
-    widx = ((filled + (M & 7u)) & M) | (widx & ~M);                            // v_bfi_b32
+    uint32_t filled;
+    asm("v_bfi_b32 %0, %1, %2, -1" : "=v"(filled) : "v"(M), "v"(widx));       // (M & widx) | ~M
+    filled += M & 7u;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(widx) : "v"(M), "v"(filled), "v"(widx));   // (M & sum) | (~M & widx)
     const uint32_t changed = __builtin_amdgcn_ubfe(w_cur, i_cur, 1u) ^ (uint32_t)open;   // bit (i_cur & 31) of the current cell's word
     i_cur = widx ^ flip;
 #if defined(NFA_WALK_EXP) && NFA_WALK_EXP == 1   /* timing experiment: no load at all */
