@@ -329,15 +329,22 @@ class KernelTimer:
         self.records = []
 
     def install(self):
+        import ctypes
         from nerfacc_amd import _backend as B
         self._orig = B.call
         timer = self
+        # a ~40 us busy-wait kernel in front of every timed call (bench_csrc/field.hip: bf_spin): the host issues the
+        # first event, the call and the second event while the GPU spins, so the event pair brackets the kernel alone and
+        # not the launch latency of a call the GPU was already waiting for
+        spin_lib = ctypes.CDLL(build_field())
+        spin_lib.bf_spin.argtypes = [ctypes.c_longlong, ctypes.c_void_p]
 
         def timed_call(name, *args):
             key = name
             if name == "nfa_traverse_grids":
                 key = "nfa_traverse_grids[mode=%d]" % args[0]._obj.mode
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            spin_lib.bf_spin(4000, torch.cuda.current_stream().cuda_stream)
             e0.record()
             timer._orig(name, *args)
             e1.record()

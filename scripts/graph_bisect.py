@@ -57,6 +57,10 @@ def child(name):
         if name == "pdf_loss_bwd":
             l = _pdf_loss(na.RayIntervals(vals=qv), qc, na.RayIntervals(vals=v), kc)
             return torch.autograd.grad(l.sum(), [kc])[0]
+    if os.environ.get("GB_EAGER_FIRST"):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):

@@ -25,7 +25,7 @@ def one(pattern):
 
 
 def short(name):
-    return name.replace("void ", "").split("(")[0][:110]
+    return name.replace("void ", "").replace("(anonymous namespace)::", "bench_field::").split("(")[0][:110]
 
 
 stats = list(csv.DictReader(open(one(f"{tag}_trace/*/*_kernel_stats.csv"))))
