@@ -163,9 +163,11 @@ int nfa_traverse_runs(const nfa_traverse_args *args, const uint32_t *bits, int32
  * the order.  scratch: 1024 + n_rays bytes. */
 int nfa_bin_rays(const float *rays_o, const float *rays_d, int64_t n_rays, const float *box, int32_t *order,
                  void *scratch, nfa_stream_t stream);
+/* capacity: number of elements the output arrays hold; nothing is written at or beyond it (a caller that allocated the
+ * outputs before the total was known to the host re-runs the expansion if the total turns out larger). */
 int nfa_expand_runs(int64_t n_rays, float step_size, const int32_t *run_cnts, const uint64_t *runs,
                     int32_t max_runs, const int64_t *packed_info /*[n_rays,2] {start, count}*/, float *t_starts,
-                    float *t_ends, float *t_mids, int64_t *ray_indices, nfa_stream_t stream);
+                    float *t_ends, float *t_mids, int64_t *ray_indices, int64_t capacity, nfa_stream_t stream);
 /* ray_indices[k] = r for every k in [packed_info[r].start, packed_info[r].start + packed_info[r].count): the inverse of
  * nfa_pack_info for contiguous, ray-ordered segments (what the traversal produces), written as coalesced 32-byte
  * stores.  Used after nfa_traverse_grids' direct fill pass with sm_ray_indices == NULL, so that the per-ray serial

@@ -144,7 +144,8 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_runs_kernel(int64_t n_ray
                                                           const unsigned long long *__restrict__ runs, int32_t max_runs,
                                                           const longlong2 *__restrict__ packed_info,
                                                           float *__restrict__ t_starts, float *__restrict__ t_ends,
-                                                          float *__restrict__ t_mids, int64_t *__restrict__ ray_indices, int vec, float cone)
+                                                          float *__restrict__ t_mids, int64_t *__restrict__ ray_indices, int vec, float cone,
+                                                          int64_t capacity)
 {
     __shared__ uint32_t s_pos[EXP_WPB][EXP_QMAX];
     __shared__ float s_t0[EXP_WPB][EXP_QMAX];
@@ -169,7 +170,9 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_runs_kernel(int64_t n_ray
         }
         const int64_t W0 = __shfl(s, 0, 64);
         const int last_lane = (int)min((int64_t)EXP_RPW, n_rays - r0) - 1;
-        const int64_t W1 = __shfl(s + n, last_lane, 64);
+        // (capacity: the output arrays may have been allocated before the total was known to the host; nothing is written
+        //  beyond them, the caller re-runs the expansion in that case)
+        const int64_t W1 = min((int64_t)__shfl(s + n, last_lane, 64), capacity);
         int32_t incl = c;
 #pragma unroll
         for (int off = 1; off < EXP_RPW; off <<= 1) {
@@ -545,8 +548,9 @@ int nfa_bin_rays(const float *rays_o, const float *rays_d, int64_t n_rays, const
 
 int nfa_expand_runs(int64_t n_rays, float step_size, const int32_t *run_cnts, const uint64_t *runs, int32_t max_runs,
                     const int64_t *packed_info, float *t_starts, float *t_ends, float *t_mids,
-                    int64_t *ray_indices, nfa_stream_t stream)
+                    int64_t *ray_indices, int64_t capacity, nfa_stream_t stream)
 {
+    NFA_REQUIRE(capacity >= 0, "expand_runs: negative capacity");
     NFA_REQUIRE(n_rays >= 0, "expand_runs: negative n_rays");
     if (n_rays == 0) return NFA_OK;
     NFA_REQUIRE(run_cnts && runs && packed_info && ray_indices && (t_mids || (t_starts && t_ends)),
@@ -559,11 +563,11 @@ int nfa_expand_runs(int64_t n_rays, float step_size, const int32_t *run_cnts, co
     if (t_mids)
         hipLaunchKernelGGL(expand_runs_kernel<EXP_MIDS>, dim3(grid), dim3(64 * EXP_WPB), 0, as_stream(stream), n_rays, step_size, run_cnts,
                            reinterpret_cast<const unsigned long long *>(runs), max_runs,
-                           reinterpret_cast<const longlong2 *>(packed_info), t_starts, t_ends, t_mids, ray_indices, vec, 0.0f);
+                           reinterpret_cast<const longlong2 *>(packed_info), t_starts, t_ends, t_mids, ray_indices, vec, 0.0f, capacity);
     else
         hipLaunchKernelGGL(expand_runs_kernel<EXP_STARTS_ENDS>, dim3(grid), dim3(64 * EXP_WPB), 0, as_stream(stream), n_rays, step_size, run_cnts,
                            reinterpret_cast<const unsigned long long *>(runs), max_runs,
-                           reinterpret_cast<const longlong2 *>(packed_info), t_starts, t_ends, t_mids, ray_indices, vec, 0.0f);
+                           reinterpret_cast<const longlong2 *>(packed_info), t_starts, t_ends, t_mids, ray_indices, vec, 0.0f, capacity);
     NFA_CHECK_LAUNCH("expand_runs");
     return NFA_OK;
 }
@@ -582,7 +586,8 @@ int nfa_expand_cone_runs(int64_t n_rays, float step_size, float cone_angle, cons
     const unsigned grid = grid_1d(ceil_div64(n_rays, EXP_RPW) * 64, 64 * EXP_WPB, 1 << 22);
     hipLaunchKernelGGL(expand_runs_kernel<EXP_CONE>, dim3(grid), dim3(64 * EXP_WPB), 0, as_stream(stream), n_rays, step_size, run_cnts,
                        reinterpret_cast<const unsigned long long *>(runs), max_runs,
-                       reinterpret_cast<const longlong2 *>(packed_info), t_starts, t_ends, nullptr, ray_indices, vec, cone_angle);
+                       reinterpret_cast<const longlong2 *>(packed_info), t_starts, t_ends, nullptr, ray_indices, vec, cone_angle,
+                       (int64_t)1 << 62);
     NFA_CHECK_LAUNCH("expand_cone_runs");
     return NFA_OK;
 }
@@ -596,7 +601,7 @@ int nfa_fill_ray_indices(int64_t n_rays, const int64_t *packed_info, int64_t *ra
     const unsigned grid = grid_1d(ceil_div64(n_rays, EXP_RPW) * 64, 64 * EXP_WPB, 1 << 22);
     hipLaunchKernelGGL(expand_runs_kernel<EXP_RAY_INDICES>, dim3(grid), dim3(64 * EXP_WPB), 0, as_stream(stream), n_rays, 0.0f,
                        nullptr, nullptr, 1, reinterpret_cast<const longlong2 *>(packed_info), nullptr, nullptr, nullptr,
-                       ray_indices, vec, 0.0f);
+                       ray_indices, vec, 0.0f, (int64_t)1 << 62);
     NFA_CHECK_LAUNCH("fill_ray_indices");
     return NFA_OK;
 }

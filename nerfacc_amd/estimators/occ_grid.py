@@ -114,7 +114,8 @@ class OccGridEstimator(AbstractEstimator):
             self._occs_mean_cache = (key, float(self.occs.mean().item()))
         return self._occs_mean_cache[1]
 
-    def _traverse(self, rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified, cone_angle):
+    def _traverse(self, rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified, cone_angle,
+                  speculate=True):
         near_planes, far_planes = self._planes(rays_o, near_plane, far_plane)
         if t_min is not None:
             near_planes = torch.clamp(near_planes, min=t_min)
@@ -126,7 +127,8 @@ class OccGridEstimator(AbstractEstimator):
         if use_bins is None:  # automatic: decided by the coherence the previous batches showed; re-measured now and then
             use_bins = self._walk_stats.get("max_over_mean", 1.0) > 5.0 and rays_o.shape[0] >= 65536  # image order: 1.6-2.5, random rays: ~12
         return _traverse_samples(rays_o, rays_d, self.binaries, self.aabbs, near_planes, far_planes, render_step_size,
-                                 cone_angle, near_hint=near_plane, bin_rays=bool(use_bins), stats_sink=self._walk_stats)
+                                 cone_angle, near_hint=near_plane, bin_rays=bool(use_bins), stats_sink=self._walk_stats,
+                                 speculate=speculate)
 
     def _traversal_key(self, rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified, cone_angle):
         """Identity of everything the geometric half of ``sampling`` reads: tensors by (address, shape, version counter)
@@ -171,8 +173,9 @@ class OccGridEstimator(AbstractEstimator):
         if wait_for_inputs:
             side.wait_stream(torch.cuda.current_stream(rays_o.device))
         with torch.cuda.stream(side):
+            # (on the side stream the size read is off the critical path already: no speculative expansion)
             out = self._traverse(rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified,
-                                 cone_angle)
+                                 cone_angle, speculate=False)
             event = torch.cuda.Event()
             event.record(side)
         key = self._traversal_key(rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified, cone_angle)

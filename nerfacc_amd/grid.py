@@ -209,7 +209,7 @@ def traverse_grids(
             sm_valid = torch.ones(n_sm, dtype=torch.bool, device=dev)
             if n_sm > 0:
                 B.call("nfa_expand_runs", n_rays, float(step_size), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS, B.ptr(sm_packed),
-                       None, None, B.ptr(sm_vals), B.ptr(sm_ri), B.stream())
+                       None, None, B.ptr(sm_vals), B.ptr(sm_ri), n_sm, B.stream())
                 B.call("nfa_expand_intervals", n_rays, float(step_size), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
                        B.ptr(iv_packed), B.ptr(iv_vals), B.ptr(iv_ri), B.ptr(iv_l), B.ptr(iv_r), B.stream())
                 if n_overflow > 0:
@@ -313,13 +313,25 @@ def _side_stream(dev) -> "torch.cuda.Stream":
     return st
 
 
+SPECULATE = os.environ.get("NERFACC_AMD_SPECULATE", "1") != "0"   # 0: read the traversal's total before allocating its outputs
+_SPEC_CAPACITY: dict = {}
+_PINNED: dict = {}
+
+
+def _pinned_meta(dev) -> Tensor:
+    buf = _PINNED.get(dev.index)
+    if buf is None:
+        buf = _PINNED[dev.index] = torch.empty(4, dtype=torch.int64, pin_memory=True)
+    return buf
+
+
 CONE_RUNS = os.environ.get("NERFACC_AMD_CONE_RUNS", "1") != "0"   # 0: the serial count + fill passes (A/B testing)
 
 
 @torch.no_grad()
 def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size, cone_angle,
                       rays_mask=None, traverse_steps_limit=None, t_sorted=None, t_indices=None, hits=None,
-                      return_terminate=False, near_hint=None, bin_rays=False, stats_sink=None):
+                      return_terminate=False, near_hint=None, bin_rays=False, stats_sink=None, speculate=True):
     """Sampler fast path: (ray_indices, t_starts, t_ends, packed_info) straight from the traversal.
 
     Same values as ``intervals.vals[is_left]``, ``intervals.vals[is_right]``,
@@ -380,13 +392,44 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
         else:
             _launch(a)
         packed_info = _cumsum_packed(sm_cnts, meta[0:3], stats=True)
-        n_sm, s_max, s_sum, n_overflow = (int(v) for v in meta.tolist())  # the one device->host read of the traversal
+        # The total is needed on the host (the outputs' shape).  With a capacity remembered from the previous batch of
+        # this shape the constant-step expansion is launched BEFORE the host knows the total: the size travels on a side
+        # stream that waits for the cumsum only, so the host reads it while the expansion runs and the launches that follow
+        # queue up behind it -- no idle GPU between the read and the next kernel.  (A total above the capacity: the
+        # expansion wrote nothing beyond it and is run again into arrays of the right size.)
+        spec_key = (n_rays, dev.index)
+        cap = _SPEC_CAPACITY.get(spec_key, 0) if (SPECULATE and speculate and use_runs) else 0
+        t_starts = t_ends = ray_indices = None
+        if cap > 0:
+            host = _pinned_meta(dev)
+            main = torch.cuda.current_stream()
+            ready = torch.cuda.Event(); ready.record(main)
+            side = _side_stream(dev)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                host.copy_(meta, non_blocking=True)
+                done = torch.cuda.Event(); done.record(side)
+            t_starts = torch.empty(cap, dtype=torch.float32, device=dev)
+            t_ends = torch.empty(cap, dtype=torch.float32, device=dev)
+            ray_indices = torch.empty(cap, dtype=torch.int64, device=dev)
+            B.call("nfa_expand_runs", n_rays, float(step_size), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
+                   B.ptr(packed_info), B.ptr(t_starts), B.ptr(t_ends), None, B.ptr(ray_indices), cap, B.stream())
+            done.synchronize()
+            n_sm, s_max, s_sum, n_overflow = (int(v) for v in host.tolist())
+        else:
+            n_sm, s_max, s_sum, n_overflow = (int(v) for v in meta.tolist())  # the one device->host read of the traversal
+        if SPECULATE and use_runs:
+            _SPEC_CAPACITY[spec_key] = ((int(n_sm * 1.03) + 4096) // 4096) * 4096
         if stats_sink is not None and s_sum > 0:
             # how much longer a wave of 64 neighbouring rays runs than its average ray (1 = perfectly coherent)
             stats_sink["max_over_mean"] = 64.0 * s_max / s_sum
-        t_starts = torch.empty(n_sm, dtype=torch.float32, device=dev)
-        t_ends = torch.empty(n_sm, dtype=torch.float32, device=dev)
-        ray_indices = torch.empty(n_sm, dtype=torch.int64, device=dev)
+        expanded = cap > 0 and n_sm <= cap
+        if expanded:
+            t_starts, t_ends, ray_indices = t_starts[:n_sm], t_ends[:n_sm], ray_indices[:n_sm]
+        else:
+            t_starts = torch.empty(n_sm, dtype=torch.float32, device=dev)
+            t_ends = torch.empty(n_sm, dtype=torch.float32, device=dev)
+            ray_indices = torch.empty(n_sm, dtype=torch.int64, device=dev)
         if n_sm > 0:
             main = torch.cuda.current_stream()
             joined = None
@@ -406,9 +449,9 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
                     _launch(a)
                     joined = torch.cuda.Event()
                     joined.record(side)
-            if use_runs:
+            if use_runs and not expanded:
                 B.call("nfa_expand_runs", n_rays, float(step_size), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
-                       B.ptr(packed_info), B.ptr(t_starts), B.ptr(t_ends), None, B.ptr(ray_indices), B.stream())
+                       B.ptr(packed_info), B.ptr(t_starts), B.ptr(t_ends), None, B.ptr(ray_indices), n_sm, B.stream())
             elif use_cone_runs:
                 B.call("nfa_expand_cone_runs", n_rays, float(step_size), float(cone_angle), B.ptr(run_cnts), B.ptr(runs),
                        MAX_RUNS, B.ptr(packed_info), B.ptr(t_starts), B.ptr(t_ends), B.ptr(ray_indices), B.stream())

@@ -1496,3 +1496,24 @@ def test_pdf_loss_packed_branch(dev, oracle):
     packed = _pdf_loss(q2, qc2.reshape(-1), key_flat, T(c.reshape(-1), dev))
     batched = _pdf_loss(na.RayIntervals(vals=q2.vals.view(R, 10)), qc2, key, T(c, dev))
     assert_close(packed.view(R, 9), batched, atol=1e-6, rtol=1e-5)
+
+
+def test_speculative_expansion_capacity(dev, oracle):
+    """The sampler launches the expansion into arrays sized from the PREVIOUS batch of the same shape before the host
+    has read this batch's total (nerfacc_amd/grid.py): a batch with more samples than that capacity must be expanded
+    again into arrays of the right size, a smaller one returns views -- both bit-identical to the oracle."""
+    rng = np.random.default_rng(31)
+    R, res, step = 3000, 32, 0.01
+    o = (rng.random((R, 3)) * 3 - 1.5).astype(np.float32)
+    d = rng.standard_normal((R, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    ab = np.array([[-1, -1, -1, 1, 1, 1]], np.float32)
+    sizes = []
+    for occ in (0.02, 0.6, 0.1, 0.6, 0.0, 0.3):     # small, much larger (over capacity), smaller (views), ..., empty, again
+        b = rng.random((1, res, res, res)) < occ
+        ri, ts, te, pi = na.grid._traverse_samples(T(o, dev), T(d, dev), T(b, dev), T(ab, dev), torch.zeros(R, device=dev),
+                                                   torch.full((R,), 1e10, device=dev), step, 0.0, near_hint=0.0)
+        ori, ots, ote = oracle.occgrid_sampling(o, d, b, ab, render_step_size=step)
+        assert (ri.cpu().numpy() == ori).all() and (ts.cpu().numpy() == ots).all() and (te.cpu().numpy() == ote).all()
+        assert ri.is_contiguous() and ts.is_contiguous() and int(pi[:, 1].sum()) == ri.numel()
+        sizes.append(ri.numel())
+    assert sizes[1] > 2 * sizes[0] and sizes[2] < sizes[1] and sizes[4] == 0
