@@ -308,10 +308,13 @@ __global__ __launch_bounds__(256) void traverse_kernel(const nfa_traverse_args a
         st.brick_id = -1; st.brick_lo = st.brick_hi = 0u;
         st.n_runs = 0; st.run_len = 0;
 
+        // A ray with a non-finite origin or direction has no geometry: upstream its NaN planes survive fmaxf / fminf as
+        // [near, far] and the ray is sampled all the way to the far plane (1e10 by default).  Here it gets no samples.
+        const bool ray_ok = isfinite(o[0]) && isfinite(o[1]) && isfinite(o[2]) && isfinite(d[0]) && isfinite(d[1]) && isfinite(d[2]);
         if (FUSED) {
             // grid.py:158-162 with one grid: events are (t_min: enter 0), (t_max: leave 0).
             float tmin, tmax;
-            const bool hit = slab_test(o, inv, a.aabbs, a.aabbs + 3, -INFINITY, INFINITY, tmin, tmax);
+            const bool hit = ray_ok && slab_test(o, inv, a.aabbs, a.aabbs + 3, -INFINITY, INFINITY, tmin, tmax);
             if (hit) {
                 const float this_tmin = fmaxf(tmin, near_plane);
                 const float this_tmax = fminf(tmax, far_plane);
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(const nfa_traverse_args a
             const uint8_t *hits = a.hits + tid * G;
             const float *ts = a.t_sorted + tid * 2 * G;
             const int64_t *ti = a.t_indices + tid * 2 * G;
-            for (int32_t i = 0; i < 2 * G - 1; ++i) {  // grid.cu:125-150
+            for (int32_t i = 0; i < (ray_ok ? 2 * G - 1 : 0); ++i) {  // grid.cu:125-150
                 const int64_t idx = ti[i];
                 const bool is_entering = idx < G;
                 int32_t level = (int32_t)(idx % G);

@@ -502,6 +502,12 @@ NFA_WALK_OCC __global__ __launch_bounds__(256) void walk_kernel(const nfa_traver
         }
         const int32_t G = a.n_grids;
         int32_t next_i = 0;  // next entry of the event walk over the sorted intersections (non-fused)
+        // A ray with a non-finite origin or direction has no geometry: upstream its NaN planes survive fmaxf / fminf as
+        // [near, far] and the ray is sampled all the way to the far plane (1e10 by default).  Here it gets no samples.
+        if (!(isfinite(o[0]) && isfinite(o[1]) && isfinite(o[2]) && isfinite(d[0]) && isfinite(d[1]) && isfinite(d[2]))) {
+            f_pending = false;
+            next_i = 2 * G;
+        }
 
         WalkSpan sp;
         sp.tx = sp.ty = sp.tz = sp.dx = sp.dy = sp.dz = 0.f; sp.mx = sp.my = sp.mz = 0u; sp.rem = 0u; sp.widx = 0u; sp.flip = 0u;

@@ -1517,3 +1517,51 @@ def test_speculative_expansion_capacity(dev, oracle):
         assert ri.is_contiguous() and ts.is_contiguous() and int(pi[:, 1].sum()) == ri.numel()
         sizes.append(ri.numel())
     assert sizes[1] > 2 * sizes[0] and sizes[2] < sizes[1] and sizes[4] == 0
+
+
+def test_walk_survives_degenerate_rays(dev, oracle):
+    """Rays the reference would read out of bounds or spin on (NaN / inf / zero directions, origins 1e30 away, zero-length
+    spans, a near plane beyond the far plane): the walk must terminate, touch nothing outside its buffers, give no samples
+    to rays without a valid span -- and leave the well-formed rays of the same batch bit-exact."""
+    rng = np.random.default_rng(41)
+    R, res, step = 2048, 32, 0.01
+    o = (rng.random((R, 3)) * 3 - 1.5).astype(np.float32)
+    d = rng.standard_normal((R, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    good = np.ones(R, bool)
+    bad = rng.choice(R, 400, replace=False)
+    good[bad] = False
+    d[bad[:50]] = np.nan
+    d[bad[50:100], 0] = np.inf
+    d[bad[100:150]] = 0.0
+    o[bad[150:200]] = 1e30
+    o[bad[200:250], 1] = np.nan
+    d[bad[250:300]] = np.array([0.0, 0.0, 1.0], np.float32); o[bad[250:300]] = np.array([1.0, 1.0, -3.0], np.float32)   # along an edge
+    o[bad[300:350]] = -1e-30; d[bad[300:350]] = 1e-30                                                                   # denormal-ish
+    d[bad[350:400]] *= -np.float32(0.0)                                                                                   # signed zeros
+    b = rng.random((2, res, res, res)) < 0.3
+    est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=res, levels=2).to(dev)
+    est.binaries = T(b, dev)
+    ab = est.aabbs.cpu().numpy()
+    ri, ts, te = est.sampling(T(o, dev), T(d, dev), render_step_size=step, far_plane=8.0)
+    torch.cuda.synchronize()
+    assert ri.numel() > 0 and (ri[1:] >= ri[:-1]).all() and ri.min() >= 0 and ri.max() < R
+    assert torch.isfinite(ts).all() and torch.isfinite(te).all() and (te > ts).all()
+    # the well-formed rays are exactly the oracle's
+    ori, ots, ote = oracle.occgrid_sampling(o[good], d[good], b, ab, render_step_size=step, far_plane=8.0)
+    idx = np.flatnonzero(good)
+    keep = np.isin(ri.cpu().numpy(), idx)
+    remap = np.full(R, -1); remap[idx] = np.arange(idx.size)
+    assert (remap[ri.cpu().numpy()[keep]] == ori).all() and (ts.cpu().numpy()[keep] == ots).all() and (te.cpu().numpy()[keep] == ote).all()
+    # rays without any finite geometry get nothing
+    cnt = torch.bincount(ri, minlength=R).cpu().numpy()
+    assert cnt[bad[:50]].sum() == 0 and cnt[bad[50:100]].sum() == 0 and cnt[bad[200:250]].sum() == 0
+    # the same rule on the serial kernels (cone angle) and in the API's traverse_grids
+    ric, tsc, tec = est.sampling(T(o, dev), T(d, dev), render_step_size=step, far_plane=8.0, cone_angle=0.01)
+    cntc = torch.bincount(ric, minlength=R).cpu().numpy()
+    assert cntc[bad[:50]].sum() == 0 and cntc[bad[200:250]].sum() == 0 and torch.isfinite(tsc).all()
+    iv, sm, _ = na.traverse_grids(T(o, dev), T(d, dev), T(b, dev), T(ab, dev), step_size=step,
+                                  far_planes=torch.full((R,), 8.0, device=dev))
+    assert int(sm.packed_info[:, 1][torch.from_numpy(bad[:50]).to(dev)].sum()) == 0
+    # near plane beyond the far plane / zero-length spans
+    r0, t0, t1 = est.sampling(T(o, dev), T(d, dev), render_step_size=step, near_plane=5.0, far_plane=1.0)
+    assert r0.numel() == 0
