@@ -932,6 +932,7 @@ def test_propnet_sampling_vs_oracle(dev, oracle):
         assert np.abs(ts.cpu().numpy() - ots).max() <= 1e-5 * scale and np.abs(te.cpu().numpy() - ote).max() <= 1e-5 * scale, kind
         assert len(est.prop_cache) == len(props) + 1
         for (iv, cdfs), (o_iv, o_cdfs) in zip(est.prop_cache[:-1], levels):
+            cdfs = cdfs.materialize() if hasattr(cdfs, "materialize") else cdfs   # (kept as the transmittance on the device)
             assert np.abs(iv.vals.cpu().numpy() - o_iv).max() <= 1e-5
             assert np.abs(cdfs.detach().cpu().numpy() - o_cdfs).max() <= 1e-5
         assert est.prop_cache[-1][1] is None
@@ -1565,3 +1566,18 @@ def test_walk_survives_degenerate_rays(dev, oracle):
     # near plane beyond the far plane / zero-length spans
     r0, t0, t1 = est.sampling(T(o, dev), T(d, dev), render_step_size=step, near_plane=5.0, far_plane=1.0)
     assert r0.numel() == 0
+
+
+def test_propnet_step_captures_into_a_hipgraph():
+    """the fixed-shape PropNet path (sampling level loop, batched transmittance, proposal loss and their
+    backward) contains no host synchronisation: it captures into a torch.cuda.CUDAGraph (hipGraph) and the replay is
+    bit-identical to the eager step.  Runs in a child process (scripts/graph_bisect.py), as a capture that fails takes its
+    process down with it."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "graph_bisect.py")
+    for piece in ("sampling_loss_grad", "transmittance_fwd_bwd", "pdf_loss_bwd"):
+        r = subprocess.run([sys.executable, script, piece], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, GB_R="8192", GB_EAGER_FIRST="1"))
+        assert r.returncode == 0 and f"OK {piece} True" in r.stdout, (piece, r.returncode, r.stdout[-300:], r.stderr[-300:])
+
