@@ -340,7 +340,8 @@ __device__ __forceinline__ int64_t uniform64(int64_t v)
 template <int DIR, bool PIPE, class Op>
 __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__ packed_info,
                                              const longlong2 *__restrict__ tiles, int64_t n_rays, int64_t tile,
-                                             int32_t *__restrict__ hid /* LDS, SEG_CHUNK ints, wave private */)
+                                             int32_t *__restrict__ hid /* LDS, SEG_CHUNK ints, wave private */,
+                                             float *__restrict__ ray_lds /* LDS, Op::RAY_LDS_FLOATS floats, wave private */)
 {
     constexpr int NCH = Op::NCH;
     const int lane = lane_id();
@@ -349,6 +350,8 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
     const int32_t r_lo = __builtin_amdgcn_readfirstlane((int32_t)t_lo.x), r_hi = __builtin_amdgcn_readfirstlane((int32_t)t_hi.x);
     if (r_lo >= r_hi) return;
     const int32_t n_own = r_hi - r_lo;
+    // every element this wave touches belongs to one of the rays r_lo .. r_hi - 1: an op may stage their per-ray data
+    if constexpr (Op::RAY_LDS_FLOATS > 0) op.tile_begin(r_lo, r_hi, ray_lds);
     const int64_t e_lo = uniform64(t_lo.y), e_hi = uniform64(t_hi.y);  // chunks are contiguous: the last owned ray ends where the next tile begins
 
     // window of packed_info rows, in walk order v = 0..n_own-1: ray(v) = r_lo + v (fwd) / r_hi-1-v (rev)
@@ -530,10 +533,12 @@ __global__ __launch_bounds__(64 * SEG_WAVES_PER_BLOCK, Op::MIN_WAVES_PER_EU) voi
                                                                        int64_t n_rays, int64_t n_tiles)
 {
     __shared__ __attribute__((aligned(16))) int32_t hid_all[SEG_WAVES_PER_BLOCK * SEG_CHUNK];
+    constexpr int RL = Op::RAY_LDS_FLOATS > 0 ? Op::RAY_LDS_FLOATS : 4;
+    __shared__ __attribute__((aligned(16))) float ray_all[SEG_WAVES_PER_BLOCK * RL];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t tile = (int64_t)blockIdx.x * SEG_WAVES_PER_BLOCK + wave;
     if (tile >= n_tiles) return;
-    seg_run_tile<DIR, PIPE>(op, packed_info, tiles, n_rays, tile, hid_all + wave * SEG_CHUNK);
+    seg_run_tile<DIR, PIPE>(op, packed_info, tiles, n_rays, tile, hid_all + wave * SEG_CHUNK, ray_all + wave * RL);
 }
 
 template <int DIR, class Op>
@@ -566,6 +571,7 @@ struct OpBase1 {  // one additive channel
     static constexpr bool NEEDS_RID = false;
     static constexpr bool TOTALS = false;
     static constexpr int MIN_WAVES_PER_EU = 1;  // occupancy floor asked of the register allocator (1 = none)
+    static constexpr int RAY_LDS_FLOATS = 0;    // per-wave LDS floats for per-ray data staged at tile start (tile_begin)
     __device__ __forceinline__ float identity(int) const { return 0.0f; }
     __device__ __forceinline__ float comb(int, float a, float b) const { return a + b; }
     __device__ __forceinline__ void ray_done(int, const float *) const {}
@@ -580,6 +586,7 @@ struct ScanOp {
     static constexpr bool NEEDS_RID = false;
     static constexpr bool TOTALS = false;
     static constexpr int MIN_WAVES_PER_EU = 1;  // occupancy floor asked of the register allocator (1 = none)
+    static constexpr int RAY_LDS_FLOATS = 0;    // per-wave LDS floats for per-ray data staged at tile start (tile_begin)
     struct Raw { F4 x; };
     const float *in;
     float *out;
@@ -683,6 +690,7 @@ struct AlphaFwdOp {
     static constexpr bool NEEDS_RID = false;
     static constexpr bool TOTALS = false;
     static constexpr int MIN_WAVES_PER_EU = 1;  // occupancy floor asked of the register allocator (1 = none)
+    static constexpr int RAY_LDS_FLOATS = 0;    // per-wave LDS floats for per-ray data staged at tile start (tile_begin)
     struct Raw { F4 a, pf; };
     const float *al, *prefix;
     float *w, *tr;
@@ -810,6 +818,7 @@ struct VisibilityOp {
     static constexpr bool NEEDS_RID = false;
     static constexpr bool TOTALS = false;
     static constexpr int MIN_WAVES_PER_EU = 1;  // occupancy floor asked of the register allocator (1 = none)
+    static constexpr int RAY_LDS_FLOATS = 0;    // per-wave LDS floats for per-ray data staged at tile start (tile_begin)
     struct Raw { F4 s, pf, a, b; };
     const float *ts, *te, *val, *prefix;
     float eps, thre;
@@ -932,6 +941,7 @@ struct AccumOp {
     static constexpr bool NEEDS_RID = false;
     static constexpr bool TOTALS = true;
     static constexpr int MIN_WAVES_PER_EU = 1;
+    static constexpr int RAY_LDS_FLOATS = 0;    // per-wave LDS floats for per-ray data staged at tile start (tile_begin)
     struct Raw { F4 w; float v[4][C]; };
     const float *w, *vals;  // vals may be null (C == 1): accumulate w
     int32_t D, d0;
@@ -1074,6 +1084,7 @@ struct RenderAccumOp {
     static constexpr bool NEEDS_RID = false;
     static constexpr bool TOTALS = true;
     static constexpr int MIN_WAVES_PER_EU = 1;
+    static constexpr int RAY_LDS_FLOATS = 0;    // per-wave LDS floats for per-ray data staged at tile start (tile_begin)
     struct Raw { F4 w, a, b; float c[12]; };
     const float *w, *rgb, *ts, *te;
     float *colors, *opac, *depth;
@@ -1317,9 +1328,32 @@ template <bool VEC, bool EXTRA /* gradients arrive at weights / trans / alphas t
 struct RenderFusedBwdOp : OpBase1 {
     static constexpr bool NEEDS_RID = true;
     static constexpr int MIN_WAVES_PER_EU = (NFA_SEG_OCC_HINTS && !EXTRA) ? 5 : 1;  // 98 VGPRs without the hint: two over the 5-wave budget
+    // The per-ray output gradients (colour, opacity, depth: 5 floats per ray) are needed per ELEMENT, after the ray id is
+    // known: as global gathers they were a second, dependent memory latency in every step (12 gather instructions per lane
+    // and step; SQ counters: the pass waits 80 % of its wave-cycles, VALU 36 % busy).  The rays of a tile are consecutive,
+    // so the wave stages their gradients in LDS with coalesced loads at tile start (up to RAY_CAP rays, the rest falls
+    // back to the gathers) and the per-element reads are LDS reads.
+    static constexpr int RAY_CAP = 192;
+    static constexpr int RAY_LDS_FLOATS = 8 * RAY_CAP;   // {g_r, g_g, g_b, g_opacity, g_depth, -, -, -} per ray
     struct Raw { F4 a, b, T, A, gw, gt, ga; float c[12]; };
     const float *ts, *te, *rgb, *tr, *al, *gc, *go, *gd, *gw, *gt, *ga;
     float *gsig, *grgb;
+    const float *g_lds;
+    int32_t g_lo, g_n;
+    __device__ __forceinline__ void tile_begin(int32_t r_lo, int32_t r_hi, float *lds)
+    {
+        g_lds = lds; g_lo = r_lo; g_n = min(r_hi - r_lo, RAY_CAP);
+        __builtin_amdgcn_wave_barrier();
+        for (int32_t i = lane_id(); i < g_n; i += 64) {
+            const int64_t r = (int64_t)r_lo + i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gc) { v.x = gc[3 * r]; v.y = gc[3 * r + 1]; v.z = gc[3 * r + 2]; }
+            if (go) v.w = go[r];
+            *reinterpret_cast<float4 *>(lds + 8 * i) = v;
+            lds[8 * i + 4] = gd ? gd[r] : 0.0f;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     float T[4], A[4], GW[4], GT[4], GA[4], dlt[4], mid[4], q[4], rs[4], c[12], gr[12];
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
@@ -1354,13 +1388,21 @@ struct RenderFusedBwdOp : OpBase1 {
         gr[3 * j] = gr[3 * j + 1] = gr[3 * j + 2] = 0.0f;
         const float wj = T[j] * A[j];
         if (valid) {
+            const uint32_t slot = (uint32_t)(rid - g_lo);
+            float g0, g1, g2, g3, g4;
+            if (slot < (uint32_t)g_n) {   // staged (the usual case)
+                const float4 v = *reinterpret_cast<const float4 *>(g_lds + 8 * slot);
+                g0 = v.x; g1 = v.y; g2 = v.z; g3 = v.w; g4 = g_lds[8 * slot + 4];
+            } else {
+                g0 = gc ? gc[3 * (int64_t)rid] : 0.0f; g1 = gc ? gc[3 * (int64_t)rid + 1] : 0.0f; g2 = gc ? gc[3 * (int64_t)rid + 2] : 0.0f;
+                g3 = go ? go[rid] : 0.0f; g4 = gd ? gd[rid] : 0.0f;
+            }
             if (gc) {
-                const float g0 = gc[3 * (int64_t)rid], g1 = gc[3 * (int64_t)rid + 1], g2 = gc[3 * (int64_t)rid + 2];
                 g += g0 * c[3 * j] + g1 * c[3 * j + 1] + g2 * c[3 * j + 2];
                 gr[3 * j] = g0 * wj; gr[3 * j + 1] = g1 * wj; gr[3 * j + 2] = g2 * wj;
             }
-            if (go) g += go[rid];
-            if (gd) g += gd[rid] * mid[j];
+            if (go) g += g3;
+            if (gd) g += g4 * mid[j];
         }
         GW[j] = g + GW[j];
         q[j] = GW[j] * wj + GT[j] * T[j];
