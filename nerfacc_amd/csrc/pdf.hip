@@ -58,6 +58,13 @@ __device__ __forceinline__ int upper_bound_lds(const float *data, int start, int
     return start;
 }
 
+__device__ __forceinline__ int64_t uniform64_pdf(int64_t v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 constexpr int IS_STAGE_MAX = 512;  // CDF entries a wave may stage in LDS (x 2 arrays x 4 waves = 16 KiB per workgroup)
 
 // L lanes per ray (power of two <= 64); 64 / L rays per wave.
@@ -67,7 +74,7 @@ constexpr int IS_STAGE_MAX = 512;  // CDF entries a wave may stage in LDS (x 2 a
 template <bool STAGED>
 __global__ __launch_bounds__(256) void importance_sampling_kernel(
     const float *__restrict__ in_vals, const float *__restrict__ cdfs, const int64_t *__restrict__ in_packed,
-    int64_t n_rays, int64_t n_edges_per_ray, int64_t S, int L, int stratified, uint64_t seed, uint64_t offset,
+    int64_t n_rays, int64_t n_edges_per_ray, int64_t S, int L, int RB, int stratified, uint64_t seed, uint64_t offset,
     float *__restrict__ out_iv, float *__restrict__ out_sm, int transform, float t_a, float t_b,
     float *__restrict__ out_ts, float *__restrict__ out_te)
 {
@@ -91,7 +98,41 @@ __global__ __launch_bounds__(256) void importance_sampling_kernel(
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     float *lc = s_cdf[threadIdx.x >> 6], *lv = s_val[threadIdx.x >> 6];
-    for (int64_t r0 = wave * rays_per_wave; r0 < n_rays; r0 += n_waves * rays_per_wave) {
+    // A wave owns blocks of RB consecutive rays (RB a multiple of 64 / L, at most 64).  The jitter is one Philox draw per RAY
+    // (ten rounds of four 32-bit multiplies, quarter rate): lane i draws it for ray i of the block once, the groups fetch
+    // it by shuffle -- with one ray per wave (S = 64) every lane would repeat the same 100+ instructions for every ray.
+    // STAGED: the rows of the NEXT group of rays are requested (into registers) before the current group is searched, and
+    // written to LDS when their turn comes: without that every group is one exposed memory latency (load -> LDS -> search
+    // -> store, ~3 us) and the kernel runs at the rate occupancy x group / latency.
+    constexpr int SLOTS = STAGED ? IS_STAGE_MAX / 64 : 1;
+    float pc[SLOTS], pv[SLOTS];
+    auto rows_here = [&](int64_t r0) { return (int)(min((int64_t)rays_per_wave, n_rays - r0) * n_edges_per_ray); };
+    auto prefetch = [&](int64_t r0) {
+        const int64_t blk = r0 * n_edges_per_ray;
+        const int n_h = rows_here(r0);
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k)
+            if (64 * k < n_h) {  // wave-uniform
+                const int f = lane + 64 * k;
+                pc[k] = cdfs[blk + (f < n_h ? f : 0)];
+                pv[k] = in_vals[blk + (f < n_h ? f : 0)];
+            }
+    };
+    int64_t rb = wave * RB;
+    int sub = 0;
+    float lane_bias = 0.5f;
+    if (STAGED && rb < n_rays) prefetch(rb);
+    while (rb < n_rays) {
+        if (sub == 0) {
+            lane_bias = 0.5f;
+            if (stratified && lane < RB && rb + lane < n_rays) lane_bias = philox_uniform(seed, (uint64_t)(rb + lane), offset);
+        }
+        const int64_t r0 = rb + sub;
+        int64_t next_rb = rb;
+        int next_sub = sub + rays_per_wave;
+        if (next_sub >= RB || rb + next_sub >= n_rays) { next_sub = 0; next_rb = rb + n_waves * RB; }
+        const int cur_sub = sub;
+        rb = next_rb; sub = next_sub;
         const int64_t ray = r0 + lane / L;
         const bool ray_ok = ray < n_rays;
         int64_t base = 0, last = 0;
@@ -101,20 +142,25 @@ __global__ __launch_bounds__(256) void importance_sampling_kernel(
         }
         int lbase = 0;  // the ray's first entry in LDS
         if (STAGED) {
-            const int64_t blk0 = r0 * n_edges_per_ray;
-            const int64_t n_here = min((int64_t)rays_per_wave, n_rays - r0) * n_edges_per_ray;
+            const int n_h = rows_here(r0);
             __builtin_amdgcn_wave_barrier();
-            for (int f = lane; f < n_here; f += 64) { lc[f] = cdfs[blk0 + f]; lv[f] = in_vals[blk0 + f]; }
+#pragma unroll
+            for (int k = 0; k < SLOTS; ++k)
+                if (64 * k < n_h) {
+                    const int f = lane + 64 * k;
+                    if (f < n_h) { lc[f] = pc[k]; lv[f] = pv[k]; }
+                }
             __builtin_amdgcn_wave_barrier();
+            if (next_rb < n_rays) prefetch(next_rb + next_sub);
             lbase = (lane / L) * (int)n_edges_per_ray;
         }
         const int llast = lbase + (int)n_edges_per_ray - 1;
-        float u_floor = 0.f, u_step = 0.f, bias = 0.5f, t_min = 0.f, t_max = 0.f;
+        float u_floor = 0.f, u_step = 0.f, t_min = 0.f, t_max = 0.f;
+        const float bias = __shfl(lane_bias, cur_sub + lane / L, 64);
         if (ray_ok) {
             u_floor = STAGED ? lc[lbase] : cdfs[base];
             const float u_ceil = STAGED ? lc[llast] : cdfs[last];
             u_step = (u_ceil - u_floor) / S;
-            if (stratified) bias = philox_uniform(seed, (uint64_t)ray, offset);
             t_min = STAGED ? lv[lbase] : in_vals[base];
             t_max = STAGED ? lv[llast] : in_vals[last];
         }
@@ -162,6 +208,107 @@ __global__ __launch_bounds__(256) void importance_sampling_kernel(
                 }
             }
             t_carry = __shfl(t, L - 1, L);
+        }
+    }
+}
+
+// The batched case that matters (PropNetEstimator: rows of <= 64 samples whose CDF rows fit the LDS stage), written
+// without divergent control flow: the general kernel above spends ~300 instructions per group of rays on exec-mask
+// branches (the search loop, four kinds of edges, 64-bit index arithmetic) and is issue-bound at 2.4 TB/s.  Same
+// arithmetic, same results:
+//   * the upper bound is the same bisection run for a wave-uniform number of rounds with selects (a finished lane idles);
+//   * every lane forms ITS edge k = sample id with selects (first edge / middle edge), the ray's last lane also the edge S;
+//   * the s -> t mapping is applied to the lane's edge and to the next one (a shuffle), so t_starts / t_ends are written as
+//     two plain coalesced rows;
+//   * rows are addressed as a scalar 64-bit base per group plus 32-bit lane offsets.
+template <int LL>
+__global__ __launch_bounds__(256) void importance_sampling_rows_kernel(
+    const float *__restrict__ in_vals, const float *__restrict__ cdfs, int64_t n_rays, int n_edges, int S, int n_rounds, int RB,
+    int stratified, uint64_t seed, uint64_t offset, float *__restrict__ out_iv, float *__restrict__ out_sm, int transform,
+    float t_a, float t_b, float *__restrict__ out_ts, float *__restrict__ out_te)
+{
+    constexpr int RPW = 64 / LL;  // rays per group
+    constexpr int SLOTS = IS_STAGE_MAX / 64;
+    __shared__ float s_cdf[4][IS_STAGE_MAX];
+    __shared__ float s_val[4][IS_STAGE_MAX];
+    const int lane = lane_id();
+    const int gl = lane & (LL - 1), grp = lane / LL;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    float *lc = s_cdf[threadIdx.x >> 6], *lv = s_val[threadIdx.x >> 6];
+    float pc[SLOTS], pv[SLOTS];
+    auto rows_here = [&](int64_t r0) { return (int)min((int64_t)RPW, n_rays - r0) * n_edges; };
+    auto prefetch = [&](int64_t r0) {
+        const float *c = cdfs + r0 * n_edges, *v = in_vals + r0 * n_edges;
+        const int n_h = rows_here(r0);
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k)
+            if (64 * k < n_h) {  // wave-uniform
+                const int f = lane + 64 * k;
+                pc[k] = c[f < n_h ? f : 0];
+                pv[k] = v[f < n_h ? f : 0];
+            }
+    };
+    int64_t rb = uniform64_pdf(wave * RB);
+    int sub = 0;
+    float lane_bias = 0.5f;
+    if (rb < n_rays) prefetch(rb);
+    while (rb < n_rays) {
+        if (sub == 0) {
+            lane_bias = 0.5f;
+            if (stratified && lane < RB && rb + lane < n_rays) lane_bias = philox_uniform(seed, (uint64_t)(rb + lane), offset);
+        }
+        const int64_t r0 = rb + sub;
+        int64_t next_rb = rb;
+        int next_sub = sub + RPW;
+        if (next_sub >= RB || rb + next_sub >= n_rays) { next_sub = 0; next_rb = rb + n_waves * RB; }
+        const float bias = __shfl(lane_bias, sub + grp, 64);
+        rb = next_rb; sub = next_sub;
+        {
+            const int n_h = rows_here(r0);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < SLOTS; ++k)
+                if (64 * k < n_h) {
+                    const int f = lane + 64 * k;
+                    if (f < n_h) { lc[f] = pc[k]; lv[f] = pv[k]; }
+                }
+            __builtin_amdgcn_wave_barrier();
+            if (next_rb < n_rays) prefetch(next_rb + next_sub);
+        }
+        const bool ok = (r0 + grp < n_rays) && gl < S;
+        const int lbase = (r0 + grp < n_rays) ? grp * n_edges : 0, llast = lbase + n_edges - 1;
+        const float u_floor = lc[lbase], u_ceil = lc[llast], t_min = lv[lbase], t_max = lv[llast];
+        const float u_step = (u_ceil - u_floor) / (float)S;
+        const float u = u_floor + ((float)gl + bias) * u_step;       // pdf.cu:133-137
+        int start = lbase, end = llast;                                // upper_bound over [lbase, llast), pdf.cu:43-63
+        for (int it = 0; it < n_rounds; ++it) {
+            const bool act = start < end;
+            const int mid = start + ((end - start) >> 1);
+            const bool right = !(lc[act ? mid : lbase] > u);
+            start = (act && right) ? mid + 1 : start;
+            end = (act && !right) ? mid : end;
+        }
+        const int p0 = min(max(start - 1, lbase), llast), p1 = min(max(start, lbase), llast);
+        const float u_lower = lc[p0], u_upper = lc[p1], t_lower = lv[p0], t_upper = lv[p1];
+        const float du = u_upper - u_lower;
+        const float t = du < 1e-10f ? (t_lower + t_upper) * 0.5f : (u - u_lower) * ((t_upper - t_lower) / du) + t_lower;
+        const int row = grp * S + gl;
+        if (out_sm && ok) (out_sm + r0 * S)[row] = t;
+        // the lane's edge k = gl and, for the ray's last sample, the edge S (pdf.cu:205-239)
+        const float t_prev = __shfl_up(t, 1, LL), t_next = __shfl_down(t, 1, LL);
+        float e = gl == 0 ? fmaxf(t - (t_next - t) * 0.5f, t_min) : (t + t_prev) * 0.5f;
+        float e_last = fminf(t + (t - t_prev) * 0.5f, t_max);
+        if (S == 1) { e = t_min; e_last = t_max; }  // one sample: its interval is the ray's whole range
+        float *iv = out_iv + r0 * (S + 1);
+        if (ok) iv[grp * (S + 1) + gl] = e;
+        if (ok && gl == S - 1) iv[grp * (S + 1) + S] = e_last;
+        if (transform) {
+            auto map = [&](float x) { const float lin = x * t_b + (1.0f - x) * t_a; return transform == 2 ? 1.0f / lin : lin; };
+            const float te0 = map(e);
+            float te1 = __shfl_down(te0, 1, LL);
+            if (gl == S - 1) te1 = map(e_last);
+            if (ok) { (out_ts + r0 * S)[row] = te0; (out_te + r0 * S)[row] = te1; }
         }
     }
 }
@@ -346,6 +493,76 @@ __global__ __launch_bounds__(256) void pdf_loss_fwd_kernel(const float *__restri
     }
 }
 
+// The same pass for rows of at most 64 query intervals whose key rows fit half the stage, in the style of
+// importance_sampling_rows_kernel: one query interval per lane, the NEXT group's key rows and query edges requested before
+// the current group is searched, both bisections run together for a wave-uniform number of rounds with selects.
+template <int LL>
+__global__ __launch_bounds__(256) void pdf_loss_fwd_rows_kernel(const float *__restrict__ q_vals, const float *__restrict__ q_cdfs,
+                                                                const float *__restrict__ k_vals, const float *__restrict__ k_cdfs,
+                                                                int64_t n_rays, int Q1, int K1, int n_rounds, float eps,
+                                                                float *__restrict__ loss, uint32_t *__restrict__ ids)
+{
+    constexpr int RPW = 64 / LL;
+    constexpr int STAGE = PL_STAGE_MAX / 2, SLOTS = STAGE / 64;
+    __shared__ float s_kv[4][STAGE];
+    __shared__ float s_kc[4][STAGE];
+    const int lane = lane_id(), gl = lane & (LL - 1), grp = lane / LL, Q = Q1 - 1;
+    float *kv = s_kv[threadIdx.x >> 6], *kc = s_kc[threadIdx.x >> 6];
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    float pkv[SLOTS], pkc[SLOTS], pq[4];
+    auto rows_here = [&](int64_t r0) { return (int)min((int64_t)RPW, n_rays - r0) * K1; };
+    auto prefetch = [&](int64_t r0) {
+        const float *v = k_vals + r0 * K1, *c = k_cdfs + r0 * K1;
+        const int n_h = rows_here(r0);
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k)
+            if (64 * k < n_h) {  // wave-uniform
+                const int f = lane + 64 * k;
+                pkv[k] = v[f < n_h ? f : 0];
+                pkc[k] = c[f < n_h ? f : 0];
+            }
+        const int qo = (r0 + grp < n_rays && gl < Q) ? grp * Q1 + gl : 0;   // rows of >= 2 edges: qo + 1 is inside the first row
+        const float *qv = q_vals + r0 * Q1, *qc = q_cdfs + r0 * Q1;
+        pq[0] = qv[qo]; pq[1] = qv[qo + 1]; pq[2] = qc[qo]; pq[3] = qc[qo + 1];
+    };
+    int64_t r0 = uniform64_pdf(wave * RPW);
+    if (r0 < n_rays) prefetch(r0);
+    while (r0 < n_rays) {
+        const int64_t r_next = r0 + n_waves * RPW;
+        const int n_h = rows_here(r0);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k)
+            if (64 * k < n_h) {
+                const int f = lane + 64 * k;
+                if (f < n_h) { kv[f] = pkv[k]; kc[f] = pkc[k]; }
+            }
+        const float qa = pq[0], qb = pq[1], w = pq[3] - pq[2];
+        __builtin_amdgcn_wave_barrier();
+        if (r_next < n_rays) prefetch(r_next);
+        const bool ok = (r0 + grp < n_rays) && gl < Q;
+        const int kb = (r0 + grp < n_rays) ? grp * K1 : 0, kl = kb + K1 - 1;
+        int s0 = kb, e0 = kl, s1 = kb, e1 = kl;   // upper_bound(kv, qa), upper_bound(kv, qb) over [kb, kl)
+        for (int it = 0; it < n_rounds; ++it) {
+            const bool a0 = s0 < e0, a1 = s1 < e1;
+            const int m0 = s0 + ((e0 - s0) >> 1), m1 = s1 + ((e1 - s1) >> 1);
+            const bool g0 = !(kv[a0 ? m0 : kb] > qa), g1 = !(kv[a1 ? m1 : kb] > qb);
+            s0 = (a0 && g0) ? m0 + 1 : s0; e0 = (a0 && !g0) ? m0 : e0;
+            s1 = (a1 && g1) ? m1 + 1 : s1; e1 = (a1 && !g1) ? m1 : e1;
+        }
+        const int left = min(max(s0 - 1, kb), kl), right = min(max(s1, kb), kl);
+        const float wo = kc[right] - kc[left];
+        const float d = fmaxf(w - wo, 0.0f);
+        const int o = grp * Q + gl;
+        if (ok) {
+            (loss + r0 * Q)[o] = (d * d) / (w + eps);
+            if (ids) (ids + r0 * Q)[o] = (uint32_t)(left - kb) | ((uint32_t)(right - kb) << 16);
+        }
+        r0 = r_next;
+    }
+}
+
 // Backward from the key indices saved by the forward pass: no searches, no key rows; a ray's key-CDF gradient row is
 // accumulated in LDS by the ray's own lane group and written once.
 __global__ __launch_bounds__(256) void pdf_loss_bwd_kernel(const float *__restrict__ q_cdfs, const float *__restrict__ k_cdfs,
@@ -415,16 +632,35 @@ static int launch_importance_sampling(const float *in_vals, const float *cdfs, c
     int L = 2;
     while (L < 64 && L < n_samples) L <<= 1;
     const int64_t rays_per_wave = 64 / L;
-    const int64_t n_waves = ceil_div64(n_rays, rays_per_wave);
+    // rays per wave block (the Philox draws of a block are shared out over the lanes): 64 when that still leaves >= 4096 waves
+    int RB = (int)rays_per_wave;
+    while (RB < 64 && n_rays / (2 * RB) >= 4096) RB <<= 1;
+    const int64_t n_waves = ceil_div64(n_rays, (int64_t)RB);
     const unsigned grid = grid_1d(n_waves * 64, 256, 1 << 16);
     const bool staged = !in_packed_info && rays_per_wave * n_edges_per_ray <= IS_STAGE_MAX;
-    if (staged)
+    if (staged && n_samples <= 64 && n_edges_per_ray < (1 << 20)) {
+        int n_rounds = 0;
+        while ((1 << n_rounds) <= (int)n_edges_per_ray - 1) ++n_rounds;   // rounds until a range of n_edges - 1 entries is empty
+#define NFA_IS_ROWS(LL)                                                                                                  \
+    hipLaunchKernelGGL(importance_sampling_rows_kernel<LL>, dim3(grid), dim3(256), 0, as_stream(stream), in_vals, cdfs, n_rays, \
+                       (int)n_edges_per_ray, (int)n_samples, n_rounds, RB, stratified, seed, offset, out_intervals, out_samples, \
+                       transform, t_a, t_b, out_ts, out_te)
+        switch (L) {
+            case 2: NFA_IS_ROWS(2); break;
+            case 4: NFA_IS_ROWS(4); break;
+            case 8: NFA_IS_ROWS(8); break;
+            case 16: NFA_IS_ROWS(16); break;
+            case 32: NFA_IS_ROWS(32); break;
+            default: NFA_IS_ROWS(64); break;
+        }
+#undef NFA_IS_ROWS
+    } else if (staged)
         hipLaunchKernelGGL(importance_sampling_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), in_vals, cdfs,
-                           in_packed_info, n_rays, n_edges_per_ray, n_samples, L, stratified, seed, offset, out_intervals,
+                           in_packed_info, n_rays, n_edges_per_ray, n_samples, L, RB, stratified, seed, offset, out_intervals,
                            out_samples, transform, t_a, t_b, out_ts, out_te);
     else
         hipLaunchKernelGGL(importance_sampling_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), in_vals, cdfs,
-                           in_packed_info, n_rays, n_edges_per_ray, n_samples, L, stratified, seed, offset, out_intervals,
+                           in_packed_info, n_rays, n_edges_per_ray, n_samples, L, RB, stratified, seed, offset, out_intervals,
                            out_samples, transform, t_a, t_b, out_ts, out_te);
     NFA_CHECK_LAUNCH("importance_sampling");
     return NFA_OK;
@@ -508,6 +744,24 @@ int nfa_pdf_loss_fwd(const float *q_vals, const float *q_cdfs, const float *k_va
     NFA_REQUIRE(q_vals && q_cdfs && k_vals && k_cdfs && loss, "pdf_loss_fwd: null pointer");
     const int L = pdf_loss_lanes(n_query_edges - 1, n_key_edges, n_query_edges);
     const unsigned grid = grid_1d(ceil_div64(n_rays, 64 / L) * 64, 256, 1 << 16);
+    if (n_query_edges - 1 <= L && (64 / L) * n_key_edges <= PL_STAGE_MAX / 2) {
+        int n_rounds = 0;
+        while ((1 << n_rounds) <= (int)n_key_edges - 1) ++n_rounds;
+#define NFA_PL_ROWS(LL)                                                                                                   \
+    hipLaunchKernelGGL(pdf_loss_fwd_rows_kernel<LL>, dim3(grid), dim3(256), 0, as_stream(stream), q_vals, q_cdfs, k_vals, k_cdfs, \
+                       n_rays, (int)n_query_edges, (int)n_key_edges, n_rounds, eps, loss, key_ids)
+        switch (L) {
+            case 2: NFA_PL_ROWS(2); break;
+            case 4: NFA_PL_ROWS(4); break;
+            case 8: NFA_PL_ROWS(8); break;
+            case 16: NFA_PL_ROWS(16); break;
+            case 32: NFA_PL_ROWS(32); break;
+            default: NFA_PL_ROWS(64); break;
+        }
+#undef NFA_PL_ROWS
+        NFA_CHECK_LAUNCH("pdf_loss_fwd");
+        return NFA_OK;
+    }
     hipLaunchKernelGGL(pdf_loss_fwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), q_vals, q_cdfs, k_vals, k_cdfs,
                        n_rays, (int)n_query_edges, (int)n_key_edges, L, eps, loss, key_ids);
     NFA_CHECK_LAUNCH("pdf_loss_fwd");

@@ -34,7 +34,20 @@ namespace nfa {
 #ifndef NFA_SEG_OCC_HINTS
 #define NFA_SEG_OCC_HINTS 0  /* A/B on one box: 5-6 waves instead of 4-5 for the fused passes is within run-to-run noise */
 #endif
-constexpr int SEG_CHUNK = 256;  // elements per wave step (4 per lane)
+#ifndef NFA_SEG_E
+#define NFA_SEG_E 4
+#endif
+// Elements per lane and step (4 or 8, consecutive).  The cross-lane part of a step (head resolution, 6 DPP steps per scan
+// channel, the window of packed_info rows) costs the same for 4 or 8 elements per lane, so 8 halves it per element; the
+// registers it costs lower the occupancy.  Measured on cfg 2 (fused fwd / bwd / visibility, us, one box): 4 -> 292 / 344 /
+// 139, 8 -> 405 / 518 / 168 (156 / 171 / 101 VGPRs: 3 / 2 / 5 waves per SIMD) -- occupancy is worth more than instructions.
+constexpr int SE = NFA_SEG_E;
+static_assert(SE == 4 || SE == 8, "NFA_SEG_E must be 4 or 8");
+constexpr int SQ = SE / 4;              // 16-byte quads per lane
+constexpr int SEG_CHUNK = 64 * SE;      // elements per wave step
+#ifndef NFA_SEG_PIPE
+#define NFA_SEG_PIPE 0
+#endif
 #ifndef NFA_SEG_WAVES_PER_BLOCK
 #define NFA_SEG_WAVES_PER_BLOCK 4
 #endif
@@ -89,17 +102,18 @@ __global__ __launch_bounds__(256) void seg_build_tiles_kernel(const int64_t *__r
 // (sel4).  A load inside an `if`, or a select right behind it, makes the compiler wait for that one
 // load on the spot, which serialises the 3-7 array loads of a step (one memory latency each) and
 // defeats the one-step-ahead prefetch.
-struct F4 { float v[4]; };
+struct F4 { float v[SE]; };  // one lane's elements of a step (the name predates SE)
 
 // Where a lane stands in the current step.  `c` (step base, multiple of 256) and `safe` are wave-uniform
 // and live in scalar registers; only `off` is per lane, so element addresses are scalar base + 32-bit
 // lane offset and the range checks are 32-bit compares against scalars.
 struct Pos {
     int64_t c;      // first element offset of the step
-    int32_t off;    // 4 * (lane in address order)
-    int32_t safe;   // offset from c of an in-range, 16 B aligned element every lane may read
-    bool valid[4];  // element c + off + j belongs to the tile's element range
-    bool any, all;
+    int32_t off;    // SE * (lane in address order)
+    int32_t safe;   // offset from c of an in-range, 16 B aligned quad every lane may read
+    bool valid[SE]; // element c + off + j belongs to the tile's element range
+    bool any, all;  // over the lane's SE elements
+    bool qany[SQ], qall[SQ];  // per 16-byte quad
     __device__ __forceinline__ int64_t p0() const { return c + off; }
 };
 
@@ -108,41 +122,47 @@ __device__ __forceinline__ void ld4(const float *__restrict__ p, const Pos &q, F
 {
     const float *b = p + q.c;
     if (VEC) {
-        const float4 v = *reinterpret_cast<const float4 *>(b + (q.any ? q.off : q.safe));
-        out.v[0] = v.x; out.v[1] = v.y; out.v[2] = v.z; out.v[3] = v.w;
+#pragma unroll
+        for (int h = 0; h < SQ; ++h) {
+            const float4 v = *reinterpret_cast<const float4 *>(b + (q.qany[h] ? q.off + 4 * h : q.safe));
+            out.v[4 * h] = v.x; out.v[4 * h + 1] = v.y; out.v[4 * h + 2] = v.z; out.v[4 * h + 3] = v.w;
+        }
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) out.v[j] = b[q.valid[j] ? q.off + j : q.safe];
+        for (int j = 0; j < SE; ++j) out.v[j] = b[q.valid[j] ? q.off + j : q.safe];
     }
 }
-__device__ __forceinline__ float sel(const F4 &r, int j, const bool valid[4], float fill) { return valid[j] ? r.v[j] : fill; }
+__device__ __forceinline__ float sel(const F4 &r, int j, const bool valid[SE], float fill) { return valid[j] ? r.v[j] : fill; }
 
 // Full lanes store one 16-byte vector.  The per-element path (a lane straddling a range end) goes
 // through a volatile pointer: otherwise the compiler if-converts both paths into dwordx3 + dword
 // stores for EVERY lane, which halves the store rate.
 template <bool VEC>
-__device__ __forceinline__ void store4(float *__restrict__ p, const Pos &q, const float v[4])
+__device__ __forceinline__ void store4(float *__restrict__ p, const Pos &q, const float v[SE])
 {
     float *b = p + q.c;
-    if (VEC && q.all) {
-        *reinterpret_cast<float4 *>(b + q.off) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-        volatile float *pv = b;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (q.valid[j]) pv[q.off + j] = v[j];
+    for (int h = 0; h < SQ; ++h) {
+        if (VEC && q.qall[h]) {
+            *reinterpret_cast<float4 *>(b + q.off + 4 * h) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+        } else {
+            volatile float *pv = b;
+#pragma unroll
+            for (int j = 4 * h; j < 4 * h + 4; ++j)
+                if (q.valid[j]) pv[q.off + j] = v[j];
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // Wave-level segmented scan primitives (256 elements per step: 4 per lane in scan order k).
 struct StepHeads {
-    int32_t lh[4];        // most recent head ray id over the lane's elements 0..k (-1: none)
+    int32_t lh[SE];       // most recent head ray id over the lane's elements 0..k (-1: none)
     uint32_t acc;         // bit s: at Hillis-Steele step s (offset 2^s) this lane still accumulates
     bool open_prefix;     // no head in any earlier lane of this step: the carry of previous steps applies
     int32_t ph;           // ray id in front of the lane's first element (carry folded in)
-    int32_t rid[4], prev_rid[4];
-    bool is_head[4];
+    int32_t rid[SE], prev_rid[SE];
+    bool is_head[SE];
 };
 
 template <int S>
@@ -154,16 +174,16 @@ __device__ __forceinline__ void heads_step(int32_t &ah, uint32_t &acc)
 }
 
 template <int DIR>
-__device__ __forceinline__ void resolve_heads(const int32_t hj[4], const bool valid[4], int32_t carry_rid, StepHeads &hd)
+__device__ __forceinline__ void resolve_heads(const int32_t hj[SE], const bool valid[SE], int32_t carry_rid, StepHeads &hd)
 {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int j = DIR > 0 ? k : 3 - k;
+    for (int k = 0; k < SE; ++k) {
+        const int j = DIR > 0 ? k : SE - 1 - k;
         const int32_t h = valid[j] ? hj[j] : -1;
         hd.is_head[k] = h >= 0;
         hd.lh[k] = (k == 0 || h >= 0) ? h : hd.lh[k - 1 < 0 ? 0 : k - 1];  // most recent head (ids fall in reverse scans)
     }
-    int32_t ah = hd.lh[3];
+    int32_t ah = hd.lh[SE - 1];
     uint32_t acc = 0;
     heads_step<0>(ah, acc); heads_step<1>(ah, acc); heads_step<2>(ah, acc);
     heads_step<3>(ah, acc); heads_step<4>(ah, acc); heads_step<5>(ah, acc);
@@ -179,7 +199,7 @@ __device__ __forceinline__ void resolve_heads(const int32_t hj[4], const bool va
     hd.ph = ph;
     int32_t pr = ph;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < SE; ++k) {
         hd.prev_rid[k] = pr;
         hd.rid[k] = hd.lh[k] >= 0 ? hd.lh[k] : ph;
         pr = hd.rid[k];
@@ -201,18 +221,18 @@ __device__ __forceinline__ void values_step(const StepHeads &hd, float av[N], FI
 // value of the element before k (in that element's own ray).  `carry` is updated to the state after
 // the step's last element.
 template <int N, class FI, class FC>
-__device__ __forceinline__ void scan_values(const StepHeads &hd, const float x[4][N], float carry[N], float incl[4][N],
-                                            float prev[4][N], FI identity, FC comb)
+__device__ __forceinline__ void scan_values(const StepHeads &hd, const float x[SE][N], float carry[N], float incl[SE][N],
+                                            float prev[SE][N], FI identity, FC comb)
 {
-    float li[4][N];
+    float li[SE][N];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < SE; ++k)
 #pragma unroll
         for (int ch = 0; ch < N; ++ch)
             li[k][ch] = (k == 0 || hd.is_head[k]) ? x[k][ch] : comb(ch, li[k - 1 < 0 ? 0 : k - 1][ch], x[k][ch]);
     float av[N];
 #pragma unroll
-    for (int ch = 0; ch < N; ++ch) av[ch] = li[3][ch];
+    for (int ch = 0; ch < N; ++ch) av[ch] = li[SE - 1][ch];
     values_step<0, N>(hd, av, identity, comb); values_step<1, N>(hd, av, identity, comb);
     values_step<2, N>(hd, av, identity, comb); values_step<3, N>(hd, av, identity, comb);
     values_step<4, N>(hd, av, identity, comb); values_step<5, N>(hd, av, identity, comb);
@@ -223,37 +243,43 @@ __device__ __forceinline__ void scan_values(const StepHeads &hd, const float x[4
         if (hd.open_prefix) pv[ch] = comb(ch, carry[ch], pv[ch]);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < SE; ++k)
 #pragma unroll
         for (int ch = 0; ch < N; ++ch) {
             prev[k][ch] = (k == 0) ? pv[ch] : incl[k - 1 < 0 ? 0 : k - 1][ch];
             incl[k][ch] = hd.lh[k] >= 0 ? li[k][ch] : comb(ch, pv[ch], li[k][ch]);
         }
 #pragma unroll
-    for (int ch = 0; ch < N; ++ch) carry[ch] = last_lane(incl[3][ch]);
+    for (int ch = 0; ch < N; ++ch) carry[ch] = last_lane(incl[SE - 1][ch]);
 }
 
 // Per-ray totals: a ray is finished where the next head appears; (prev_rid, prev) there is its id and
 // its inclusive total.  A lane has at most 4 such heads and almost always at most one, so the first is
 // handled in one predicated block and further ones behind a wave-uniform (rarely taken) branch.
 template <int N, class F>
-__device__ __forceinline__ void flush_totals(const StepHeads &hd, const float prev[4][N], F &&done)
+__device__ __forceinline__ void flush_totals(const StepHeads &hd, const float prev[SE][N], F &&done)
 {
-    bool f[4];
+    bool f[SE];
     int nf = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { f[k] = hd.is_head[k] && hd.prev_rid[k] >= 0; nf += f[k] ? 1 : 0; }
+    for (int k = 0; k < SE; ++k) { f[k] = hd.is_head[k] && hd.prev_rid[k] >= 0; nf += f[k] ? 1 : 0; }
     if (nf > 0) {
-        const int32_t rid = f[0] ? hd.prev_rid[0] : (f[1] ? hd.prev_rid[1] : (f[2] ? hd.prev_rid[2] : hd.prev_rid[3]));
+        int32_t rid = hd.prev_rid[SE - 1];   // the FIRST finished ray of the lane (lowest k wins)
         float t[N];
 #pragma unroll
-        for (int ch = 0; ch < N; ++ch) t[ch] = f[0] ? prev[0][ch] : (f[1] ? prev[1][ch] : (f[2] ? prev[2][ch] : prev[3][ch]));
+        for (int ch = 0; ch < N; ++ch) t[ch] = prev[SE - 1][ch];
+#pragma unroll
+        for (int k = SE - 2; k >= 0; --k) {
+            if (f[k]) rid = hd.prev_rid[k];
+#pragma unroll
+            for (int ch = 0; ch < N; ++ch) if (f[k]) t[ch] = prev[k][ch];
+        }
         done(rid, t);
     }
     if (__ballot(nf > 1) != 0ull) {
         bool seen = false;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < SE; ++k) {
             if (f[k] && seen) done(hd.prev_rid[k], prev[k]);
             seen = seen || f[k];
         }
@@ -266,21 +292,23 @@ __device__ __forceinline__ void flush_totals(const StepHeads &hd, const float pr
 template <int N, class FX, class FD>
 __device__ __forceinline__ void scan_totals(const StepHeads &hd, FX &&xb, float carry[N], FD &&done)
 {
-    bool f[4];
+    bool f[SE];
     int nf = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { f[k] = hd.is_head[k] && hd.prev_rid[k] >= 0; nf += f[k] ? 1 : 0; }
-    const int32_t rid1 = f[0] ? hd.prev_rid[0] : (f[1] ? hd.prev_rid[1] : (f[2] ? hd.prev_rid[2] : hd.prev_rid[3]));
+    for (int k = 0; k < SE; ++k) { f[k] = hd.is_head[k] && hd.prev_rid[k] >= 0; nf += f[k] ? 1 : 0; }
+    int32_t rid1 = hd.prev_rid[SE - 1];   // the first finished ray of the lane
+#pragma unroll
+    for (int k = SE - 2; k >= 0; --k) if (f[k]) rid1 = hd.prev_rid[k];
     const bool more = __ballot(nf > 1) != 0ull;  // wave-uniform, rare: a lane closing two or more rays
 #pragma unroll
     for (int ch = 0; ch < N; ++ch) {
-        float li[4];
+        float li[SE];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < SE; ++k) {
             const float x = xb(k, ch);
             li[k] = (k == 0 || hd.is_head[k]) ? x : li[k - 1 < 0 ? 0 : k - 1] + x;
         }
-        float av[1] = {li[3]};
+        float av[1] = {li[SE - 1]};
         auto ident = [](int) { return 0.0f; };
         auto add = [](int, float u, float v) { return u + v; };
         values_step<0, 1>(hd, av, ident, add); values_step<1, 1>(hd, av, ident, add);
@@ -289,17 +317,20 @@ __device__ __forceinline__ void scan_totals(const StepHeads &hd, FX &&xb, float 
         float pv = dpp_prev_lane(0.0f, av[0]);
         if (hd.open_prefix) pv = carry[ch] + pv;
         // prev[k]: inclusive value of the element before k
-        float prev[4], incl = pv;
+        float prev[SE], incl = pv;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < SE; ++k) {
             prev[k] = incl;
             incl = hd.lh[k] >= 0 ? li[k] : pv + li[k];
         }
-        if (nf > 0) done(rid1, ch, f[0] ? prev[0] : (f[1] ? prev[1] : (f[2] ? prev[2] : prev[3])));
+        float t1 = prev[SE - 1];
+#pragma unroll
+        for (int k = SE - 2; k >= 0; --k) if (f[k]) t1 = prev[k];
+        if (nf > 0) done(rid1, ch, t1);
         if (more) {
             bool seen = false;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < SE; ++k) {
                 if (f[k] && seen) done(hd.prev_rid[k], ch, prev[k]);
                 seen = seen || f[k];
             }
@@ -337,7 +368,7 @@ __device__ __forceinline__ int64_t uniform64(int64_t v)
 //   void  empty_ray(int rid);
 // Everything that is the same for the whole wave (tile bounds, step base, loop control) is kept in
 // scalar registers (the tile index is made uniform with readfirstlane).
-template <int DIR, bool PIPE, class Op>
+template <int DIR, int PIPE /* 0: none, 1: next step's loads before this step's compute, 2: before this step's stores */, class Op>
 __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__ packed_info,
                                              const longlong2 *__restrict__ tiles, int64_t n_rays, int64_t tile,
                                              int32_t *__restrict__ hid /* LDS, SEG_CHUNK ints, wave private */,
@@ -386,12 +417,17 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
         const int32_t d_lo = lo64 < 0 ? 0 : (lo64 > SEG_CHUNK ? SEG_CHUNK : (int32_t)lo64);
         const int32_t d_hi = hi64 < 0 ? 0 : (hi64 > SEG_CHUNK ? SEG_CHUNK : (int32_t)hi64);
         q.c = c;
-        q.off = 4 * alane;
+        q.off = SE * alane;
         q.safe = (d_lo / 4) * 4;  // first in-range multiple of 4 (every step holds at least one element)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) q.valid[j] = (q.off + j >= d_lo) && (q.off + j < d_hi);
-        q.any = (q.off + 3 >= d_lo) && (q.off < d_hi);
-        q.all = (q.off >= d_lo) && (q.off + 3 < d_hi);
+        for (int j = 0; j < SE; ++j) q.valid[j] = (q.off + j >= d_lo) && (q.off + j < d_hi);
+        q.any = (q.off + SE - 1 >= d_lo) && (q.off < d_hi);
+        q.all = (q.off >= d_lo) && (q.off + SE - 1 < d_hi);
+#pragma unroll
+        for (int h = 0; h < SQ; ++h) {
+            q.qany[h] = (q.off + 4 * h + 3 >= d_lo) && (q.off + 4 * h < d_hi);
+            q.qall[h] = (q.off + 4 * h >= d_lo) && (q.off + 4 * h + 3 < d_hi);
+        }
     };
     // Software pipeline (PIPE): the loads of step i+1 are issued before step i is computed and stored
     // (vmcnt retires in order: loads issued BEFORE the stores can be waited for without them).
@@ -403,13 +439,14 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
     }
     for (int64_t ci = 0; ci < n_chunks; ++ci) {
         const int64_t c = chunk_base(ci);
-        if (PIPE && ci + 1 < n_chunks) {
+        if (PIPE == 1 && ci + 1 < n_chunks) {
             Pos qn;
             make_pos(chunk_base(ci + 1), qn);
             op.fetch(qn, raw_next);
         }
         // ---- segment heads of this chunk -> LDS
-        *reinterpret_cast<int4 *>(hid + 4 * lane) = make_int4(-1, -1, -1, -1);
+#pragma unroll
+        for (int h = 0; h < SQ; ++h) *reinterpret_cast<int4 *>(hid + 256 * h + 4 * lane) = make_int4(-1, -1, -1, -1);
         __builtin_amdgcn_wave_barrier();
         for (;;) {
             const int32_t v = win_base + lane;
@@ -458,9 +495,13 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
             break;
         }
         __builtin_amdgcn_wave_barrier();
-        const int4 h4 = *reinterpret_cast<const int4 *>(hid + 4 * alane);
+        int32_t hj[SE];
+#pragma unroll
+        for (int h = 0; h < SQ; ++h) {
+            const int4 h4 = *reinterpret_cast<const int4 *>(hid + SE * alane + 4 * h);
+            hj[4 * h] = h4.x; hj[4 * h + 1] = h4.y; hj[4 * h + 2] = h4.z; hj[4 * h + 3] = h4.w;
+        }
         __builtin_amdgcn_wave_barrier();
-        const int32_t hj[4] = {h4.x, h4.y, h4.z, h4.w};
 
         // ---- this step's data
         Pos q;
@@ -473,26 +514,26 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
         resolve_heads<DIR>(hj, q.valid, carry_rid, hd);
         if constexpr (Op::NEEDS_RID) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int j = DIR > 0 ? k : 3 - k;
+            for (int k = 0; k < SE; ++k) {
+                const int j = DIR > 0 ? k : SE - 1 - k;
                 op.pre(j, q.p0() + j, q.valid[j], hd.rid[k]);
             }
             op.store_pre(q);
         }
         // ---- stage A: scan of op.x, results to op.emit
         {
-            float xa[4][NCH], incl[4][NCH], prev[4][NCH];
+            float xa[SE][NCH], incl[SE][NCH], prev[SE][NCH];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int j = DIR > 0 ? k : 3 - k;
+            for (int k = 0; k < SE; ++k) {
+                const int j = DIR > 0 ? k : SE - 1 - k;
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch) xa[k][ch] = q.valid[j] ? op.x(j, ch) : op.identity(ch);
             }
             scan_values<NCH>(hd, xa, carry, incl, prev, [&](int ch) { return op.identity(ch); },
                              [&](int ch, float u, float v) { return op.comb(ch, u, v); });
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int j = DIR > 0 ? k : 3 - k;
+            for (int k = 0; k < SE; ++k) {
+                const int j = DIR > 0 ? k : SE - 1 - k;
                 op.emit(j, q.p0() + j, q.valid[j], hd.is_head[k], hd.rid[k], hd.prev_rid[k], incl[k], prev[k]);
             }
             if constexpr (Op::TOTALS) flush_totals<NCH>(hd, prev, [&](int32_t rid, const float *t) { op.ray_done(rid, t); });
@@ -500,13 +541,20 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
         // ---- stage B (optional): per-ray totals of values derived from stage A's results.  The per-element
         //      outputs are complete after stage A: they are stored first (their registers are free for stage B
         //      and the stores are in flight while it runs).
+        if (PIPE == 2 && ci + 1 < n_chunks) {
+            // the results are in registers, most temporaries are dead: request the next step's inputs BEFORE the stores
+            // (vmcnt retires in order, so the next step can wait for its loads without waiting for these stores)
+            Pos qn;
+            make_pos(chunk_base(ci + 1), qn);
+            op.fetch(qn, raw_next);
+        }
         op.store(q);
         if constexpr (Op::NCHB > 0) {
             scan_totals<NCB>(hd,
-                             [&](int k, int ch) { const int j = DIR > 0 ? k : 3 - k; return q.valid[j] ? op.xb(j, ch) : 0.0f; },
+                             [&](int k, int ch) { const int j = DIR > 0 ? k : SE - 1 - k; return q.valid[j] ? op.xb(j, ch) : 0.0f; },
                              carry_b, [&](int32_t rid, int ch, float t) { op.ray_done_b(rid, ch, t); });
         }
-        carry_rid = last_lane(hd.rid[3]);
+        carry_rid = last_lane(hd.rid[SE - 1]);
         if (PIPE) raw_cur = raw_next;
     }
     // remaining owned rays are all empty (their start equals e_hi / e_lo)
@@ -527,7 +575,7 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
     }
 }
 
-template <int DIR, bool PIPE, class Op>
+template <int DIR, int PIPE, class Op>
 __global__ __launch_bounds__(64 * SEG_WAVES_PER_BLOCK, Op::MIN_WAVES_PER_EU) void seg_kernel(Op op, const int64_t *__restrict__ packed_info,
                                                                        const longlong2 *__restrict__ tiles,
                                                                        int64_t n_rays, int64_t n_tiles)
@@ -547,17 +595,10 @@ static void launch_seg(const Op &op, const int64_t *packed_info, const int64_t *
 {
     const longlong2 *tiles = reinterpret_cast<const longlong2 *>(tiles_raw);
     const unsigned grid = (unsigned)ceil_div64(n_tiles, SEG_WAVES_PER_BLOCK);
-    // The one-step-ahead software prefetch (PIPE) measured slower than the extra occupancy its registers cost on
-    // every op; it is compiled only with -DNFA_SEG_ENABLE_PIPE=1 (then NFA_SEG_PIPELINE=1 selects it at run time).
-#if defined(NFA_SEG_ENABLE_PIPE) && NFA_SEG_ENABLE_PIPE
-    static const bool pipe = getenv("NFA_SEG_PIPELINE") ? atoi(getenv("NFA_SEG_PIPELINE")) != 0 : false;
-    if (pipe) {
-        hipLaunchKernelGGL((seg_kernel<DIR, true, Op>), dim3(grid), dim3(64 * SEG_WAVES_PER_BLOCK), 0, s, op, packed_info, tiles,
-                           n_rays, n_tiles);
-        return;
-    }
-#endif
-    hipLaunchKernelGGL((seg_kernel<DIR, false, Op>), dim3(grid), dim3(64 * SEG_WAVES_PER_BLOCK), 0, s, op, packed_info, tiles,
+    // NFA_SEG_PIPE (compile time): 0 = a step's loads are requested when the step starts; 1 = one step ahead, before the
+    // previous step's compute (its registers cost occupancy: slower on every op); 2 = one step ahead, between the previous
+    // step's compute and its stores.
+    hipLaunchKernelGGL((seg_kernel<DIR, NFA_SEG_PIPE, Op>), dim3(grid), dim3(64 * SEG_WAVES_PER_BLOCK), 0, s, op, packed_info, tiles,
                        n_rays, n_tiles);
 }
 
@@ -590,7 +631,7 @@ struct ScanOp {
     struct Raw { F4 x; };
     const float *in;
     float *out;
-    float xin[4], res[4];
+    float xin[SE], res[SE];
     __device__ __forceinline__ float identity(int) const { return PROD ? 1.0f : 0.0f; }
     __device__ __forceinline__ float comb(int, float a, float b) const { return PROD ? a * b : a + b; }
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const { ld4<VEC>(in, q, r.x); }
@@ -598,7 +639,7 @@ struct ScanOp {
     {
         const bool *valid = pos.valid;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xin[j] = sel(r.x, j, valid, identity(0));
+        for (int j = 0; j < SE; ++j) xin[j] = sel(r.x, j, valid, identity(0));
     }
     __device__ __forceinline__ float x(int j, int) const { return xin[j]; }
     __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int, int, const float incl[1], const float prev[1])
@@ -617,7 +658,7 @@ struct ProdBwdOp : OpBase1 {
     struct Raw { F4 o, g, in; };
     const float *in, *outv, *g;
     float *gin;
-    float q[4], den[4], res[4];
+    float q[SE], den[SE], res[SE];
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
         ld4<VEC>(outv, q, r.o);
@@ -628,7 +669,7 @@ struct ProdBwdOp : OpBase1 {
     {
         const bool *valid = pos.valid;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { q[j] = sel(r.g, j, valid, 0.0f) * sel(r.o, j, valid, 0.0f); den[j] = sel(r.in, j, valid, 1.0f); }
+        for (int j = 0; j < SE; ++j) { q[j] = sel(r.g, j, valid, 0.0f) * sel(r.o, j, valid, 0.0f); den[j] = sel(r.in, j, valid, 1.0f); }
     }
     __device__ __forceinline__ float x(int j, int) const { return q[j]; }
     __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int, int, const float incl[1], const float prev[1])
@@ -645,7 +686,7 @@ struct DensityFwdOp : OpBase1 {
     struct Raw { F4 a, b, s, pf; };
     const float *ts, *te, *sig, *prefix;
     float *w, *tr, *al;
-    float xs[4], pf[4], rw[4], rt[4], ra[4];
+    float xs[SE], pf[SE], rw[SE], rt[SE], ra[SE];
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
         ld4<VEC>(ts, q, r.a);
@@ -657,7 +698,7 @@ struct DensityFwdOp : OpBase1 {
     {
         const bool *valid = pos.valid;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < SE; ++j) {
             xs[j] = valid[j] ? r.s.v[j] * (r.b.v[j] - r.a.v[j]) : 0.0f;
             pf[j] = prefix ? r.pf.v[j] : 1.0f;
         }
@@ -694,7 +735,7 @@ struct AlphaFwdOp {
     struct Raw { F4 a, pf; };
     const float *al, *prefix;
     float *w, *tr;
-    float a4[4], pf[4], rw[4], rt[4];
+    float a4[SE], pf[SE], rw[SE], rt[SE];
     __device__ __forceinline__ float identity(int) const { return 1.0f; }
     __device__ __forceinline__ float comb(int, float a, float b) const { return a * b; }
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
@@ -706,7 +747,7 @@ struct AlphaFwdOp {
     {
         const bool *valid = pos.valid;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { a4[j] = sel(r.a, j, valid, 0.0f); pf[j] = prefix ? r.pf.v[j] : 1.0f; }
+        for (int j = 0; j < SE; ++j) { a4[j] = sel(r.a, j, valid, 0.0f); pf[j] = prefix ? r.pf.v[j] : 1.0f; }
     }
     __device__ __forceinline__ float x(int j, int) const { return 1.0f - a4[j]; }
     __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int, int, const float *, const float prev[1])
@@ -733,7 +774,7 @@ struct DensityBwdOp : OpBase1 {
     struct Raw { F4 a, b, T, A, gw, gt, ga; };
     const float *ts, *te, *tr, *al, *gw, *gt, *ga;
     float *gsig, *gx;
-    float T[4], A[4], GW[4], GA[4], dlt[4], q[4], rs[4], rx[4];
+    float T[SE], A[SE], GW[SE], GA[SE], dlt[SE], q[SE], rs[SE], rx[SE];
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
         ld4<VEC>(ts, q, r.a);
@@ -748,7 +789,7 @@ struct DensityBwdOp : OpBase1 {
     {
         const bool *valid = pos.valid;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < SE; ++j) {
             T[j] = sel(r.T, j, valid, 0.0f); A[j] = sel(r.A, j, valid, 0.0f);
             GW[j] = (gw && valid[j]) ? r.gw.v[j] : 0.0f;
             const float GT = (gt && valid[j]) ? r.gt.v[j] : 0.0f;
@@ -781,7 +822,7 @@ struct AlphaBwdOp : OpBase1 {
     struct Raw { F4 T, A, gw, gt; };
     const float *al, *tr, *gw, *gt;
     float *galpha;
-    float T[4], A[4], GW[4], q[4], res[4];
+    float T[SE], A[SE], GW[SE], q[SE], res[SE];
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
         ld4<VEC>(tr, q, r.T);
@@ -793,7 +834,7 @@ struct AlphaBwdOp : OpBase1 {
     {
         const bool *valid = pos.valid;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < SE; ++j) {
             T[j] = sel(r.T, j, valid, 0.0f); A[j] = sel(r.A, j, valid, 0.0f);
             GW[j] = (gw && valid[j]) ? r.gw.v[j] : 0.0f;
             const float GT = (gt && valid[j]) ? r.gt.v[j] : 0.0f;
@@ -824,8 +865,8 @@ struct VisibilityOp {
     float eps, thre;
     uint8_t *vis;
     int64_t *cnts;
-    float x0[4], a4[4], pf[4];
-    uint8_t m[4];
+    float x0[SE], a4[SE], pf[SE];
+    uint8_t m[SE];
     __device__ __forceinline__ float identity(int) const { return DENSITY ? 0.0f : 1.0f; }
     __device__ __forceinline__ float comb(int, float a, float b) const { return DENSITY ? a + b : a * b; }
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
@@ -841,7 +882,7 @@ struct VisibilityOp {
     {
         const bool *valid = pos.valid;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < SE; ++j) {
             pf[j] = prefix ? r.pf.v[j] : 1.0f;
             const float sv = sel(r.s, j, valid, 0.0f);
             if (DENSITY) { x0[j] = valid[j] ? sv * (r.b.v[j] - r.a.v[j]) : 0.0f; a4[j] = (thre > 0.0f) ? 1.0f - expf(-x0[j]) : 1.0f; }  // alpha only when it is tested
@@ -865,13 +906,16 @@ struct VisibilityOp {
         const int64_t p0 = q.p0();
         (void)valid; (void)p0;
         uint8_t *b = vis + q.c;
-        if (VEC && q.all) {
-            *reinterpret_cast<uchar4 *>(b + q.off) = make_uchar4(m[0], m[1], m[2], m[3]);
-        } else {
-            volatile uint8_t *pv = b;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (q.valid[j]) pv[q.off + j] = m[j];
+        for (int h = 0; h < SQ; ++h) {
+            if (VEC && q.qall[h]) {
+                *reinterpret_cast<uchar4 *>(b + q.off + 4 * h) = make_uchar4(m[4 * h], m[4 * h + 1], m[4 * h + 2], m[4 * h + 3]);
+            } else {
+                volatile uint8_t *pv = b;
+#pragma unroll
+                for (int j = 4 * h; j < 4 * h + 4; ++j)
+                    if (q.valid[j]) pv[q.off + j] = m[j];
+            }
         }
     }
     __device__ __forceinline__ void ray_done(int, const float *) const {}
@@ -881,22 +925,25 @@ struct VisibilityOp {
     }
 };
 
-struct U4 { uint32_t w; };  // 4 mask bytes, raw
+struct U4 { uint32_t w[SQ]; };  // the lane's SE mask bytes, raw
 __device__ __forceinline__ void load_mask4(const uint8_t *vis, bool vec, const Pos &q, U4 &m)
 {
     const uint8_t *b = vis + q.c;
-    if (vec) {
-        m.w = *reinterpret_cast<const uint32_t *>(b + (q.any ? q.off : q.safe));
-    } else {
-        uint32_t w = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w |= (uint32_t)b[q.valid[j] ? q.off + j : q.safe] << (8 * j);
-        m.w = w;
+    for (int h = 0; h < SQ; ++h) {
+        if (vec) {
+            m.w[h] = *reinterpret_cast<const uint32_t *>(b + (q.qany[h] ? q.off + 4 * h : q.safe));
+        } else {
+            uint32_t w = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w |= (uint32_t)b[q.valid[4 * h + j] ? q.off + 4 * h + j : q.safe] << (8 * j);
+            m.w[h] = w;
+        }
     }
 }
-__device__ __forceinline__ float mask_sel(const U4 &m, int j, const bool valid[4])
+__device__ __forceinline__ float mask_sel(const U4 &m, int j, const bool valid[SE])
 {
-    return (valid[j] && ((m.w >> (8 * j)) & 0xFFu)) ? 1.0f : 0.0f;
+    return (valid[j] && ((m.w[j / 4] >> (8 * (j % 4))) & 0xFFu)) ? 1.0f : 0.0f;
 }
 
 // ---- compaction of the visible samples (per-ray output offsets = cumsum of VisibilityOp's counts)
@@ -909,7 +956,7 @@ struct CompactOp : OpBase1 {
     const int64_t *out_starts;
     int64_t *o_ri;
     float *o_ts, *o_te;
-    float m[4], a[4], b[4];
+    float m[SE], a[SE], b[SE];
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
         load_mask4(vis, vis_vec != 0, q, r.m);
@@ -920,7 +967,7 @@ struct CompactOp : OpBase1 {
     {
         const bool *valid = pos.valid;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { m[j] = mask_sel(r.m, j, valid); a[j] = r.a.v[j]; b[j] = r.b.v[j]; }
+        for (int j = 0; j < SE; ++j) { m[j] = mask_sel(r.m, j, valid); a[j] = r.a.v[j]; b[j] = r.b.v[j]; }
     }
     __device__ __forceinline__ float x(int j, int) const { return m[j]; }
     __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int rid, int, const float *, const float prev[1])
@@ -942,12 +989,12 @@ struct AccumOp {
     static constexpr bool TOTALS = true;
     static constexpr int MIN_WAVES_PER_EU = 1;
     static constexpr int RAY_LDS_FLOATS = 0;    // per-wave LDS floats for per-ray data staged at tile start (tile_begin)
-    struct Raw { F4 w; float v[4][C]; };
+    struct Raw { F4 w; float v[SE][C]; };
     const float *w, *vals;  // vals may be null (C == 1): accumulate w
     int32_t D, d0;
     float *out;
     int accumulate;
-    float xv[4][C];
+    float xv[SE][C];
     __device__ __forceinline__ float identity(int) const { return 0.0f; }
     __device__ __forceinline__ float comb(int, float a, float b) const { return a + b; }
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
@@ -955,7 +1002,7 @@ struct AccumOp {
         ld4<VEC>(w, q, r.w);
         if (vals) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < SE; ++j)
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch) r.v[j][ch] = vals[(q.c + (q.valid[j] ? q.off + j : q.safe)) * D + d0 + ch];
         }
@@ -964,7 +1011,7 @@ struct AccumOp {
     {
         const bool *valid = pos.valid;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < SE; ++j)
 #pragma unroll
             for (int ch = 0; ch < C; ++ch) xv[j][ch] = valid[j] ? (vals ? r.w.v[j] * r.v[j][ch] : r.w.v[j]) : 0.0f;
     }
@@ -990,19 +1037,19 @@ struct AccumOp {
 
 template <int C, bool VEC>
 struct AccumBwdOp : OpBase1 {
-    struct Raw { F4 w, g; float v[4][C]; };
+    struct Raw { F4 w, g; float v[SE][C]; };
     const float *w, *vals, *gout;
     int32_t D, d0;
     int first;  // first channel group: g_w is written, later groups add to it
     float *gw, *gv;
-    float ww[4], res[4], vv[4][C];
+    float ww[SE], res[SE], vv[SE][C];
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
         ld4<VEC>(w, q, r.w);
         if (gw && !first) ld4<VEC>(gw, q, r.g);
         if (vals) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < SE; ++j)
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch) r.v[j][ch] = vals[(q.c + (q.valid[j] ? q.off + j : q.safe)) * D + d0 + ch];
         }
@@ -1010,7 +1057,7 @@ struct AccumBwdOp : OpBase1 {
     __device__ __forceinline__ void load(const Raw &r, const Pos &)
     {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < SE; ++j) {
             ww[j] = r.w.v[j];
             res[j] = (gw && !first) ? r.g.v[j] : 0.0f;
 #pragma unroll
@@ -1044,36 +1091,64 @@ struct AccumBwdOp : OpBase1 {
 // 4 x rgb (12 consecutive floats at 3*p), raw.  With VEC the 48 bytes are three aligned 16 B loads from
 // p0 when all 4 elements are valid, else from the step's base (always inside the array); the few
 // lanes that straddle a range end re-read their valid elements one by one in fix_rgb12.
-__device__ __forceinline__ void load_rgb12(const float *rgb, bool vec, const Pos &q, float c[12])
+__device__ __forceinline__ void load_rgb12(const float *rgb, bool vec, const Pos &q, float c[3 * SE])
 {
     const float *b = rgb + 3 * q.c;
     if (vec) {
-        const float4 *v = reinterpret_cast<const float4 *>(b + 3 * (q.all ? q.off : q.safe));
-        const float4 q0 = v[0], q1 = v[1], q2 = v[2];
-        c[0] = q0.x; c[1] = q0.y; c[2] = q0.z; c[3] = q0.w; c[4] = q1.x; c[5] = q1.y;
-        c[6] = q1.z; c[7] = q1.w; c[8] = q2.x; c[9] = q2.y; c[10] = q2.z; c[11] = q2.w;
+#pragma unroll
+        for (int h = 0; h < SQ; ++h) {
+            const float4 *v = reinterpret_cast<const float4 *>(b + 3 * (q.qall[h] ? q.off + 4 * h : q.safe));
+            const float4 q0 = v[0], q1 = v[1], q2 = v[2];
+            float *o = c + 12 * h;
+            o[0] = q0.x; o[1] = q0.y; o[2] = q0.z; o[3] = q0.w; o[4] = q1.x; o[5] = q1.y;
+            o[6] = q1.z; o[7] = q1.w; o[8] = q2.x; o[9] = q2.y; o[10] = q2.z; o[11] = q2.w;
+        }
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < SE; ++j)
 #pragma unroll
             for (int k = 0; k < 3; ++k) c[3 * j + k] = b[3 * (q.valid[j] ? q.off + j : q.safe) + k];
     }
 }
-__device__ __forceinline__ void fix_rgb12(const float *rgb, bool vec, const Pos &q, const float raw[12], float c[12])
+__device__ __forceinline__ void fix_rgb12(const float *rgb, bool vec, const Pos &q, const float raw[3 * SE], float c[3 * SE])
 {
 #pragma unroll
-    for (int k = 0; k < 12; ++k) c[k] = raw[k];
+    for (int k = 0; k < 3 * SE; ++k) c[k] = raw[k];
     if (vec && q.any && !q.all) {  // rare: first / last lane of a range
         const float *b = rgb + 3 * q.c;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < SE; ++j)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) c[3 * j + k] = q.valid[j] ? b[3 * (q.off + j) + k] : 0.0f;
+            for (int k = 0; k < 3; ++k)
+                if (!q.qall[j / 4]) c[3 * j + k] = q.valid[j] ? b[3 * (q.off + j) + k] : 0.0f;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < SE; ++j)
 #pragma unroll
         for (int k = 0; k < 3; ++k) c[3 * j + k] = q.valid[j] ? c[3 * j + k] : 0.0f;
+}
+
+// SE x rgb out: three 16 B stores per full quad, element-wise (volatile, see store4) where a range ends
+__device__ __forceinline__ void store_rgb12(float *rgb, bool vec, const Pos &q, const float g[3 * SE])
+{
+    float *b = rgb + 3 * q.c;
+#pragma unroll
+    for (int h = 0; h < SQ; ++h) {
+        if (vec && q.qall[h]) {
+            float4 *o = reinterpret_cast<float4 *>(b + 3 * (q.off + 4 * h));
+            const float *s = g + 12 * h;
+            o[0] = make_float4(s[0], s[1], s[2], s[3]);
+            o[1] = make_float4(s[4], s[5], s[6], s[7]);
+            o[2] = make_float4(s[8], s[9], s[10], s[11]);
+        } else {
+            volatile float *pv = b;
+#pragma unroll
+            for (int j = 4 * h; j < 4 * h + 4; ++j)
+                if (q.valid[j]) {
+                    pv[3 * (q.off + j)] = g[3 * j]; pv[3 * (q.off + j) + 1] = g[3 * j + 1]; pv[3 * (q.off + j) + 2] = g[3 * j + 2];
+                }
+        }
+    }
 }
 
 // ---- the three accumulations of `rendering` fused: colours(3), opacity, depth  (volrend.py:140-151)
@@ -1085,10 +1160,10 @@ struct RenderAccumOp {
     static constexpr bool TOTALS = true;
     static constexpr int MIN_WAVES_PER_EU = 1;
     static constexpr int RAY_LDS_FLOATS = 0;    // per-wave LDS floats for per-ray data staged at tile start (tile_begin)
-    struct Raw { F4 w, a, b; float c[12]; };
+    struct Raw { F4 w, a, b; float c[3 * SE]; };
     const float *w, *rgb, *ts, *te;
     float *colors, *opac, *depth;
-    float xv[4][5];
+    float xv[SE][5];
     __device__ __forceinline__ float identity(int) const { return 0.0f; }
     __device__ __forceinline__ float comb(int, float a, float b) const { return a + b; }
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
@@ -1101,10 +1176,10 @@ struct RenderAccumOp {
     __device__ __forceinline__ void load(const Raw &r, const Pos &pos)
     {
         const bool *valid = pos.valid;
-        float c[12];
+        float c[3 * SE];
         fix_rgb12(rgb, VEC, pos, r.c, c);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < SE; ++j) {
             const float ww = sel(r.w, j, valid, 0.0f);
             xv[j][0] = ww * c[3 * j]; xv[j][1] = ww * c[3 * j + 1]; xv[j][2] = ww * c[3 * j + 2];
             xv[j][3] = ww;
@@ -1129,11 +1204,10 @@ struct RenderAccumOp {
 
 template <bool VEC>
 struct RenderAccumBwdOp : OpBase1 {
-    struct Raw { F4 w, a, b; float c[12]; };
+    struct Raw { F4 w, a, b; float c[3 * SE]; };
     const float *w, *rgb, *ts, *te, *gc, *go, *gd;
     float *gw, *grgb;
-    float ww[4], mid[4], res[4], c[12], gr[12];
-    bool full;
+    float ww[SE], mid[SE], res[SE], c[3 * SE], gr[3 * SE];
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
         ld4<VEC>(w, q, r.w);
@@ -1144,9 +1218,9 @@ struct RenderAccumBwdOp : OpBase1 {
     __device__ __forceinline__ void load(const Raw &r, const Pos &pos)
     {
         const bool *valid = pos.valid;
-        full = VEC && valid[0] && valid[1] && valid[2] && valid[3];
+        (void)valid;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { ww[j] = r.w.v[j]; mid[j] = (r.a.v[j] + r.b.v[j]) / 2.0f; }
+        for (int j = 0; j < SE; ++j) { ww[j] = r.w.v[j]; mid[j] = (r.a.v[j] + r.b.v[j]) / 2.0f; }
         fix_rgb12(rgb, VEC, pos, r.c, c);
     }
     __device__ __forceinline__ float x(int, int) const { return 0.0f; }
@@ -1171,21 +1245,7 @@ struct RenderAccumBwdOp : OpBase1 {
         const int64_t p0 = q.p0();
         (void)valid; (void)p0;
         if (gw) store4<VEC>(gw, q, res);
-        if (grgb) {
-            if (full) {
-                float4 *q = reinterpret_cast<float4 *>(grgb + 3 * p0);
-                q[0] = make_float4(gr[0], gr[1], gr[2], gr[3]);
-                q[1] = make_float4(gr[4], gr[5], gr[6], gr[7]);
-                q[2] = make_float4(gr[8], gr[9], gr[10], gr[11]);
-            } else {
-                volatile float *pv = grgb;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (valid[j]) {
-                        pv[3 * (p0 + j)] = gr[3 * j]; pv[3 * (p0 + j) + 1] = gr[3 * j + 1]; pv[3 * (p0 + j) + 2] = gr[3 * j + 2];
-                    }
-            }
-        }
+        if (grgb) store_rgb12(grgb, VEC, q, gr);
     }
 };
 
@@ -1197,10 +1257,10 @@ template <bool VEC>
 struct RenderFusedFwdOp : OpBase1 {
     static constexpr int NCHB = 5;
     static constexpr int MIN_WAVES_PER_EU = NFA_SEG_OCC_HINTS ? 6 : 1;  // 81 VGPRs without the hint: one over the 6-wave budget
-    struct Raw { F4 a, b, s; float c[12]; };
+    struct Raw { F4 a, b, s; float c[3 * SE]; };
     const float *ts, *te, *sig, *rgb;
     float *w, *tr, *al, *colors, *opac, *depth;
-    float xs[4], mid[4], rw[4], rt[4], ra[4], c[12];
+    float xs[SE], mid[SE], rw[SE], rt[SE], ra[SE], c[3 * SE];
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
         ld4<VEC>(ts, q, r.a);
@@ -1213,7 +1273,7 @@ struct RenderFusedFwdOp : OpBase1 {
         const bool *valid = pos.valid;
         fix_rgb12(rgb, VEC, pos, r.c, c);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < SE; ++j) {
             xs[j] = valid[j] ? r.s.v[j] * (r.b.v[j] - r.a.v[j]) : 0.0f;
             mid[j] = (r.a.v[j] + r.b.v[j]) / 2.0f;
         }
@@ -1265,13 +1325,13 @@ template <bool VEC>
 struct RenderStepOp : OpBase1 {
     static constexpr int NCHB = 5;
     static constexpr bool NEEDS_RID = true;
-    struct Raw { F4 a, b, s; float c[12]; };
+    struct Raw { F4 a, b, s; float c[3 * SE]; };
     const float *ts, *te, *sig, *rgb;
     float thre;
     float *colors, *opac, *depth;  // [R,3], [R], [R] in/out
     unsigned long long *n_visible;  // += samples that pass the alpha threshold (the loop's sample count), or null
-    float xs[4], mid[4], pf[4], rw[4], c[12];
-    bool keep[4];
+    float xs[SE], mid[SE], pf[SE], rw[SE], c[3 * SE];
+    bool keep[SE];
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
         ld4<VEC>(ts, q, r.a);
@@ -1284,7 +1344,7 @@ struct RenderStepOp : OpBase1 {
         const bool *valid = pos.valid;
         fix_rgb12(rgb, VEC, pos, r.c, c);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < SE; ++j) {
             xs[j] = valid[j] ? r.s.v[j] * (r.b.v[j] - r.a.v[j]) : 0.0f;
             mid[j] = (r.a.v[j] + r.b.v[j]) / 2.0f;
         }
@@ -1313,8 +1373,9 @@ struct RenderStepOp : OpBase1 {
     __device__ __forceinline__ void store(const Pos &) const
     {
         if (n_visible) {
-            const int c = __builtin_popcountll(__ballot(keep[0])) + __builtin_popcountll(__ballot(keep[1])) +
-                          __builtin_popcountll(__ballot(keep[2])) + __builtin_popcountll(__ballot(keep[3]));
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < SE; ++j) c += __builtin_popcountll(__ballot(keep[j]));
             if (c > 0 && lane_id() == 0) atomicAdd(n_visible, (unsigned long long)c);
         }
     }
@@ -1324,6 +1385,9 @@ struct RenderStepOp : OpBase1 {
 //      from the per-ray output gradients (needs the ray id before the scan: NEEDS_RID), added to the
 //      gradients arriving at extras' weights / trans / alphas, and pushed through the transmittance
 //      chain.  Same expressions as RenderAccumBwdOp followed by DensityBwdOp.
+#ifndef NFA_BWD_RAY_CAP
+#define NFA_BWD_RAY_CAP 192   // 0: no staging (A/B switch)
+#endif
 template <bool VEC, bool EXTRA /* gradients arrive at weights / trans / alphas too */>
 struct RenderFusedBwdOp : OpBase1 {
     static constexpr bool NEEDS_RID = true;
@@ -1333,13 +1397,13 @@ struct RenderFusedBwdOp : OpBase1 {
     // and step; SQ counters: the pass waits 80 % of its wave-cycles, VALU 36 % busy).  The rays of a tile are consecutive,
     // so the wave stages their gradients in LDS with coalesced loads at tile start (up to RAY_CAP rays, the rest falls
     // back to the gathers) and the per-element reads are LDS reads.
-    static constexpr int RAY_CAP = 192;
+    static constexpr int RAY_CAP = NFA_BWD_RAY_CAP;
     static constexpr int RAY_LDS_FLOATS = 8 * RAY_CAP;   // {g_r, g_g, g_b, g_opacity, g_depth, -, -, -} per ray
-    struct Raw { F4 a, b, T, A, gw, gt, ga; float c[12]; };
+    struct Raw { F4 a, b, T, A, gw, gt, ga; float c[3 * SE]; };
     const float *ts, *te, *rgb, *tr, *al, *gc, *go, *gd, *gw, *gt, *ga;
     float *gsig, *grgb;
-    const float *g_lds;
-    int32_t g_lo, g_n;
+    const float *g_lds = nullptr;
+    int32_t g_lo = 0, g_n = 0;
     __device__ __forceinline__ void tile_begin(int32_t r_lo, int32_t r_hi, float *lds)
     {
         g_lds = lds; g_lo = r_lo; g_n = min(r_hi - r_lo, RAY_CAP);
@@ -1354,7 +1418,7 @@ struct RenderFusedBwdOp : OpBase1 {
         }
         __builtin_amdgcn_wave_barrier();
     }
-    float T[4], A[4], GW[4], GT[4], GA[4], dlt[4], mid[4], q[4], rs[4], c[12], gr[12];
+    float T[SE], A[SE], GW[SE], GT[SE], GA[SE], dlt[SE], mid[SE], q[SE], rs[SE], c[3 * SE], gr[3 * SE];
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
         ld4<VEC>(ts, q, r.a);
@@ -1373,7 +1437,7 @@ struct RenderFusedBwdOp : OpBase1 {
         const bool *valid = pos.valid;
         fix_rgb12(rgb, VEC, pos, r.c, c);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < SE; ++j) {
             T[j] = sel(r.T, j, valid, 0.0f); A[j] = sel(r.A, j, valid, 0.0f);
             GW[j] = (EXTRA && gw && valid[j]) ? r.gw.v[j] : 0.0f;
             GT[j] = (EXTRA && gt && valid[j]) ? r.gt.v[j] : 0.0f;
@@ -1410,21 +1474,7 @@ struct RenderFusedBwdOp : OpBase1 {
     // g_rgb is complete before the scan: stored first (frees its registers, stores in flight during the scan)
     __device__ __forceinline__ void store_pre(const Pos &pq)
     {
-        if (!grgb) return;
-        float *b = grgb + 3 * pq.c;
-        if (VEC && pq.all) {
-            float4 *qq = reinterpret_cast<float4 *>(b + 3 * pq.off);
-            qq[0] = make_float4(gr[0], gr[1], gr[2], gr[3]);
-            qq[1] = make_float4(gr[4], gr[5], gr[6], gr[7]);
-            qq[2] = make_float4(gr[8], gr[9], gr[10], gr[11]);
-        } else {
-            volatile float *pv = b;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (pq.valid[j]) {
-                    pv[3 * (pq.off + j)] = gr[3 * j]; pv[3 * (pq.off + j) + 1] = gr[3 * j + 1]; pv[3 * (pq.off + j) + 2] = gr[3 * j + 2];
-                }
-        }
+        if (grgb) store_rgb12(grgb, VEC, pq, gr);
     }
     __device__ __forceinline__ float x(int j, int) const { return q[j]; }
     __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int, int, const float *, const float prev[1])

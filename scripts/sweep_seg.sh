@@ -1,6 +1,6 @@
 #!/bin/bash
 # scratch: sweep tile size / prefetch for the segmented engine on the bench workload
-for pipe in 0; do for tile in 512 1024 2048 4096; do  # pipe=1 needs a build with -DNFA_SEG_ENABLE_PIPE=1
+for pipe in 0; do for tile in 512 1024 2048 4096; do  # the prefetch mode is a compile-time flag now (-DNFA_SEG_PIPE=0|1|2, scripts/bench_flags.sh)
   echo "== pipeline=$pipe tile=$tile"
   NFA_SEG_PIPELINE=$pipe NFA_SEG_TILE=$tile python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys

@@ -867,6 +867,17 @@ def test_importance_sampling_and_searchsorted(dev, oracle):
     assert_close(s_sm.vals, e_sm, atol=1e-6, rtol=1e-6)                # same Philox stream as the oracle
     s2_iv, _ = na.importance_sampling(na.RayIntervals(vals=T(v, dev)), T(c, dev), 16, stratified=True)
     assert not torch.equal(s_iv.vals, s2_iv.vals)                       # generator advanced
+    # the short-row kernel (S <= 64, CDF rows staged): enough rays that a wave's block of rays shares out its Philox draws
+    # over the lanes (R >= 65536 for 8 rays per group), a ragged last block, S == 1, S == lanes
+    R2 = 70001
+    v2 = np.sort(rng.random((R2, 9)), -1).astype(np.float32); c2 = np.sort(rng.random((R2, 9)), -1).astype(np.float32)
+    for S2, strat in ((8, True), (5, False), (64, True)):
+        seed, off = gen.initial_seed(), gen.get_offset()
+        r_iv, r_sm = na.importance_sampling(na.RayIntervals(vals=T(v2, dev)), T(c2, dev), S2, stratified=strat)
+        e_iv, e_sm = oracle.importance_sampling(v2, c2, S2, strat, seed=seed, offset=off)
+        assert_close(r_iv.vals, e_iv, atol=1e-6, rtol=1e-6); assert_close(r_sm.vals, e_sm, atol=1e-6, rtol=1e-6)
+    r_iv, _ = na.importance_sampling(na.RayIntervals(vals=T(v2, dev)), T(c2, dev), 1)     # S == 1: the ray's whole range
+    assert np.array_equal(r_iv.vals.cpu().numpy(), v2[:, [0, -1]])
     # s -> t mapping fused into the resampling: same intervals, and t rows bit-equal to the reference's tensor
     # expression (estimators/prop_net.py:215-229) on them, for both mappings, short and long rows, packed input too
     from nerfacc_amd.estimators.prop_net import _transform_stot
