@@ -103,4 +103,26 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
 __device__ __forceinline__ int32_t last_lane(int32_t v) { return __builtin_amdgcn_readlane(v, 63); }
 __device__ __forceinline__ float last_lane(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
 
+
+// 16-byte stores of streamed outputs.  NFA_NT_STORES=1 marks them non-temporal (A/B switch).
+#ifndef NFA_NT_STORES
+#define NFA_NT_STORES 0
+#endif
+typedef float nfa_v4f __attribute__((ext_vector_type(4)));
+typedef long long nfa_v2l __attribute__((ext_vector_type(2)));
+template <bool NT = (NFA_NT_STORES != 0)>
+__device__ __forceinline__ void store_f4(float *p, float a, float b, float c, float d)
+{
+    nfa_v4f v = {a, b, c, d};
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<nfa_v4f *>(p));
+    else *reinterpret_cast<nfa_v4f *>(p) = v;
+}
+template <bool NT = (NFA_NT_STORES != 0)>
+__device__ __forceinline__ void store_l2(int64_t *p, int64_t a, int64_t b)
+{
+    nfa_v2l v = {a, b};
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<nfa_v2l *>(p));
+    else *reinterpret_cast<nfa_v2l *>(p) = v;
+}
+
 }  // namespace nfa

@@ -144,7 +144,7 @@ __device__ __forceinline__ void store4(float *__restrict__ p, const Pos &q, cons
 #pragma unroll
     for (int h = 0; h < SQ; ++h) {
         if (VEC && q.qall[h]) {
-            *reinterpret_cast<float4 *>(b + q.off + 4 * h) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+            store_f4(b + q.off + 4 * h, v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
         } else {
             volatile float *pv = b;
 #pragma unroll
@@ -1135,11 +1135,11 @@ __device__ __forceinline__ void store_rgb12(float *rgb, bool vec, const Pos &q, 
 #pragma unroll
     for (int h = 0; h < SQ; ++h) {
         if (vec && q.qall[h]) {
-            float4 *o = reinterpret_cast<float4 *>(b + 3 * (q.off + 4 * h));
+            float *o = b + 3 * (q.off + 4 * h);
             const float *s = g + 12 * h;
-            o[0] = make_float4(s[0], s[1], s[2], s[3]);
-            o[1] = make_float4(s[4], s[5], s[6], s[7]);
-            o[2] = make_float4(s[8], s[9], s[10], s[11]);
+            store_f4(o, s[0], s[1], s[2], s[3]);
+            store_f4(o + 4, s[4], s[5], s[6], s[7]);
+            store_f4(o + 8, s[8], s[9], s[10], s[11]);
         } else {
             volatile float *pv = b;
 #pragma unroll

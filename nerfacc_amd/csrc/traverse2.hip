@@ -11,6 +11,9 @@
 //                 sample centres; expand_intervals: the API's edge stream with is_left / is_right.
 // Results are bit-identical to the reference's serial accumulation (oracle/nerfacc_oracle.c).
 #include "common.hip.h"
+#ifndef NFA_NT_EXPAND
+#define NFA_NT_EXPAND 1   /* sample arrays are written once and read by later kernels long after they left L2: non-temporal stores, expand 160 -> 152 us and the whole cfg-2 step -40 us (A/B on one box); the engine ops lose with them */
+#endif
 #include "march.h"
 
 namespace nfa {
@@ -308,14 +311,13 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_runs_kernel(int64_t n_ray
                 }
                 if (vec && valid[0] && valid[1] && valid[2] && valid[3]) {
                     if (MODE == EXP_MIDS) {
-                        *reinterpret_cast<float4 *>(t_mids + p0) = make_float4(ts4[0], ts4[1], ts4[2], ts4[3]);
+                        store_f4<NFA_NT_EXPAND>(t_mids + p0, ts4[0], ts4[1], ts4[2], ts4[3]);
                     } else if (MODE == EXP_STARTS_ENDS || MODE == EXP_CONE) {
-                        *reinterpret_cast<float4 *>(t_starts + p0) = make_float4(ts4[0], ts4[1], ts4[2], ts4[3]);
-                        *reinterpret_cast<float4 *>(t_ends + p0) = make_float4(te4[0], te4[1], te4[2], te4[3]);
+                        store_f4<NFA_NT_EXPAND>(t_starts + p0, ts4[0], ts4[1], ts4[2], ts4[3]);
+                        store_f4<NFA_NT_EXPAND>(t_ends + p0, te4[0], te4[1], te4[2], te4[3]);
                     }
-                    longlong2 *rp = reinterpret_cast<longlong2 *>(ray_indices + p0);
-                    rp[0] = make_longlong2(ri4[0], ri4[1]);
-                    rp[1] = make_longlong2(ri4[2], ri4[3]);
+                    store_l2<NFA_NT_EXPAND>(ray_indices + p0, ri4[0], ri4[1]);
+                    store_l2<NFA_NT_EXPAND>(ray_indices + p0 + 2, ri4[2], ri4[3]);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
@@ -481,9 +483,8 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_intervals_kernel(int64_t 
                 }
                 if (vec && valid[0] && valid[1] && valid[2] && valid[3]) {
                     *reinterpret_cast<float4 *>(vals + p0) = make_float4(v4[0], v4[1], v4[2], v4[3]);
-                    longlong2 *rp = reinterpret_cast<longlong2 *>(ray_indices + p0);
-                    rp[0] = make_longlong2(ri4[0], ri4[1]);
-                    rp[1] = make_longlong2(ri4[2], ri4[3]);
+                    store_l2<NFA_NT_EXPAND>(ray_indices + p0, ri4[0], ri4[1]);
+                    store_l2<NFA_NT_EXPAND>(ray_indices + p0 + 2, ri4[2], ri4[3]);
                     *reinterpret_cast<uchar4 *>(is_left + p0) = make_uchar4(l4[0], l4[1], l4[2], l4[3]);
                     *reinterpret_cast<uchar4 *>(is_right + p0) = make_uchar4(r4[0], r4[1], r4[2], r4[3]);
                 } else {
