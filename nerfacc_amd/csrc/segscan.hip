@@ -45,6 +45,14 @@ constexpr int SE = NFA_SEG_E;
 static_assert(SE == 4 || SE == 8, "NFA_SEG_E must be 4 or 8");
 constexpr int SQ = SE / 4;              // 16-byte quads per lane
 constexpr int SEG_CHUNK = 64 * SE;      // elements per wave step
+// non-temporal loads per op (A/B switches): visibility -7 %, fused forward -2 %, but the backward pass that re-reads the
+// same arrays later loses as much (+9 us): the step does not move, so they stay off
+#ifndef NFA_NT_VIS
+#define NFA_NT_VIS false
+#endif
+#ifndef NFA_NT_FWD
+#define NFA_NT_FWD false
+#endif
 #ifndef NFA_SEG_PIPE
 #define NFA_SEG_PIPE 0
 #endif
@@ -117,14 +125,15 @@ struct Pos {
     __device__ __forceinline__ int64_t p0() const { return c + off; }
 };
 
-template <bool VEC>
+template <bool VEC, bool NT = false>
 __device__ __forceinline__ void ld4(const float *__restrict__ p, const Pos &q, F4 &out)
 {
     const float *b = p + q.c;
     if (VEC) {
 #pragma unroll
         for (int h = 0; h < SQ; ++h) {
-            const float4 v = *reinterpret_cast<const float4 *>(b + (q.qany[h] ? q.off + 4 * h : q.safe));
+            const nfa_v4f *src = reinterpret_cast<const nfa_v4f *>(b + (q.qany[h] ? q.off + 4 * h : q.safe));
+            const nfa_v4f v = NT ? __builtin_nontemporal_load(src) : *src;
             out.v[4 * h] = v.x; out.v[4 * h + 1] = v.y; out.v[4 * h + 2] = v.z; out.v[4 * h + 3] = v.w;
         }
     } else {
@@ -871,11 +880,11 @@ struct VisibilityOp {
     __device__ __forceinline__ float comb(int, float a, float b) const { return DENSITY ? a + b : a * b; }
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
-        ld4<VEC>(val, q, r.s);
-        if (prefix) ld4<VEC>(prefix, q, r.pf);
+        ld4<VEC, NFA_NT_VIS>(val, q, r.s);
+        if (prefix) ld4<VEC, NFA_NT_VIS>(prefix, q, r.pf);
         if (DENSITY) {
-            ld4<VEC>(ts, q, r.a);
-            ld4<VEC>(te, q, r.b);
+            ld4<VEC, NFA_NT_VIS>(ts, q, r.a);
+            ld4<VEC, NFA_NT_VIS>(te, q, r.b);
         }
     }
     __device__ __forceinline__ void load(const Raw &r, const Pos &pos)
@@ -1263,9 +1272,9 @@ struct RenderFusedFwdOp : OpBase1 {
     float xs[SE], mid[SE], rw[SE], rt[SE], ra[SE], c[3 * SE];
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
-        ld4<VEC>(ts, q, r.a);
-        ld4<VEC>(te, q, r.b);
-        ld4<VEC>(sig, q, r.s);
+        ld4<VEC, NFA_NT_FWD>(ts, q, r.a);
+        ld4<VEC, NFA_NT_FWD>(te, q, r.b);
+        ld4<VEC, NFA_NT_FWD>(sig, q, r.s);
         load_rgb12(rgb, VEC, q, r.c);
     }
     __device__ __forceinline__ void load(const Raw &r, const Pos &pos)
