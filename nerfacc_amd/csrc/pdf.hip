@@ -612,6 +612,89 @@ __global__ __launch_bounds__(256) void pdf_loss_bwd_kernel(const float *__restri
     }
 }
 
+// The backward for short rows, in the style of the forward: one query interval per lane, the key-CDF rows of the group in
+// LDS (coalesced loads, requested one group ahead together with the lane's id / query weights / loss gradient), so that
+// nothing in a group waits for a gather that depends on another load of the same group.
+template <int LL>
+__global__ __launch_bounds__(256) void pdf_loss_bwd_rows_kernel(const float *__restrict__ q_cdfs, const float *__restrict__ k_cdfs,
+                                                                const uint32_t *__restrict__ ids, int64_t n_rays, int Q1, int K1,
+                                                                float eps, const float *__restrict__ g_loss,
+                                                                float *__restrict__ g_k_cdfs, float *__restrict__ g_q_cdfs)
+{
+    constexpr int RPW = 64 / LL;
+    constexpr int STAGE = PL_STAGE_MAX / 2, SLOTS = STAGE / 64;
+    __shared__ float s_kc[4][STAGE];
+    __shared__ float s_gk[4][STAGE];
+    __shared__ float s_gq[4][64 + RPW];      // RPW rows of Q1 <= LL + 1 entries
+    const int lane = lane_id(), gl = lane & (LL - 1), grp = lane / LL, Q = Q1 - 1;
+    float *kc = s_kc[threadIdx.x >> 6], *gk = s_gk[threadIdx.x >> 6], *gq = s_gq[threadIdx.x >> 6];
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    float pkc[SLOTS], pq0, pq1, pg;
+    uint32_t pid;
+    auto rows_here = [&](int64_t r0) { return (int)min((int64_t)RPW, n_rays - r0); };
+    auto prefetch = [&](int64_t r0) {
+        const float *c = k_cdfs + r0 * K1;
+        const int n_h = rows_here(r0) * K1;
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k)
+            if (64 * k < n_h) {  // wave-uniform
+                const int f = lane + 64 * k;
+                pkc[k] = c[f < n_h ? f : 0];
+            }
+        const bool ok = (r0 + grp < n_rays) && gl < Q;
+        const int qo = ok ? grp * Q1 + gl : 0, lo = ok ? grp * Q + gl : 0;
+        const float *qc = q_cdfs + r0 * Q1;
+        pq0 = qc[qo]; pq1 = qc[qo + 1];
+        pid = (ids + r0 * Q)[lo];
+        pg = (g_loss + r0 * Q)[lo];
+    };
+    int64_t r0 = uniform64_pdf(wave * RPW);
+    if (r0 < n_rays) prefetch(r0);
+    while (r0 < n_rays) {
+        const int64_t r_next = r0 + n_waves * RPW;
+        const int n_r = rows_here(r0), n_h = n_r * K1;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k)
+            if (64 * k < n_h) {
+                const int f = lane + 64 * k;
+                if (f < n_h) { kc[f] = pkc[k]; gk[f] = 0.0f; }
+            }
+        if (g_q_cdfs) for (int f = lane; f < n_r * Q1; f += 64) gq[f] = 0.0f;
+        const uint32_t id = pid;
+        const float w = pq1 - pq0, g = pg;
+        __builtin_amdgcn_wave_barrier();
+        if (r_next < n_rays) prefetch(r_next);
+        const bool ok = (r0 + grp < n_rays) && gl < Q;
+        const int kb = (r0 + grp < n_rays) ? grp * K1 : 0;
+        const int left = min((int)(id & 0xFFFFu), K1 - 1), right = min((int)(id >> 16), K1 - 1);
+        const float d = fmaxf(w - (kc[kb + right] - kc[kb + left]), 0.0f);
+        if (ok && d > 0.0f) {
+            // d l / d wo = -2 d / (w + eps);  d l / d w = 2 d / (w + eps) - d^2 / (w + eps)^2
+            const float inv = 1.0f / (w + eps);
+            const float gwo = -2.0f * d * inv * g;
+            atomicAdd(&gk[kb + right], gwo);
+            atomicAdd(&gk[kb + left], -gwo);
+            if (g_q_cdfs) {
+                const float gw = (2.0f * d * inv - d * d * inv * inv) * g;
+                atomicAdd(&gq[grp * Q1 + gl + 1], gw);
+                atomicAdd(&gq[grp * Q1 + gl], -gw);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        float *ok_rows = g_k_cdfs + r0 * K1;
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k)
+            if (64 * k < n_h) {
+                const int f = lane + 64 * k;
+                if (f < n_h) ok_rows[f] = gk[f];
+            }
+        if (g_q_cdfs) for (int f = lane; f < n_r * Q1; f += 64) (g_q_cdfs + r0 * Q1)[f] = gq[f];
+        r0 = r_next;
+    }
+}
+
 }  // namespace nfa
 
 using namespace nfa;
@@ -778,6 +861,22 @@ int nfa_pdf_loss_bwd(const float *q_cdfs, const float *k_cdfs, const uint32_t *k
     NFA_REQUIRE(q_cdfs && k_cdfs && key_ids && g_loss && g_k_cdfs, "pdf_loss_bwd: null pointer");
     const int L = pdf_loss_lanes(n_query_edges - 1, n_key_edges, n_query_edges);
     const unsigned grid = grid_1d(ceil_div64(n_rays, 64 / L) * 64, 256, 1 << 16);
+    if (n_query_edges - 1 <= L && (64 / L) * n_key_edges <= PL_STAGE_MAX / 2) {
+#define NFA_PLB_ROWS(LL)                                                                                                  \
+    hipLaunchKernelGGL(pdf_loss_bwd_rows_kernel<LL>, dim3(grid), dim3(256), 0, as_stream(stream), q_cdfs, k_cdfs, key_ids, n_rays, \
+                       (int)n_query_edges, (int)n_key_edges, eps, g_loss, g_k_cdfs, g_q_cdfs)
+        switch (L) {
+            case 2: NFA_PLB_ROWS(2); break;
+            case 4: NFA_PLB_ROWS(4); break;
+            case 8: NFA_PLB_ROWS(8); break;
+            case 16: NFA_PLB_ROWS(16); break;
+            case 32: NFA_PLB_ROWS(32); break;
+            default: NFA_PLB_ROWS(64); break;
+        }
+#undef NFA_PLB_ROWS
+        NFA_CHECK_LAUNCH("pdf_loss_bwd");
+        return NFA_OK;
+    }
     hipLaunchKernelGGL(pdf_loss_bwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), q_cdfs, k_cdfs, key_ids, n_rays,
                        (int)n_query_edges, (int)n_key_edges, L, eps, g_loss, g_k_cdfs, g_q_cdfs);
     NFA_CHECK_LAUNCH("pdf_loss_bwd");
