@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void importance_sampling_kernel(
 //   * the s -> t mapping is applied to the lane's edge and to the next one (a shuffle), so t_starts / t_ends are written as
 //     two plain coalesced rows;
 //   * rows are addressed as a scalar 64-bit base per group plus 32-bit lane offsets.
-template <int LL>
+template <int LL, int NB /* blocks of LL samples per ray: sample i * LL + lane-in-group, so that S <= LL * NB */>
 __global__ __launch_bounds__(256) void importance_sampling_rows_kernel(
     const float *__restrict__ in_vals, const float *__restrict__ cdfs, int64_t n_rays, int n_edges, int S, int n_rounds, int RB,
     int stratified, uint64_t seed, uint64_t offset, float *__restrict__ out_iv, float *__restrict__ out_sm, int transform,
@@ -276,39 +276,68 @@ __global__ __launch_bounds__(256) void importance_sampling_rows_kernel(
             __builtin_amdgcn_wave_barrier();
             if (next_rb < n_rays) prefetch(next_rb + next_sub);
         }
-        const bool ok = (r0 + grp < n_rays) && gl < S;
-        const int lbase = (r0 + grp < n_rays) ? grp * n_edges : 0, llast = lbase + n_edges - 1;
+        const bool ray_ok = r0 + grp < n_rays;
+        const int lbase = ray_ok ? grp * n_edges : 0, llast = lbase + n_edges - 1;
         const float u_floor = lc[lbase], u_ceil = lc[llast], t_min = lv[lbase], t_max = lv[llast];
         const float u_step = (u_ceil - u_floor) / (float)S;
-        const float u = u_floor + ((float)gl + bias) * u_step;       // pdf.cu:133-137
-        int start = lbase, end = llast;                                // upper_bound over [lbase, llast), pdf.cu:43-63
-        for (int it = 0; it < n_rounds; ++it) {
-            const bool act = start < end;
-            const int mid = start + ((end - start) >> 1);
-            const bool right = !(lc[act ? mid : lbase] > u);
-            start = (act && right) ? mid + 1 : start;
-            end = (act && !right) ? mid : end;
+        // the NB samples of the lane: their bisections run together (upper_bound over [lbase, llast), pdf.cu:43-63, 133-137)
+        float u[NB];
+        int start[NB], end[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            u[i] = u_floor + ((float)(i * LL + gl) + bias) * u_step;
+            start[i] = lbase; end[i] = llast;
         }
-        const int p0 = min(max(start - 1, lbase), llast), p1 = min(max(start, lbase), llast);
-        const float u_lower = lc[p0], u_upper = lc[p1], t_lower = lv[p0], t_upper = lv[p1];
-        const float du = u_upper - u_lower;
-        const float t = du < 1e-10f ? (t_lower + t_upper) * 0.5f : (u - u_lower) * ((t_upper - t_lower) / du) + t_lower;
-        const int row = grp * S + gl;
-        if (out_sm && ok) (out_sm + r0 * S)[row] = t;
-        // the lane's edge k = gl and, for the ray's last sample, the edge S (pdf.cu:205-239)
-        const float t_prev = __shfl_up(t, 1, LL), t_next = __shfl_down(t, 1, LL);
-        float e = gl == 0 ? fmaxf(t - (t_next - t) * 0.5f, t_min) : (t + t_prev) * 0.5f;
-        float e_last = fminf(t + (t - t_prev) * 0.5f, t_max);
-        if (S == 1) { e = t_min; e_last = t_max; }  // one sample: its interval is the ray's whole range
-        float *iv = out_iv + r0 * (S + 1);
-        if (ok) iv[grp * (S + 1) + gl] = e;
-        if (ok && gl == S - 1) iv[grp * (S + 1) + S] = e_last;
+        for (int it = 0; it < n_rounds; ++it) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const bool act = start[i] < end[i];
+                const int mid = start[i] + ((end[i] - start[i]) >> 1);
+                const bool right = !(lc[act ? mid : lbase] > u[i]);
+                start[i] = (act && right) ? mid + 1 : start[i];
+                end[i] = (act && !right) ? mid : end[i];
+            }
+        }
+        float t[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int p0 = min(max(start[i] - 1, lbase), llast), p1 = min(max(start[i], lbase), llast);
+            const float u_lower = lc[p0], u_upper = lc[p1], t_lower = lv[p0], t_upper = lv[p1];
+            const float du = u_upper - u_lower;
+            t[i] = du < 1e-10f ? (t_lower + t_upper) * 0.5f : (u[i] - u_lower) * ((t_upper - t_lower) / du) + t_lower;
+        }
+        // edges (pdf.cu:205-239): the lane forms edge k = sample id of each of its samples, the ray's last sample also edge S
+        float *iv = out_iv + r0 * (S + 1) + grp * (S + 1);
+        float e[NB], te0[NB];
+        float e_last = 0.0f;
+        auto map = [&](float x) { const float lin = x * t_b + (1.0f - x) * t_a; return transform == 2 ? 1.0f / lin : lin; };
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int sid = i * LL + gl;
+            float t_prev = __shfl_up(t[i], 1, LL);
+            const float t_carry = __shfl(t[i > 0 ? i - 1 : 0], LL - 1, LL);   // (every lane takes part in a shuffle)
+            if (i > 0 && gl == 0) t_prev = t_carry;
+            const float t_next = __shfl_down(t[i], 1, LL);   // only the first sample of a ray looks at it (S >= 2: lane 1 holds t_1)
+            e[i] = sid == 0 ? fmaxf(t[i] - (t_next - t[i]) * 0.5f, t_min) : (t[i] + t_prev) * 0.5f;
+            if (S == 1) e[i] = t_min;  // one sample: its interval is the ray's whole range
+            const bool ok = ray_ok && sid < S;
+            if (sid == S - 1) e_last = S == 1 ? t_max : fminf(t[i] + (t[i] - t_prev) * 0.5f, t_max);
+            if (out_sm && ok) (out_sm + r0 * S)[grp * S + sid] = t[i];
+            if (ok) iv[sid] = e[i];
+            if (ok && sid == S - 1) iv[S] = e_last;
+            te0[i] = transform ? map(e[i]) : 0.0f;
+        }
         if (transform) {
-            auto map = [&](float x) { const float lin = x * t_b + (1.0f - x) * t_a; return transform == 2 ? 1.0f / lin : lin; };
-            const float te0 = map(e);
-            float te1 = __shfl_down(te0, 1, LL);
-            if (gl == S - 1) te1 = map(e_last);
-            if (ok) { (out_ts + r0 * S)[row] = te0; (out_te + r0 * S)[row] = te1; }
+            const float te_last = map(e_last);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int sid = i * LL + gl;
+                float te1 = __shfl_down(te0[i], 1, LL);
+                const float te_first = __shfl(te0[i + 1 < NB ? i + 1 : i], 0, LL);
+                if (i + 1 < NB && gl == LL - 1) te1 = te_first;
+                if (sid == S - 1) te1 = te_last;
+                if (ray_ok && sid < S) { (out_ts + r0 * S)[grp * S + sid] = te0[i]; (out_te + r0 * S)[grp * S + sid] = te1; }
+            }
         }
     }
 }
@@ -724,17 +753,27 @@ static int launch_importance_sampling(const float *in_vals, const float *cdfs, c
     if (staged && n_samples <= 64 && n_edges_per_ray < (1 << 20)) {
         int n_rounds = 0;
         while ((1 << n_rounds) <= (int)n_edges_per_ray - 1) ++n_rounds;   // rounds until a range of n_edges - 1 entries is empty
-#define NFA_IS_ROWS(LL)                                                                                                  \
-    hipLaunchKernelGGL(importance_sampling_rows_kernel<LL>, dim3(grid), dim3(256), 0, as_stream(stream), in_vals, cdfs, n_rays, \
-                       (int)n_edges_per_ray, (int)n_samples, n_rounds, RB, stratified, seed, offset, out_intervals, out_samples, \
+        // more than 16 samples per ray: 16 lanes per ray and 2 or 4 samples per lane (4 rays per group instead of 1-2:
+        // the per-group work is shared and a lane's bisections overlap), if four CDF rows fit the stage
+        const bool blocks = n_samples > 16 && 4 * n_edges_per_ray <= IS_STAGE_MAX;
+        const int LL = blocks ? 16 : L, NB = blocks ? (n_samples > 32 ? 4 : 2) : 1;
+        const int64_t rpw = 64 / LL;
+        int RBk = (int)rpw;
+        while (RBk < 64 && n_rays / (2 * RBk) >= 4096) RBk <<= 1;
+        const unsigned gridk = grid_1d(ceil_div64(n_rays, (int64_t)RBk) * 64, 256, 1 << 16);
+#define NFA_IS_ROWS(L_, NB_)                                                                                              \
+    hipLaunchKernelGGL((importance_sampling_rows_kernel<L_, NB_>), dim3(gridk), dim3(256), 0, as_stream(stream), in_vals, cdfs, n_rays, \
+                       (int)n_edges_per_ray, (int)n_samples, n_rounds, RBk, stratified, seed, offset, out_intervals, out_samples, \
                        transform, t_a, t_b, out_ts, out_te)
-        switch (L) {
-            case 2: NFA_IS_ROWS(2); break;
-            case 4: NFA_IS_ROWS(4); break;
-            case 8: NFA_IS_ROWS(8); break;
-            case 16: NFA_IS_ROWS(16); break;
-            case 32: NFA_IS_ROWS(32); break;
-            default: NFA_IS_ROWS(64); break;
+        if (NB == 4) NFA_IS_ROWS(16, 4);
+        else if (NB == 2) NFA_IS_ROWS(16, 2);
+        else switch (LL) {
+            case 2: NFA_IS_ROWS(2, 1); break;
+            case 4: NFA_IS_ROWS(4, 1); break;
+            case 8: NFA_IS_ROWS(8, 1); break;
+            case 16: NFA_IS_ROWS(16, 1); break;
+            case 32: NFA_IS_ROWS(32, 1); break;
+            default: NFA_IS_ROWS(64, 1); break;
         }
 #undef NFA_IS_ROWS
     } else if (staged)

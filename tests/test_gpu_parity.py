@@ -871,7 +871,7 @@ def test_importance_sampling_and_searchsorted(dev, oracle):
     # over the lanes (R >= 65536 for 8 rays per group), a ragged last block, S == 1, S == lanes
     R2 = 70001
     v2 = np.sort(rng.random((R2, 9)), -1).astype(np.float32); c2 = np.sort(rng.random((R2, 9)), -1).astype(np.float32)
-    for S2, strat in ((8, True), (5, False), (64, True)):
+    for S2, strat in ((8, True), (5, False), (64, True), (24, True), (33, False)):
         seed, off = gen.initial_seed(), gen.get_offset()
         r_iv, r_sm = na.importance_sampling(na.RayIntervals(vals=T(v2, dev)), T(c2, dev), S2, stratified=strat)
         e_iv, e_sm = oracle.importance_sampling(v2, c2, S2, strat, seed=seed, offset=off)
