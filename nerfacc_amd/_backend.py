@@ -75,6 +75,8 @@ _SIGS = {
     "nfa_render_from_density_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
     "nfa_render_from_alpha_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],
     "nfa_render_from_density_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],
+    "nfa_density_cdf_rows_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp],
+    "nfa_density_cdf_rows_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp],
     "nfa_render_from_alpha_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp],
     "nfa_render_visibility": [_vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],
     "nfa_compact_samples": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp],

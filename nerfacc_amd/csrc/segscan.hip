@@ -697,6 +697,11 @@ struct DensityFwdOp : OpBase1 {
     struct Raw { F4 a, b, s, pf; };
     const float *ts, *te, *sig, *prefix;
     float *w, *tr, *al;
+    // batched rows of row_len samples (PropNetEstimator): the resampler's CDF rows `1 - cat([T, 0])` (row_len + 1 entries,
+    // ref estimators/prop_net.py:104-107) written by the same pass; element p of ray r lands at p + r
+    float *cdf = nullptr;
+    int32_t row_len = 0;
+    int32_t crid[SE];
     float xs[SE], pf[SE], rw[SE], rt[SE], ra[SE];
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
@@ -715,13 +720,17 @@ struct DensityFwdOp : OpBase1 {
         }
     }
     __device__ __forceinline__ float x(int j, int) const { return xs[j]; }
-    __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int, int, const float *, const float prev[1])
+    __device__ __forceinline__ void emit(int j, int64_t pos, bool valid, bool is_head, int rid, int, const float *, const float prev[1])
     {
         const float S = is_head ? 0.0f : prev[0];
         float T = expf(-S);
         if (prefix) T *= pf[j];
         const float a = 1.0f - expf(-xs[j]);
         rt[j] = T; ra[j] = a; rw[j] = T * a;
+        if (cdf) {
+            crid[j] = rid;
+            if (valid && is_head) cdf[pos + rid + row_len] = 1.0f;   // the row's last entry, 1 - 0
+        }
     }
     __device__ __forceinline__ void store(const Pos &q)
     {
@@ -731,6 +740,23 @@ struct DensityFwdOp : OpBase1 {
         if (w) store4<VEC>(w, q, rw);
         if (tr) store4<VEC>(tr, q, rt);
         if (al) store4<VEC>(al, q, ra);
+        if (cdf) {
+            // a quad inside one row is one 16-byte store at a 4-byte aligned address (rows are shifted by their index)
+            struct __attribute__((packed, aligned(4))) Q4 { float x, y, z, w; };
+            float *b = cdf + q.c;
+#pragma unroll
+            for (int h = 0; h < SQ; ++h) {
+                if (q.qall[h] && crid[4 * h] == crid[4 * h + 3]) {
+                    Q4 v = {1.0f - rt[4 * h], 1.0f - rt[4 * h + 1], 1.0f - rt[4 * h + 2], 1.0f - rt[4 * h + 3]};
+                    *reinterpret_cast<Q4 *>(b + q.off + 4 * h + crid[4 * h]) = v;
+                } else {
+                    volatile float *pv = b;
+#pragma unroll
+                    for (int j = 4 * h; j < 4 * h + 4; ++j)
+                        if (q.valid[j]) pv[q.off + j + crid[j]] = 1.0f - rt[j];
+                }
+            }
+        }
     }
 };
 
@@ -780,12 +806,39 @@ struct AlphaFwdOp {
 };
 
 // ---- backward of the fused density op (reverse scan), SURVEY App. A.7
-template <bool VEC>
+template <bool VEC, bool CDF = false /* the gradient arrives at the CDF rows of DensityFwdOp::cdf: g_T[p] = -g_cdf[p + ray] */>
 struct DensityBwdOp : OpBase1 {
+    static constexpr bool NEEDS_RID = CDF;
     struct Raw { F4 a, b, T, A, gw, gt, ga; };
     const float *ts, *te, *tr, *al, *gw, *gt, *ga;
+    const float *gcdf = nullptr;
     float *gsig, *gx;
     float T[SE], A[SE], GW[SE], GA[SE], dlt[SE], q[SE], rs[SE], rx[SE];
+    int32_t crid[SE];
+    __device__ __forceinline__ void pre(int j, int64_t, bool, int rid) { crid[j] = rid; }
+    // (called after the ray ids of all the lane's elements are known: a quad inside one row is one 16-byte load)
+    __device__ __forceinline__ void store_pre(const Pos &pq)
+    {
+        struct __attribute__((packed, aligned(4))) Q4 { float x, y, z, w; };
+        const float *b = gcdf + pq.c;
+#pragma unroll
+        for (int h = 0; h < SQ; ++h) {
+            float g4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (pq.qall[h] && crid[4 * h] == crid[4 * h + 3]) {
+                const Q4 v = *reinterpret_cast<const Q4 *>(b + pq.off + 4 * h + crid[4 * h]);
+                g4[0] = v.x; g4[1] = v.y; g4[2] = v.z; g4[3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (pq.valid[4 * h + j]) g4[j] = b[pq.off + 4 * h + j + crid[4 * h + j]];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float GT = -g4[j];
+                q[4 * h + j] = GW[4 * h + j] * (T[4 * h + j] * A[4 * h + j]) + GT * T[4 * h + j];
+            }
+        }
+    }
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
         ld4<VEC>(ts, q, r.a);
@@ -1728,6 +1781,46 @@ int nfa_render_from_density_bwd(const float *t_starts, const float *t_ends, cons
     if (vec) NFA_DB(true); else NFA_DB(false);
 #undef NFA_DB
     NFA_CHECK_LAUNCH("render_from_density_bwd");
+    return NFA_OK;
+}
+
+int nfa_density_cdf_rows_fwd(const float *t_starts, const float *t_ends, const float *sigmas, const int64_t *packed_info,
+                             const int64_t *tiles, int64_t n_tiles, int64_t n_rays, int64_t n_elems, int32_t row_len,
+                             float *trans, float *alphas, float *cdfs, nfa_stream_t stream)
+{
+    SEG_COMMON_CHECKS("density_cdf_rows_fwd");
+    if (n_elems == 0) return NFA_OK;
+    NFA_REQUIRE(t_starts && t_ends && sigmas && cdfs, "density_cdf_rows_fwd: null pointer");
+    NFA_REQUIRE(row_len >= 1 && n_rays * (int64_t)row_len == n_elems, "density_cdf_rows_fwd: n_elems must be n_rays * row_len");
+    hipStream_t s = as_stream(stream);
+    const bool vec = all_aligned16(t_starts, t_ends, sigmas, trans, alphas);
+#define NFA_DC(V)                                                                                          \
+    do { DensityFwdOp<V> op; op.ts = t_starts; op.te = t_ends; op.sig = sigmas; op.prefix = nullptr;         \
+         op.w = nullptr; op.tr = trans; op.al = alphas; op.cdf = cdfs; op.row_len = row_len;                \
+         launch_seg<1>(op, packed_info, tiles, n_rays, n_tiles, s); } while (0)
+    if (vec) NFA_DC(true); else NFA_DC(false);
+#undef NFA_DC
+    NFA_CHECK_LAUNCH("density_cdf_rows_fwd");
+    return NFA_OK;
+}
+
+int nfa_density_cdf_rows_bwd(const float *t_starts, const float *t_ends, const float *trans, const float *alphas,
+                             const float *g_cdfs, const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles,
+                             int64_t n_rays, int64_t n_elems, int32_t row_len, float *grad_sigmas, nfa_stream_t stream)
+{
+    SEG_COMMON_CHECKS("density_cdf_rows_bwd");
+    if (n_elems == 0) return NFA_OK;
+    NFA_REQUIRE(t_starts && t_ends && trans && alphas && g_cdfs && grad_sigmas, "density_cdf_rows_bwd: null pointer");
+    NFA_REQUIRE(row_len >= 1 && n_rays * (int64_t)row_len == n_elems, "density_cdf_rows_bwd: n_elems must be n_rays * row_len");
+    hipStream_t s = as_stream(stream);
+    const bool vec = all_aligned16(t_starts, t_ends, trans, alphas, grad_sigmas);
+#define NFA_DCB(V)                                                                                         \
+    do { DensityBwdOp<V, true> op; op.ts = t_starts; op.te = t_ends; op.tr = trans; op.al = alphas; op.gw = nullptr; \
+         op.gt = nullptr; op.ga = nullptr; op.gcdf = g_cdfs; op.gsig = grad_sigmas; op.gx = nullptr;          \
+         launch_seg<-1>(op, packed_info, tiles, n_rays, n_tiles, s); } while (0)
+    if (vec) NFA_DCB(true); else NFA_DCB(false);
+#undef NFA_DCB
+    NFA_CHECK_LAUNCH("density_cdf_rows_bwd");
     return NFA_OK;
 }
 

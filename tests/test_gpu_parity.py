@@ -1086,6 +1086,35 @@ def test_traversal_fuzz_bit_exact(dev, oracle):
             assert (ri.cpu().numpy() == rsm["ray_indices"][keep]).all() and (ts.cpu().numpy() == L).all() and (te.cpu().numpy() == Rr).all(), case
 
 
+def test_cdf_rows_fused_with_the_transmittance_pass(dev):
+    """PropNetEstimator's level step `1 - cat([T(sigma), 0])` as one engine pass (nfa_density_cdf_rows_fwd / _bwd) against
+    the two-step form (render_transmittance_from_density, then the complement): same bits forward and backward; ragged
+    row lengths around the engine's step / tile sizes."""
+    from nerfacc_amd.estimators import prop_net as PN
+    rng = np.random.default_rng(31)
+    for R, S in ((513, 64), (1000, 17), (3, 1), (257, 300), (70, 1025)):
+        ts0 = np.sort(rng.uniform(0.1, 5.0, (R, S + 1)).astype(np.float32), -1)
+        ts, te = T(ts0[:, :-1].copy(), dev), T(ts0[:, 1:].copy(), dev)
+        sg_np = rng.uniform(0.0, 6.0, (R, S)).astype(np.float32)
+        gc = T(rng.normal(size=(R, S + 1)).astype(np.float32), dev)
+        outs = []
+        for fuse in (True, False):
+            PN.FUSE_CDFS = fuse
+            try:
+                sg = T(sg_np, dev).requires_grad_(True)
+                cd = PN._cdfs_from_density(ts, te, sg)
+                (cd * gc).sum().backward()
+                with torch.no_grad():
+                    cd_ng = PN._cdfs_from_density(ts, te, sg.detach())
+            finally:
+                PN.FUSE_CDFS = True
+            outs.append((cd.detach(), sg.grad.clone(), cd_ng))
+        (c1, g1, n1), (c0, g0, n0) = outs
+        assert c1.shape == (R, S + 1) and torch.equal(c1, c0) and torch.equal(n1, c1) and torch.equal(n0, c0)
+        assert torch.equal(g1, g0)
+        assert float(c1[:, -1].min()) == 1.0 and float(c1[:, 0].max()) == 0.0      # T_0 = 1, the appended 0
+
+
 def test_pdf_loss_fused_matches_composition(dev):
     """The batched interlevel loss as one native pass each way against the reference's composition (searchsorted +
     gathers + elementwise, prop_net.py:232-256) evaluated with torch autograd: values and both gradients."""
