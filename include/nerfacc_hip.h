@@ -269,7 +269,8 @@ int nfa_render_from_density_bwd(const float *t_starts, const float *t_ends, cons
 /* PropNetEstimator's level loop for batched rows of row_len samples (ref: estimators/prop_net.py:96-107, 139-142):
  * transmittance from the proposal density AND the resampler's CDF rows `1 - cat([T, 0], -1)` ([n_rays, row_len + 1]) in
  * one pass, and the backward from the gradient at those rows (g_T = -g_cdfs[:, :-1]) to the densities.  packed_info /
- * tiles describe n_rays chunks of exactly row_len elements.  Same arithmetic as nfa_render_from_density_{fwd,bwd}. */
+ * tiles describe n_rays chunks of exactly row_len elements.  Same arithmetic as nfa_render_from_density_{fwd,bwd};
+ * alphas may be NULL in both (with only g_T arriving, alpha drops out of the backward). */
 int nfa_density_cdf_rows_fwd(const float *t_starts, const float *t_ends, const float *sigmas, const int64_t *packed_info,
                              const int64_t *tiles, int64_t n_tiles, int64_t n_rays, int64_t n_elems, int32_t row_len,
                              float *trans, float *alphas, float *cdfs /*[n_rays, row_len + 1]*/, nfa_stream_t stream);

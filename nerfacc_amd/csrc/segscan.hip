@@ -844,7 +844,7 @@ struct DensityBwdOp : OpBase1 {
         ld4<VEC>(ts, q, r.a);
         ld4<VEC>(te, q, r.b);
         ld4<VEC>(tr, q, r.T);
-        ld4<VEC>(al, q, r.A);
+        if (!CDF) ld4<VEC>(al, q, r.A);   // (with only g_T arriving alpha drops out: B = -E, q = g_T T)
         if (gw) ld4<VEC>(gw, q, r.gw);
         if (gt) ld4<VEC>(gt, q, r.gt);
         if (ga) ld4<VEC>(ga, q, r.ga);
@@ -854,7 +854,7 @@ struct DensityBwdOp : OpBase1 {
         const bool *valid = pos.valid;
 #pragma unroll
         for (int j = 0; j < SE; ++j) {
-            T[j] = sel(r.T, j, valid, 0.0f); A[j] = sel(r.A, j, valid, 0.0f);
+            T[j] = sel(r.T, j, valid, 0.0f); A[j] = CDF ? 0.0f : sel(r.A, j, valid, 0.0f);
             GW[j] = (gw && valid[j]) ? r.gw.v[j] : 0.0f;
             const float GT = (gt && valid[j]) ? r.gt.v[j] : 0.0f;
             GA[j] = (ga && valid[j]) ? r.ga.v[j] : 0.0f;
@@ -1810,7 +1810,8 @@ int nfa_density_cdf_rows_bwd(const float *t_starts, const float *t_ends, const f
 {
     SEG_COMMON_CHECKS("density_cdf_rows_bwd");
     if (n_elems == 0) return NFA_OK;
-    NFA_REQUIRE(t_starts && t_ends && trans && alphas && g_cdfs && grad_sigmas, "density_cdf_rows_bwd: null pointer");
+    NFA_REQUIRE(t_starts && t_ends && trans && g_cdfs && grad_sigmas, "density_cdf_rows_bwd: null pointer");
+    (void)alphas;  // not needed: only the transmittance carries a gradient
     NFA_REQUIRE(row_len >= 1 && n_rays * (int64_t)row_len == n_elems, "density_cdf_rows_bwd: n_elems must be n_rays * row_len");
     hipStream_t s = as_stream(stream);
     const bool vec = all_aligned16(t_starts, t_ends, trans, alphas, grad_sigmas);

@@ -159,26 +159,26 @@ class _CdfsFromDensity(torch.autograd.Function):
     def forward(ctx, t_starts: Tensor, t_ends: Tensor, sigmas: Tensor, seg) -> Tensor:
         ts, te, sg = t_starts.contiguous(), t_ends.contiguous(), sigmas.contiguous()
         R, S = sg.shape
-        trans, alphas = torch.empty_like(sg), torch.empty_like(sg)
+        trans = torch.empty_like(sg)   # (alphas are neither written nor read: only T carries a gradient here)
         cdfs = sg.new_empty((R, S + 1))
         with torch.cuda.device(sg.device):
             B.call("nfa_density_cdf_rows_fwd", B.ptr(ts), B.ptr(te), B.ptr(sg), B.ptr(seg.packed_info), B.ptr(seg.tiles),
-                   seg.n_tiles, seg.n_rays, sg.numel(), S, B.ptr(trans), B.ptr(alphas), B.ptr(cdfs), B.stream())
+                   seg.n_tiles, seg.n_rays, sg.numel(), S, B.ptr(trans), None, B.ptr(cdfs), B.stream())
         ctx.seg = seg
-        ctx.save_for_backward(ts, te, trans, alphas)
+        ctx.save_for_backward(ts, te, trans)
         return cdfs
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g: Tensor):
-        ts, te, trans, alphas = ctx.saved_tensors
+        ts, te, trans = ctx.saved_tensors
         seg = ctx.seg
         if not ctx.needs_input_grad[2]:
             return None, None, None, None
         g = g.contiguous()
         g_sig = torch.empty_like(trans)
         with torch.cuda.device(trans.device):
-            B.call("nfa_density_cdf_rows_bwd", B.ptr(ts), B.ptr(te), B.ptr(trans), B.ptr(alphas), B.ptr(g), B.ptr(seg.packed_info),
+            B.call("nfa_density_cdf_rows_bwd", B.ptr(ts), B.ptr(te), B.ptr(trans), None, B.ptr(g), B.ptr(seg.packed_info),
                    B.ptr(seg.tiles), seg.n_tiles, seg.n_rays, trans.numel(), trans.shape[-1], B.ptr(g_sig), B.stream())
         return None, None, g_sig, None
 
