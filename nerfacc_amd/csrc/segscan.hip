@@ -1013,6 +1013,14 @@ __device__ __forceinline__ float mask_sel(const U4 &m, int j, const bool valid[S
 // ---- compaction of the visible samples (per-ray output offsets = cumsum of VisibilityOp's counts)
 template <bool VEC>
 struct CompactOp : OpBase1 {
+    // The kept samples of a step go to CONSECUTIVE output positions (out_starts is the running sum of the per-ray counts and
+    // a ray's kept samples are numbered by the scan), so the wave packs them in LDS and writes them out as 16-byte vectors,
+    // 4 outputs per lane, instead of three predicated 4/8-byte scatters per element.  A caller whose out_starts are not that
+    // running sum still gets every sample written (element-wise fallback, decided per step).
+    // The output offsets of the tile's rays (consecutive rays) are staged in LDS when the tile starts, like the fused
+    // backward's per-ray gradients: per element they would be a gather that depends on the ray id.
+    static constexpr int RAY_CAP = 192;
+    static constexpr int RAY_LDS_FLOATS = 3 * SEG_CHUNK + 2 * RAY_CAP;
     struct Raw { U4 m; F4 a, b; };
     const uint8_t *vis;
     int vis_vec;
@@ -1020,7 +1028,21 @@ struct CompactOp : OpBase1 {
     const int64_t *out_starts;
     int64_t *o_ri;
     float *o_ts, *o_te;
+    float *stage = nullptr;
+    const int64_t *s_start = nullptr;
+    int32_t g_lo = 0, g_n = 0;
     float m[SE], a[SE], b[SE];
+    int64_t dst[SE];
+    int32_t er[SE];
+    __device__ __forceinline__ void tile_begin(int32_t r_lo, int32_t r_hi, float *lds)
+    {
+        stage = lds;
+        int64_t *st = reinterpret_cast<int64_t *>(lds + 3 * SEG_CHUNK);   // (8-byte aligned: the per-wave block is 16-byte aligned)
+        s_start = st; g_lo = r_lo; g_n = min(r_hi - r_lo, RAY_CAP);
+        __builtin_amdgcn_wave_barrier();
+        for (int32_t i = lane_id(); i < g_n; i += 64) st[i] = out_starts[(int64_t)r_lo + i];
+        __builtin_amdgcn_wave_barrier();
+    }
     __device__ __forceinline__ void fetch(const Pos &q, Raw &r) const
     {
         load_mask4(vis, vis_vec != 0, q, r.m);
@@ -1036,12 +1058,72 @@ struct CompactOp : OpBase1 {
     __device__ __forceinline__ float x(int j, int) const { return m[j]; }
     __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int rid, int, const float *, const float prev[1])
     {
+        er[j] = rid;
+        dst[j] = 0;
         if (m[j] != 0.0f) {
-            const int64_t dst = out_starts[rid] + (int64_t)(is_head ? 0.0f : prev[0]);
-            o_ri[dst] = rid; o_ts[dst] = a[j]; o_te[dst] = b[j];
+            const uint32_t slot = (uint32_t)(rid - g_lo);
+            const int64_t start = slot < (uint32_t)g_n ? s_start[slot] : out_starts[rid];
+            dst[j] = start + (int64_t)(is_head ? 0.0f : prev[0]);
         }
     }
-    __device__ __forceinline__ void store(const Pos &) const {}
+    __device__ __forceinline__ void store(const Pos &)
+    {
+        struct __attribute__((packed, aligned(4))) Q4 { float x, y, z, w; };
+        struct __attribute__((packed, aligned(8))) L2 { int64_t x, y; };
+        bool keep[SE];
+        bool any = false;
+        int n_mine = 0;
+#pragma unroll
+        for (int j = 0; j < SE; ++j) { keep[j] = m[j] != 0.0f; any = any || keep[j]; n_mine += keep[j] ? 1 : 0; }
+        const unsigned long long lanes = __ballot(any);
+        if (lanes == 0ull) return;  // wave-uniform
+        const int lane = lane_id();
+        const int first = __builtin_ctzll(lanes), last = 63 - __builtin_clzll(lanes);
+        int64_t my_first = dst[SE - 1], my_last = dst[0];
+#pragma unroll
+        for (int j = SE - 2; j >= 0; --j) if (keep[j]) my_first = dst[j];
+#pragma unroll
+        for (int j = 1; j < SE; ++j) if (keep[j]) my_last = dst[j];
+        const int64_t base = uniform64(__shfl(my_first, first, 64));
+        const int64_t span = uniform64(__shfl(my_last, last, 64)) - base + 1;
+        // number kept in the step (sum over lanes): equals span exactly when the outputs are consecutive
+        int cnt = n_mine;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        if (span == (int64_t)cnt && span <= SEG_CHUNK) {
+            float *s_ts = stage, *s_te = stage + SEG_CHUNK;
+            int32_t *s_ri = reinterpret_cast<int32_t *>(stage + 2 * SEG_CHUNK);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < SE; ++j)
+                if (keep[j]) {
+                    const uint32_t o = (uint32_t)(dst[j] - base);
+                    if (o < (uint32_t)SEG_CHUNK) { s_ts[o] = a[j]; s_te[o] = b[j]; s_ri[o] = er[j]; }
+                }
+            __builtin_amdgcn_wave_barrier();
+            const int n = (int)span;
+            float *g_ts = o_ts + base, *g_te = o_te + base;
+            int64_t *g_ri = o_ri + base;
+            for (int o = 4 * lane; o < n; o += 256) {
+                if (o + 3 < n) {
+                    const Q4 vt = {s_ts[o], s_ts[o + 1], s_ts[o + 2], s_ts[o + 3]};
+                    const Q4 ve = {s_te[o], s_te[o + 1], s_te[o + 2], s_te[o + 3]};
+                    *reinterpret_cast<Q4 *>(g_ts + o) = vt;
+                    *reinterpret_cast<Q4 *>(g_te + o) = ve;
+                    const L2 r0 = {(int64_t)s_ri[o], (int64_t)s_ri[o + 1]}, r1 = {(int64_t)s_ri[o + 2], (int64_t)s_ri[o + 3]};
+                    *reinterpret_cast<L2 *>(g_ri + o) = r0;
+                    *reinterpret_cast<L2 *>(g_ri + o + 2) = r1;
+                } else {
+                    for (int i = o; i < n; ++i) { g_ts[i] = s_ts[i]; g_te[i] = s_te[i]; g_ri[i] = (int64_t)s_ri[i]; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+#pragma unroll
+            for (int j = 0; j < SE; ++j)
+                if (keep[j]) { o_ri[dst[j]] = er[j]; o_ts[dst[j]] = a[j]; o_te[dst[j]] = b[j]; }
+        }
+    }
 };
 
 // ---- per-ray accumulation of w * values[:, d0:d0+C], volrend.py:532-547
