@@ -1086,6 +1086,41 @@ def test_traversal_fuzz_bit_exact(dev, oracle):
             assert (ri.cpu().numpy() == rsm["ray_indices"][keep]).all() and (ts.cpu().numpy() == L).all() and (te.cpu().numpy() == Rr).all(), case
 
 
+def test_compact_samples_consecutive_and_arbitrary_output_offsets(dev):
+    """nfa_compact_samples through the C ABI: with the running-sum offsets the sampler passes (kept samples of a step are
+    consecutive outputs: packed in LDS, written as vectors) and with per-ray output blocks in REVERSE ray order (not
+    consecutive: the element-wise fallback) -- every kept sample lands at out_starts[ray] + its rank in the ray."""
+    from nerfacc_amd import _backend as B
+    from nerfacc_amd._segments import seginfo_from_packed
+    rng = np.random.default_rng(77)
+    for R, lam, p_keep in ((5000, 30, 0.6), (300, 400, 0.97), (2000, 3, 0.2), (64, 2000, 0.5)):
+        cnt = rng.poisson(lam, R).astype(np.int64)
+        cnt[rng.random(R) < 0.1] = 0
+        n = int(cnt.sum())
+        pi = np.stack([np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt], -1)
+        vis = (rng.random(n) < p_keep).astype(np.uint8)
+        ts = rng.random(n).astype(np.float32); te = ts + 1
+        ray = np.repeat(np.arange(R), cnt)
+        kept = np.bincount(ray[vis != 0], minlength=R).astype(np.int64)
+        m = int(kept.sum())
+        seg = seginfo_from_packed(torch.from_numpy(pi).to(dev), n)
+        fwd = np.concatenate([[0], np.cumsum(kept)[:-1]])
+        rev = np.concatenate([[0], np.cumsum(kept[::-1])[:-1]])[::-1].copy()     # ray R-1 first
+        for starts in (fwd, rev):
+            o_ri = torch.full((m,), -1, dtype=torch.int64, device=dev)
+            o_ts = torch.full((m,), -1.0, device=dev); o_te = torch.full((m,), -1.0, device=dev)
+            d = [torch.from_numpy(x).to(dev) for x in (vis, ts, te, starts)]
+            B.call("nfa_compact_samples", B.ptr(d[0]), B.ptr(d[1]), B.ptr(d[2]), B.ptr(seg.packed_info), B.ptr(seg.tiles),
+                   seg.n_tiles, B.ptr(d[3]), R, n, B.ptr(o_ri), B.ptr(o_ts), B.ptr(o_te), B.stream())
+            k = vis != 0
+            rank = np.concatenate([np.arange(c) for c in kept]) if m else np.zeros(0, np.int64)
+            want_pos = starts[ray[k]] + rank
+            e_ri = np.full(m, -1, np.int64); e_ts = np.full(m, -1, np.float32); e_te = np.full(m, -1, np.float32)
+            e_ri[want_pos] = ray[k]; e_ts[want_pos] = ts[k]; e_te[want_pos] = te[k]
+            assert np.array_equal(o_ri.cpu().numpy(), e_ri) and np.array_equal(o_ts.cpu().numpy(), e_ts)
+            assert np.array_equal(o_te.cpu().numpy(), e_te)
+
+
 def test_cdf_rows_fused_with_the_transmittance_pass(dev):
     """PropNetEstimator's level step `1 - cat([T(sigma), 0])` as one engine pass (nfa_density_cdf_rows_fwd / _bwd) against
     the two-step form (render_transmittance_from_density, then the complement): same bits forward and backward; ragged
