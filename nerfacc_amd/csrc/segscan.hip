@@ -145,9 +145,17 @@ __device__ __forceinline__ void ld4(const float *__restrict__ p, const Pos &q, F
 }
 __device__ __forceinline__ float sel(const F4 &r, int j, const bool valid[SE], float fill) { return valid[j] ? r.v[j] : fill; }
 
-// Full lanes store one 16-byte vector.  The per-element path (a lane straddling a range end) goes
-// through a volatile pointer: otherwise the compiler if-converts both paths into dwordx3 + dword
-// stores for EVERY lane, which halves the store rate.
+// Full lanes store one 16-byte vector.  The per-element path (a lane straddling a range end) starts with an opaque asm
+// statement: without it the compiler if-converts both paths into dwordx3 + dword stores for EVERY lane, which halves the
+// store rate.  (It used to go through a volatile pointer instead -- which compiles to system-scope flat stores with an
+// s_waitcnt vmcnt(0) after EACH of them: sixteen serial round trips to memory in the first and last step of every tile
+// of the fused backward, 22 us of its 344.)
+#define NFA_ELEMENTWISE_PATH() asm volatile("; element-wise path" ::: "memory")
+#if defined(NFA_VOLATILE_ELEMENTWISE) && NFA_VOLATILE_ELEMENTWISE   /* the old form, for A/B runs */
+#define NFA_PV volatile
+#else
+#define NFA_PV
+#endif
 template <bool VEC>
 __device__ __forceinline__ void store4(float *__restrict__ p, const Pos &q, const float v[SE])
 {
@@ -157,7 +165,8 @@ __device__ __forceinline__ void store4(float *__restrict__ p, const Pos &q, cons
         if (VEC && q.qall[h]) {
             store_f4(b + q.off + 4 * h, v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
         } else {
-            volatile float *pv = b;
+            NFA_ELEMENTWISE_PATH();
+            NFA_PV float *pv = b;
 #pragma unroll
             for (int j = 4 * h; j < 4 * h + 4; ++j)
                 if (q.valid[j]) pv[q.off + j] = v[j];
@@ -750,7 +759,8 @@ struct DensityFwdOp : OpBase1 {
                     Q4 v = {1.0f - rt[4 * h], 1.0f - rt[4 * h + 1], 1.0f - rt[4 * h + 2], 1.0f - rt[4 * h + 3]};
                     *reinterpret_cast<Q4 *>(b + q.off + 4 * h + crid[4 * h]) = v;
                 } else {
-                    volatile float *pv = b;
+                    NFA_ELEMENTWISE_PATH();
+            NFA_PV float *pv = b;
 #pragma unroll
                     for (int j = 4 * h; j < 4 * h + 4; ++j)
                         if (q.valid[j]) pv[q.off + j + crid[j]] = 1.0f - rt[j];
@@ -975,7 +985,8 @@ struct VisibilityOp {
             if (VEC && q.qall[h]) {
                 *reinterpret_cast<uchar4 *>(b + q.off + 4 * h) = make_uchar4(m[4 * h], m[4 * h + 1], m[4 * h + 2], m[4 * h + 3]);
             } else {
-                volatile uint8_t *pv = b;
+                NFA_ELEMENTWISE_PATH();
+                NFA_PV uint8_t *pv = b;
 #pragma unroll
                 for (int j = 4 * h; j < 4 * h + 4; ++j)
                     if (q.valid[j]) pv[q.off + j] = m[j];
@@ -1274,7 +1285,7 @@ __device__ __forceinline__ void fix_rgb12(const float *rgb, bool vec, const Pos 
         for (int k = 0; k < 3; ++k) c[3 * j + k] = q.valid[j] ? c[3 * j + k] : 0.0f;
 }
 
-// SE x rgb out: three 16 B stores per full quad, element-wise (volatile, see store4) where a range ends
+// SE x rgb out: three 16 B stores per full quad, element-wise (see store4) where a range ends
 __device__ __forceinline__ void store_rgb12(float *rgb, bool vec, const Pos &q, const float g[3 * SE])
 {
     float *b = rgb + 3 * q.c;
@@ -1287,7 +1298,8 @@ __device__ __forceinline__ void store_rgb12(float *rgb, bool vec, const Pos &q, 
             store_f4(o + 4, s[4], s[5], s[6], s[7]);
             store_f4(o + 8, s[8], s[9], s[10], s[11]);
         } else {
-            volatile float *pv = b;
+            NFA_ELEMENTWISE_PATH();
+            NFA_PV float *pv = b;
 #pragma unroll
             for (int j = 4 * h; j < 4 * h + 4; ++j)
                 if (q.valid[j]) {
@@ -1720,8 +1732,8 @@ void nfa_seg_plan(int64_t n_elems, int64_t *tile_elems, int64_t *n_tiles)
     // (4 steps per wave, ~120 waves per CU) are fastest; longer tiles lose to the tail of the last
     // wave round, shorter ones to the per-tile prologue.
     (void)n_elems;
-    int64_t t = 1024;
-    if (const char *e = getenv("NFA_SEG_TILE")) t = atoll(e);  // tuning knob (multiple of 256)
+    static const int64_t t_env = getenv("NFA_SEG_TILE") ? atoll(getenv("NFA_SEG_TILE")) : 0;  // tuning knob (multiple of 256), read once
+    const int64_t t = t_env > 0 ? t_env : 1024;
     *tile_elems = t;
     *n_tiles = n_elems / t + 1;
 }
