@@ -1007,7 +1007,9 @@ __device__ __forceinline__ void load_mask4(const uint8_t *vis, bool vec, const P
 #pragma unroll
     for (int h = 0; h < SQ; ++h) {
         if (vec) {
-            m.w[h] = *reinterpret_cast<const uint32_t *>(b + (q.qany[h] ? q.off + 4 * h : q.safe));
+            // (written as arithmetic: the plain select became a two-entry table in scratch memory)
+            const int32_t o = q.safe + (q.qany[h] ? 1 : 0) * (q.off + 4 * h - q.safe);
+            m.w[h] = *reinterpret_cast<const uint32_t *>(b + o);
         } else {
             uint32_t w = 0;
 #pragma unroll
@@ -1073,7 +1075,9 @@ struct CompactOp : OpBase1 {
         dst[j] = 0;
         if (m[j] != 0.0f) {
             const uint32_t slot = (uint32_t)(rid - g_lo);
-            const int64_t start = slot < (uint32_t)g_n ? s_start[slot] : out_starts[rid];
+            int64_t start = s_start[slot < (uint32_t)g_n ? slot : 0u];
+            asm volatile("; staged offset" : "+v"(start));   // (pins the LDS read: otherwise the two loads become one flat
+            if (slot >= (uint32_t)g_n) start = out_starts[rid];   //  load through a select of the two POINTERS)
             dst[j] = start + (int64_t)(is_head ? 0.0f : prev[0]);
         }
     }
