@@ -1057,6 +1057,7 @@ struct CompactOp : OpBase1 {
     float m[SE], a[SE], b[SE];
     int64_t dst[SE];
     int32_t er[SE];
+    float rank[SE];
     __device__ __forceinline__ void tile_begin(int32_t r_lo, int32_t r_hi, float *lds)
     {
         stage = lds;
@@ -1082,14 +1083,7 @@ struct CompactOp : OpBase1 {
     __device__ __forceinline__ void emit(int j, int64_t, bool, bool is_head, int rid, int, const float *, const float prev[1])
     {
         er[j] = rid;
-        dst[j] = 0;
-        if (m[j] != 0.0f) {
-            const uint32_t slot = (uint32_t)(rid - g_lo);
-            int64_t start = s_start[slot < (uint32_t)g_n ? slot : 0u];
-            asm volatile("; staged offset" : "+v"(start));   // (pins the LDS read: otherwise the two loads become one flat
-            if (slot >= (uint32_t)g_n) start = out_starts[rid];   //  load through a select of the two POINTERS)
-            dst[j] = start + (int64_t)(is_head ? 0.0f : prev[0]);
-        }
+        rank[j] = is_head ? 0.0f : prev[0];   // kept samples of the ray in front of this one
     }
     __device__ __forceinline__ void store(const Pos &)
     {
@@ -1102,6 +1096,25 @@ struct CompactOp : OpBase1 {
         for (int j = 0; j < SE; ++j) { keep[j] = m[j] != 0.0f; any = any || keep[j]; n_mine += keep[j] ? 1 : 0; }
         const unsigned long long lanes = __ballot(any);
         if (lanes == 0ull) return;  // wave-uniform
+        // output offsets of the elements' rays: the staged ones are four independent LDS reads; rays beyond the stage
+        // (a tile owning more than RAY_CAP rays) read global memory behind a wave-uniform branch.  (Written as a plain
+        // select of the two sources the compiler forms ONE flat load through a select of the two pointers.)
+        bool far = false;
+#pragma unroll
+        for (int j = 0; j < SE; ++j) {
+            const uint32_t slot = (uint32_t)(er[j] - g_lo);
+            const bool staged = slot < (uint32_t)g_n;
+            dst[j] = s_start[staged ? slot : 0u];
+            far = far || (keep[j] && !staged);
+        }
+        if (__ballot(far) != 0ull) {
+            asm volatile("; output offsets beyond the staged rays" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < SE; ++j)
+                if (keep[j] && (uint32_t)(er[j] - g_lo) >= (uint32_t)g_n) dst[j] = out_starts[er[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < SE; ++j) dst[j] = keep[j] ? dst[j] + (int64_t)rank[j] : 0;
         const int lane = lane_id();
         const int first = __builtin_ctzll(lanes), last = 63 - __builtin_clzll(lanes);
         int64_t my_first = dst[SE - 1], my_last = dst[0];
