@@ -56,6 +56,9 @@ constexpr int SEG_CHUNK = 64 * SE;      // elements per wave step
 #ifndef NFA_SEG_PIPE
 #define NFA_SEG_PIPE 0
 #endif
+#ifndef NFA_SEG_EARLY_FETCH
+#define NFA_SEG_EARLY_FETCH 1
+#endif
 #ifndef NFA_BWD_PIPE
 #define NFA_BWD_PIPE 1
 #endif
@@ -470,6 +473,13 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
             make_pos(chunk_base(ci + 1), qn);
             op.fetch(qn, raw_next);
         }
+        if (PIPE == 0 && ci > 0 && NFA_SEG_EARLY_FETCH) {
+            // this step's inputs are requested BEFORE its segment heads are resolved (the window of packed_info rows, the
+            // LDS scatter and its read-back: ~150 instructions and two LDS round trips that need none of the data)
+            Pos qf;
+            make_pos(c, qf);
+            op.fetch(qf, raw_cur);
+        }
         // ---- segment heads of this chunk -> LDS
 #pragma unroll
         for (int h = 0; h < SQ; ++h) *reinterpret_cast<int4 *>(hid + 256 * h + 4 * lane) = make_int4(-1, -1, -1, -1);
@@ -532,7 +542,7 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
         // ---- this step's data
         Pos q;
         make_pos(c, q);
-        if (!PIPE && ci > 0) op.fetch(q, raw_cur);
+        if (PIPE == 0 && ci > 0 && !NFA_SEG_EARLY_FETCH) op.fetch(q, raw_cur);   // (the old place, for A/B runs)
         op.load(raw_cur, q);
 
         // ---- segment structure of this step: ray id of every element (scan order k, address j = DIR>0 ? k : 3-k)
