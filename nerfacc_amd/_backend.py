@@ -68,6 +68,7 @@ _SIGS = {
     "nfa_expand_cone_runs": [_i64, _f32, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "nfa_expand_intervals": [_i64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "nfa_seg_plan": [_i64, C.POINTER(_i64), C.POINTER(_i64)],
+    "nfa_seg_table_rows": [_i64],
     "nfa_seg_build_tiles": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "nfa_packed_scan": [_int, _int, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],
     "nfa_packed_scan_generic": [_int, _int, _int, _vp, _i64, _i64, _vp, _vp, _vp],
@@ -97,7 +98,7 @@ _SIGS = {
     "nfa_version": [],
     "nfa_device_arch": [C.c_char_p, _int],
 }
-_RESTYPES = {"nfa_grid_rebinarize_scratch_bytes": _i64, "nfa_bricks_words": _i64, "nfa_walk_bits_words": _i64, "nfa_cumsum_scratch_bytes": _i64, "nfa_seg_plan": None, "nfa_last_error": C.c_char_p}
+_RESTYPES = {"nfa_grid_rebinarize_scratch_bytes": _i64, "nfa_bricks_words": _i64, "nfa_walk_bits_words": _i64, "nfa_cumsum_scratch_bytes": _i64, "nfa_seg_table_rows": _i64, "nfa_seg_plan": None, "nfa_last_error": C.c_char_p}
 
 EXPORTED_SYMBOLS = tuple(_SIGS)
 

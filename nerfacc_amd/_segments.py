@@ -23,7 +23,7 @@ class SegInfo:
     packed_info: Tensor          # int64 [n_rays, 2], contiguous
     n_rays: int
     n_elems: int
-    tiles: Optional[Tensor]      # int64 [n_tiles + 1, 2] {first ray, first element}; None when chunks are not contiguous
+    tiles: Optional[Tensor]      # int64 [nfa_seg_table_rows(n_tiles), 2]: {first ray, first element} x (n_tiles + 1), then the heavy-tile list; None when chunks are not contiguous
     contiguous: bool             # starts[r+1] == starts[r] + cnts[r]  (flat kernels usable)
     sorted_indices: bool = True  # for infos derived from ray_indices
     n_tiles: int = 0
@@ -38,7 +38,7 @@ def _build_tiles(packed_info: Tensor, n_elems: int, trusted: bool) -> SegInfo:
     n_rays = packed_info.shape[0]
     with torch.cuda.device(dev):
         tile_elems, n_tiles = B.seg_plan(n_elems)
-        tiles = torch.empty((n_tiles + 1, 2), dtype=torch.int64, device=dev)
+        tiles = torch.empty((int(B.load().nfa_seg_table_rows(n_tiles)), 2), dtype=torch.int64, device=dev)
         flag = None if trusted else torch.empty(1, dtype=torch.int32, device=dev)  # (no flag: no memset launch either)
         B.call("nfa_seg_build_tiles", B.ptr(packed_info), n_rays, n_elems, tile_elems, n_tiles, B.ptr(tiles), B.ptr(flag),
                B.stream())

@@ -56,6 +56,12 @@ constexpr int SEG_CHUNK = 64 * SE;      // elements per wave step
 #ifndef NFA_SEG_PIPE
 #define NFA_SEG_PIPE 0
 #endif
+#ifndef NFA_SEG_SEARCH_MIN_ROWS
+#define NFA_SEG_SEARCH_MIN_ROWS 2048
+#endif
+#ifndef NFA_SEG_WINDOW_PREFETCH
+#define NFA_SEG_WINDOW_PREFETCH 1
+#endif
 #ifndef NFA_SEG_EARLY_FETCH
 #define NFA_SEG_EARLY_FETCH 1
 #endif
@@ -112,6 +118,38 @@ __global__ __launch_bounds__(256) void seg_build_tiles_kernel(const int64_t *__r
         }
         for (int64_t b = b_lo; b <= b_hi && b <= n_tiles; ++b) tiles[b] = make_longlong2(r, e_first);
     }
+}
+
+// Tiles that own very many rays go first.  A tile covers ~1024 elements however many rays start in it, and in image
+// regions where almost every ray is empty a tile owns thousands of rows of packed_info (the bench's cfg 2: median 7 rows
+// per tile, 99.9th percentile 1 000-1 300, maximum 8 500-8 800), which its one wave walks 64 at a time: 130 us for the
+// heaviest against 43 us for an ordinary tile.  Dispatched in index order such a tile can start last and the whole launch
+// waits for it (fused fwd 322 us instead of 235 us with cfg 4's 256^3 grid; what is slow in such a tile is one dependent
+// load per window of rows, and with more than RAY_CAP rays the backward's per-element gathers).  So the table carries,
+// behind the n_tiles + 1 tile entries, a counter and a list of up to SEG_HEAVY_MAX heavy tiles; the first SEG_HEAVY_MAX
+// waves of a launch take the listed tiles, the others take the tiles in index order and skip the listed ones (flag bit
+// in .x).
+#ifndef NFA_SEG_HEAVY_MAX
+#define NFA_SEG_HEAVY_MAX 4096
+#endif
+#ifndef NFA_SEG_HEAVY_ROWS
+#define NFA_SEG_HEAVY_ROWS 128   /* measured: 1024 / 512 / 256 / 128 rows -> fused bwd 287 / 283 / 278 / 275 us on cfg 2 */
+#endif
+constexpr int SEG_HEAVY_MAX = NFA_SEG_HEAVY_MAX;
+constexpr int64_t SEG_HEAVY_ROWS = NFA_SEG_HEAVY_ROWS;
+constexpr int64_t SEG_LISTED = (int64_t)1 << 62;
+__host__ __device__ inline int64_t seg_table_rows(int64_t n_tiles) { return n_tiles + 2 + SEG_HEAVY_MAX / 2; }
+
+__global__ __launch_bounds__(256) void seg_mark_heavy_kernel(longlong2 *__restrict__ table, int64_t n_tiles)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const int64_t r0 = table[t].x & ~SEG_LISTED, r1 = table[t + 1].x & ~SEG_LISTED;   // (a neighbour may be setting its flag)
+    if (r1 - r0 < SEG_HEAVY_ROWS) return;
+    const unsigned long long slot = atomicAdd(reinterpret_cast<unsigned long long *>(&table[n_tiles + 1].x), 1ull);
+    if (slot >= (unsigned long long)SEG_HEAVY_MAX) return;   // more heavy tiles than the list holds: the rest stay in index order
+    reinterpret_cast<int64_t *>(table + n_tiles + 2)[slot] = t;
+    atomicOr(reinterpret_cast<unsigned long long *>(&table[t].x), (unsigned long long)SEG_LISTED);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -406,7 +444,7 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
     constexpr int NCH = Op::NCH;
     const int lane = lane_id();
     const int alane = DIR > 0 ? lane : 63 - lane;  // lane in address order
-    const longlong2 t_lo = tiles[tile], t_hi = tiles[tile + 1];
+    const longlong2 t_lo = tiles[tile], t_hi = tiles[tile + 1];   // (.x may carry the SEG_LISTED flag in bit 62: the ray index is its low 32 bits)
     const int32_t r_lo = __builtin_amdgcn_readfirstlane((int32_t)t_lo.x), r_hi = __builtin_amdgcn_readfirstlane((int32_t)t_hi.x);
     if (r_lo >= r_hi) return;
     const int32_t n_own = r_hi - r_lo;
@@ -416,14 +454,25 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
 
     // window of packed_info rows, in walk order v = 0..n_own-1: ray(v) = r_lo + v (fwd) / r_hi-1-v (rev)
     int32_t v_next = 0, win_base = 0;
-    int64_t win_s = 0, win_n = 0;
-    auto load_window = [&]() {
-        const int32_t v = win_base + lane;
+    // The window FOLLOWING the current one is requested as soon as the current one is in place (nxt_*): a tile in a region
+    // of short and empty rays owns hundreds of rows, and every window used to be a dependent load the wave waited for
+    // (the bench's 30 % empty rays cost the fused passes 8 %, at 256^3 -- the same number of rays, interleaved with short
+    // ones instead of lying in long runs -- 20 %).
+    int64_t win_s = 0, win_n = 0, nxt_s = 0, nxt_n = 0;
+    int32_t nxt_base = -1;   // window base the prefetched rows belong to (-1: none)
+    auto fetch_rows = [&](int32_t base, int64_t &rs, int64_t &rn) {
+        const int32_t v = base + lane;
         if (v < n_own) {
             const int64_t ray = DIR > 0 ? (int64_t)r_lo + v : (int64_t)r_hi - 1 - v;
             const longlong2 row = *reinterpret_cast<const longlong2 *>(packed_info + 2 * ray);
-            win_s = row.x; win_n = row.y;
+            rs = row.x; rn = row.y;
         }
+    };
+    auto load_window = [&]() {
+        if (NFA_SEG_WINDOW_PREFETCH && nxt_base == win_base) { win_s = nxt_s; win_n = nxt_n; }
+        else fetch_rows(win_base, win_s, win_n);
+        nxt_base = -1;
+        if (NFA_SEG_WINDOW_PREFETCH && win_base + 64 < n_own) { nxt_base = win_base + 64; fetch_rows(nxt_base, nxt_s, nxt_n); }
     };
     load_window();
 
@@ -502,7 +551,10 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
                 // sorted by start and of the rows with one start only the last can be non-empty, so the end of the
                 // run is found by a 64-ary search on the starts (4 dependent loads for 16 M rows) instead of
                 // walking it one window -- one dependent load -- at a time.
-                if (cnt == 64 && __ballot(take && win_n > 0) == 0ull && n_own - v_next >= 64) {
+                // (only for LONG runs: each probe round is a dependent load, so on a run of a few windows the search costs more
+                // than walking it -- the next window is already on its way; rays interleaved with runs of 64-500 empty ones
+                // made the fused passes 20 % slower through this path)
+                if (cnt == 64 && __ballot(take && win_n > 0) == 0ull && n_own - v_next >= NFA_SEG_SEARCH_MIN_ROWS) {
                     const int64_t S = uniform64(__shfl(win_s, 63, 64));
                     int32_t lo = v_next, hi = n_own;  // first v in [lo, hi] whose row is past the run
                     while (hi - lo > 0) {
@@ -620,8 +672,18 @@ __global__ __launch_bounds__(64 * SEG_WAVES_PER_BLOCK, Op::MIN_WAVES_PER_EU) voi
     constexpr int RL = Op::RAY_LDS_FLOATS > 0 ? Op::RAY_LDS_FLOATS : 4;
     __shared__ __attribute__((aligned(16))) float ray_all[SEG_WAVES_PER_BLOCK * RL];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t tile = (int64_t)blockIdx.x * SEG_WAVES_PER_BLOCK + wave;
-    if (tile >= n_tiles) return;
+    const int64_t w = (int64_t)blockIdx.x * SEG_WAVES_PER_BLOCK + wave;
+    int64_t tile;
+    if (w < SEG_HEAVY_MAX) {   // the launch's first waves: the listed heavy tiles
+        const int64_t n_heavy = tiles[n_tiles + 1].x;
+        if (w >= n_heavy) return;
+        tile = reinterpret_cast<const int64_t *>(tiles + n_tiles + 2)[w];
+    } else {
+        tile = w - SEG_HEAVY_MAX;
+        if (tile >= n_tiles) return;
+        if (tiles[tile].x & SEG_LISTED) return;
+    }
+    tile = uniform64(tile);
     seg_run_tile<DIR, PIPE>(op, packed_info, tiles, n_rays, tile, hid_all + wave * SEG_CHUNK, ray_all + wave * RL);
 }
 
@@ -630,7 +692,7 @@ static void launch_seg(const Op &op, const int64_t *packed_info, const int64_t *
                        hipStream_t s)
 {
     const longlong2 *tiles = reinterpret_cast<const longlong2 *>(tiles_raw);
-    const unsigned grid = (unsigned)ceil_div64(n_tiles, SEG_WAVES_PER_BLOCK);
+    const unsigned grid = (unsigned)ceil_div64(n_tiles + SEG_HEAVY_MAX, SEG_WAVES_PER_BLOCK);
     // NFA_SEG_PIPE (compile time): 0 = a step's loads are requested when the step starts; 1 = one step ahead, before the
     // previous step's compute (its registers cost occupancy: slower on every op); 2 = one step ahead, between the previous
     // step's compute and its stores.
@@ -1778,6 +1840,8 @@ void nfa_seg_plan(int64_t n_elems, int64_t *tile_elems, int64_t *n_tiles)
     *n_tiles = n_elems / t + 1;
 }
 
+int64_t nfa_seg_table_rows(int64_t n_tiles) { return seg_table_rows(n_tiles); }
+
 int nfa_seg_build_tiles(const int64_t *packed_info, int64_t n_rays, int64_t n_elems, int64_t tile_elems, int64_t n_tiles,
                         int64_t *tiles, int32_t *flags, nfa_stream_t stream)
 {
@@ -1790,6 +1854,9 @@ int nfa_seg_build_tiles(const int64_t *packed_info, int64_t n_rays, int64_t n_el
     if (flags && hipMemsetAsync(flags, 0, sizeof(int32_t), s) != hipSuccess) { set_error("seg_build_tiles: memset failed"); return NFA_EHIP; }
     hipLaunchKernelGGL(seg_build_tiles_kernel, dim3(grid_1d(n_rays + 1, 256)), dim3(256), 0, s, packed_info, n_rays,
                        n_elems, tile_elems, n_tiles, reinterpret_cast<longlong2 *>(tiles), flags);
+    // the heavy-tile list behind the n_tiles + 1 entries (the table holds nfa_seg_table_rows(n_tiles) pairs)
+    if (hipMemsetAsync(tiles + 2 * (n_tiles + 1), 0, 2 * sizeof(int64_t), s) != hipSuccess) { set_error("seg_build_tiles: memset failed"); return NFA_EHIP; }
+    hipLaunchKernelGGL(seg_mark_heavy_kernel, dim3(grid_1d(n_tiles, 256)), dim3(256), 0, s, reinterpret_cast<longlong2 *>(tiles), n_tiles);
     NFA_CHECK_LAUNCH("seg_build_tiles");
     return NFA_OK;
 }

@@ -38,7 +38,24 @@ def run(cnt, tag):
         out.append(e0.elapsed_time(e1) / 10 * 1e3)
     print(f"{tag:34s} rays {R:9d} samples {n:10d}  fwd {out[0]:7.1f} us  bwd {out[1]:7.1f} us   per Msample {out[0]/n*1e6:6.2f} {out[1]/n*1e6:6.2f}", flush=True)
 
-for L in (32, 36, 35, 28, 29, 40, 41):
-    run(np.full(M // L, L), f"uniform {L}")
-run(4 * rng.poisson(7.7, M // 31), "4 x poisson 7.7 (heads at quad starts)")
-run(rng.poisson(30.7, M // 31), "poisson 30.7")
+import bench
+w = bench.make_workload(dev, res=256)
+bench.run_step(w)
+cnt = torch.bincount(w["last"][0], minlength=w["n_rays"]).cpu().numpy()
+del w
+torch.cuda.empty_cache()
+run(cnt, "bench rays, 256^3 grid")
+ne = cnt[cnt > 0]; nz = int((cnt == 0).sum())
+run(ne, "  without the empty rays")
+run(np.concatenate([ne, np.zeros(nz, np.int64)]), "  empties moved to the end")
+run(np.concatenate([np.zeros(nz, np.int64), ne]), "  empties moved to the front")
+# empties spread evenly: one after every k-th non-empty ray
+k = max(1, ne.size // nz)
+ev = np.insert(ne, np.arange(k, k * nz + 1, k)[:nz].clip(max=ne.size), 0)
+run(ev, f"  empties spread evenly (every {k} rays)")
+# runs of empties as in the bench but the non-empty rays replaced by uniform 38
+u = cnt.copy(); u[u > 0] = 38
+run(u, "  same empties, other rays uniform 38")
+# run-length stats of the empties
+z = (cnt == 0).astype(np.int8); d = np.diff(np.concatenate([[0], z, [0]])); st = np.where(d == 1)[0]; en = np.where(d == -1)[0]; rl = en - st
+print("empty runs:", rl.size, "mean", rl.mean(), "pct", np.percentile(rl, [50, 90, 99, 100]).tolist(), flush=True)
