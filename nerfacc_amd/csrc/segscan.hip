@@ -1666,10 +1666,12 @@ struct RenderFusedBwdOp : OpBase1 {
     int32_t g_lo = 0, g_n = 0;
     __device__ __forceinline__ void tile_begin(int32_t r_lo, int32_t r_hi, float *lds)
     {
-        g_lds = lds; g_lo = r_lo; g_n = min(r_hi - r_lo, RAY_CAP);
+        // (the pass runs from the tile's last ray to its first: when the tile owns more than RAY_CAP rays the stage holds
+        //  the LAST ones, which most of its elements belong to)
+        g_lds = lds; g_n = min(r_hi - r_lo, RAY_CAP); g_lo = r_hi - g_n;
         __builtin_amdgcn_wave_barrier();
         for (int32_t i = lane_id(); i < g_n; i += 64) {
-            const int64_t r = (int64_t)r_lo + i;
+            const int64_t r = (int64_t)g_lo + i;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gc) { v.x = gc[3 * r]; v.y = gc[3 * r + 1]; v.z = gc[3 * r + 2]; }
             if (go) v.w = go[r];
