@@ -67,7 +67,7 @@ _SIGS = {
     "nfa_traverse_cone_runs": [C.POINTER(TraverseArgs), _vp, _vp, _i32, _vp, _vp],
     "nfa_expand_cone_runs": [_i64, _f32, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "nfa_expand_intervals": [_i64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
-    "nfa_seg_plan": [_i64, C.POINTER(_i64), C.POINTER(_i64)],
+    "nfa_seg_plan": [_i64, _i64, C.POINTER(_i64), C.POINTER(_i64)],
     "nfa_seg_table_rows": [_i64],
     "nfa_seg_build_tiles": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "nfa_packed_scan": [_int, _int, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],
@@ -170,10 +170,10 @@ def require_device(*tensors: Optional[torch.Tensor]) -> torch.device:
     return dev
 
 
-def seg_plan(n_elems: int):
-    """(tile_elems, n_tiles) chosen by the library for an array of n_elems samples."""
+def seg_plan(n_elems: int, n_rays: int = 0):
+    """(tile_elems, n_tiles) chosen by the library for n_rays rays with n_elems samples in all."""
     t, n = _i64(0), _i64(0)
-    load().nfa_seg_plan(n_elems, C.byref(t), C.byref(n))
+    load().nfa_seg_plan(n_elems, n_rays, C.byref(t), C.byref(n))
     return int(t.value), int(n.value)
 
 

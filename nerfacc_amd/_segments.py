@@ -37,7 +37,7 @@ def _build_tiles(packed_info: Tensor, n_elems: int, trusted: bool) -> SegInfo:
     dev = B.require_device(packed_info)
     n_rays = packed_info.shape[0]
     with torch.cuda.device(dev):
-        tile_elems, n_tiles = B.seg_plan(n_elems)
+        tile_elems, n_tiles = B.seg_plan(n_elems, n_rays)
         tiles = torch.empty((int(B.load().nfa_seg_table_rows(n_tiles)), 2), dtype=torch.int64, device=dev)
         flag = None if trusted else torch.empty(1, dtype=torch.int32, device=dev)  # (no flag: no memset launch either)
         B.call("nfa_seg_build_tiles", B.ptr(packed_info), n_rays, n_elems, tile_elems, n_tiles, B.ptr(tiles), B.ptr(flag),

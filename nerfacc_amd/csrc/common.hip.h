@@ -102,6 +102,9 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
 }
 __device__ __forceinline__ int32_t last_lane(int32_t v) { return __builtin_amdgcn_readlane(v, 63); }
 __device__ __forceinline__ float last_lane(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+// value of lane `l` (wave-uniform index)
+__device__ __forceinline__ int32_t lane_value(int32_t v, int32_t l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float lane_value(float v, int32_t l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
 
 // 16-byte stores of streamed outputs.  NFA_NT_STORES=1 marks them non-temporal (A/B switch).

@@ -56,6 +56,10 @@ constexpr int SEG_CHUNK = 64 * SE;      // elements per wave step
 #ifndef NFA_SEG_PIPE
 #define NFA_SEG_PIPE 0
 #endif
+#ifndef NFA_SEG_TILE_ROWS
+#define NFA_SEG_TILE_ROWS 256
+#endif
+constexpr int64_t SEG_TILE_ROWS = NFA_SEG_TILE_ROWS;
 #ifndef NFA_SEG_SEARCH_MIN_ROWS
 #define NFA_SEG_SEARCH_MIN_ROWS 2048
 #endif
@@ -85,6 +89,9 @@ constexpr int SEG_WAVES_PER_BLOCK = NFA_SEG_WAVES_PER_BLOCK;
 // {n_rays, end of the last ray}.  Tile b covers element offsets [b*tile_elems, (b+1)*tile_elems).
 // (Uniform tiles: cutting the last sixth of the range into quarter-size tiles, to shorten a launch's emptying last
 // round of waves, was measured slower -- fused fwd / bwd 290 / 352 -> 304 / 373 us.)
+// A tile boundary is also drawn every SEG_TILE_ROWS rays: tile(ray r) = start[r] / tile_elems + r / SEG_TILE_ROWS (monotone in
+// r), so that a region of short and empty rays is cut into tiles of at most SEG_TILE_ROWS rows instead of one tile with
+// thousands (SS4 (10)): n_tiles = n_elems / tile_elems + n_rays / SEG_TILE_ROWS + 1.
 __global__ __launch_bounds__(256) void seg_build_tiles_kernel(const int64_t *__restrict__ packed_info, int64_t n_rays,
                                                               int64_t n_elems, int64_t tile_elems, int64_t n_tiles,
                                                               longlong2 *__restrict__ tiles, int32_t *__restrict__ flags)
@@ -105,13 +112,13 @@ __global__ __launch_bounds__(256) void seg_build_tiles_kernel(const int64_t *__r
             }
             bad |= (n < 0) || (s < 0) || (s + n > n_elems);
             if (bad) { if (flags) atomicOr(flags, 1); continue; }
-            b_lo = (s_prev < 0) ? 0 : s_prev / tile_elems + 1;
-            b_hi = s / tile_elems;
+            b_lo = (s_prev < 0) ? 0 : s_prev / tile_elems + (r - 1) / SEG_TILE_ROWS + 1;
+            b_hi = s / tile_elems + r / SEG_TILE_ROWS;
             e_first = s;
         } else {
             const int64_t s_prev = n_rays > 0 ? packed_info[2 * n_rays - 2] : -1;
             const int64_t n_prev = n_rays > 0 ? packed_info[2 * n_rays - 1] : 0;
-            b_lo = (s_prev < 0) ? 0 : s_prev / tile_elems + 1;
+            b_lo = (s_prev < 0) ? 0 : s_prev / tile_elems + (n_rays - 1) / SEG_TILE_ROWS + 1;
             b_hi = n_tiles;
             e_first = (s_prev < 0) ? 0 : s_prev + n_prev;
             if (s_prev > n_elems) { if (flags) atomicOr(flags, 1); continue; }
@@ -170,6 +177,7 @@ struct Pos {
     int32_t safe;   // offset from c of an in-range, 16 B aligned quad every lane may read
     bool valid[SE]; // element c + off + j belongs to the tile's element range
     bool any, all;  // over the lane's SE elements
+    int32_t d_lo, d_hi;  // the step's valid element offsets [d_lo, d_hi) from c (wave-uniform)
     bool qany[SQ], qall[SQ];  // per 16-byte quad
     __device__ __forceinline__ int64_t p0() const { return c + off; }
 };
@@ -227,6 +235,9 @@ struct StepHeads {
     int32_t lh[SE];       // most recent head ray id over the lane's elements 0..k (-1: none)
     uint32_t acc;         // bit s: at Hillis-Steele step s (offset 2^s) this lane still accumulates
     bool open_prefix;     // no head in any earlier lane of this step: the carry of previous steps applies
+    bool carry_on_lane_end;  // (wave-uniform) the range's last element is that lane's last element
+    int32_t carry_lane;   // (wave-uniform) last lane in scan order that holds an element of the tile's range: carries are read
+                          // THERE -- a ray that ends at the range's end gets the same scan tree as a ray that ends anywhere else
     int32_t ph;           // ray id in front of the lane's first element (carry folded in)
     int32_t rid[SE], prev_rid[SE];
     bool is_head[SE];
@@ -316,8 +327,15 @@ __device__ __forceinline__ void scan_values(const StepHeads &hd, const float x[S
             prev[k][ch] = (k == 0) ? pv[ch] : incl[k - 1 < 0 ? 0 : k - 1][ch];
             incl[k][ch] = hd.lh[k] >= 0 ? li[k][ch] : comb(ch, pv[ch], li[k][ch]);
         }
+    // The state after the range's last element, formed exactly as the NEXT element would see it (so that a ray's total does
+    // not depend on whether the ray ends inside a tile or at its end): behind a lane's last element that is the scanned lane
+    // aggregate (what the next lane reads as `pv`), inside a lane the element's inclusive value.
+    const bool open_next = hd.open_prefix && hd.lh[SE - 1] < 0;
 #pragma unroll
-    for (int ch = 0; ch < N; ++ch) carry[ch] = last_lane(incl[SE - 1][ch]);
+    for (int ch = 0; ch < N; ++ch) {
+        const float nxt = open_next ? comb(ch, carry[ch], av[ch]) : av[ch];
+        carry[ch] = lane_value(hd.carry_on_lane_end ? nxt : incl[SE - 1][ch], hd.carry_lane);
+    }
 }
 
 // Per-ray totals: a ray is finished where the next head appears; (prev_rid, prev) there is its id and
@@ -402,7 +420,8 @@ __device__ __forceinline__ void scan_totals(const StepHeads &hd, FX &&xb, float 
                 seen = seen || f[k];
             }
         }
-        carry[ch] = last_lane(incl);
+        const float nxt = (hd.open_prefix && hd.lh[SE - 1] < 0) ? carry[ch] + av[0] : av[0];   // (see scan_values)
+        carry[ch] = lane_value(hd.carry_on_lane_end ? nxt : incl, hd.carry_lane);
     }
 }
 
@@ -495,6 +514,7 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
         const int32_t d_lo = lo64 < 0 ? 0 : (lo64 > SEG_CHUNK ? SEG_CHUNK : (int32_t)lo64);
         const int32_t d_hi = hi64 < 0 ? 0 : (hi64 > SEG_CHUNK ? SEG_CHUNK : (int32_t)hi64);
         q.c = c;
+        q.d_lo = d_lo; q.d_hi = d_hi;
         q.off = SE * alane;
         q.safe = (d_lo / 4) * 4;  // first in-range multiple of 4 (every step holds at least one element)
 #pragma unroll
@@ -600,6 +620,8 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
         // ---- segment structure of this step: ray id of every element (scan order k, address j = DIR>0 ? k : 3-k)
         StepHeads hd;
         resolve_heads<DIR>(hj, q.valid, carry_rid, hd);
+        hd.carry_lane = DIR > 0 ? (q.d_hi - 1) / SE : 63 - q.d_lo / SE;
+        hd.carry_on_lane_end = DIR > 0 ? (q.d_hi % SE == 0) : (q.d_lo % SE == 0);
         if constexpr (Op::NEEDS_RID) {
 #pragma unroll
             for (int k = 0; k < SE; ++k) {
@@ -642,7 +664,7 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
                              [&](int k, int ch) { const int j = DIR > 0 ? k : SE - 1 - k; return q.valid[j] ? op.xb(j, ch) : 0.0f; },
                              carry_b, [&](int32_t rid, int ch, float t) { op.ray_done_b(rid, ch, t); });
         }
-        carry_rid = last_lane(hd.rid[SE - 1]);
+        carry_rid = lane_value(hd.rid[SE - 1], hd.carry_lane);
         if (PIPE) raw_cur = raw_next;
     }
     // remaining owned rays are all empty (their start equals e_hi / e_lo)
@@ -1830,16 +1852,15 @@ using namespace nfa;
 
 extern "C" {
 
-void nfa_seg_plan(int64_t n_elems, int64_t *tile_elems, int64_t *n_tiles)
+void nfa_seg_plan(int64_t n_elems, int64_t n_rays, int64_t *tile_elems, int64_t *n_tiles)
 {
     // One wave per tile.  Measured on MI355X (scripts/sweep_seg.sh, 32 M samples): 1024-element tiles
     // (4 steps per wave, ~120 waves per CU) are fastest; longer tiles lose to the tail of the last
-    // wave round, shorter ones to the per-tile prologue.
-    (void)n_elems;
-    static const int64_t t_env = getenv("NFA_SEG_TILE") ? atoll(getenv("NFA_SEG_TILE")) : 0;  // tuning knob (multiple of 256), read once
+    // wave round, shorter ones to the per-tile prologue.  A tile also ends after SEG_TILE_ROWS rays.
+    static const int64_t t_env = getenv("NFA_SEG_TILE") ? atoll(getenv("NFA_SEG_TILE")) : 0;  // tuning knob (multiple of 4), read once
     const int64_t t = t_env > 0 ? t_env : 1024;
     *tile_elems = t;
-    *n_tiles = n_elems / t + 1;
+    *n_tiles = n_elems / t + (n_rays > 0 ? n_rays : 0) / SEG_TILE_ROWS + 1;
 }
 
 int64_t nfa_seg_table_rows(int64_t n_tiles) { return seg_table_rows(n_tiles); }
@@ -1850,8 +1871,8 @@ int nfa_seg_build_tiles(const int64_t *packed_info, int64_t n_rays, int64_t n_el
     NFA_REQUIRE(n_rays >= 0 && n_elems >= 0 && tiles, "seg_build_tiles: bad arguments");
     NFA_REQUIRE(n_rays == 0 || packed_info, "seg_build_tiles: packed_info is null");
     NFA_REQUIRE(n_rays < ((int64_t)1 << 31) - 64, "seg_build_tiles: too many rays");
-    NFA_REQUIRE(tile_elems >= 256 && tile_elems % 256 == 0 && n_tiles == n_elems / tile_elems + 1,
-                "seg_build_tiles: tile_elems must be a multiple of 256 and n_tiles == n_elems / tile_elems + 1");
+    NFA_REQUIRE(tile_elems >= 256 && tile_elems % 256 == 0 && n_tiles == n_elems / tile_elems + n_rays / SEG_TILE_ROWS + 1,
+                "seg_build_tiles: tile_elems must be a multiple of 256 and n_tiles what nfa_seg_plan returns for (n_elems, n_rays)");
     hipStream_t s = as_stream(stream);
     if (flags && hipMemsetAsync(flags, 0, sizeof(int32_t), s) != hipSuccess) { set_error("seg_build_tiles: memset failed"); return NFA_EHIP; }
     hipLaunchKernelGGL(seg_build_tiles_kernel, dim3(grid_1d(n_rays + 1, 256)), dim3(256), 0, s, packed_info, n_rays,

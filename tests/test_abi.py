@@ -18,6 +18,7 @@ def test_header_and_library_agree():
     assert lib.nfa_version() >= 100
     from nerfacc_amd._backend import seg_plan
     assert seg_plan(0) == (1024, 1) and seg_plan(32 * 1024 * 1024)[0] % 256 == 0
+    assert seg_plan(2048, 1000) == (1024, 2 + 1000 // 256 + 1)   # a tile also ends after 256 rays
 
 
 def test_argument_errors_are_reported():
