@@ -5,10 +5,11 @@
 // shared-memory Blelloch tile with ~10 __syncthreads per tile (include/utils_scan.cuh) and
 // builds everything else out of ATen elementwise launches.  Here a single engine streams the
 // flat sample arrays once:
-//   * the flat element range is cut into tiles of NFA_SEG_TILE element offsets; a tile OWNS the
-//     rays whose chunk starts inside it (ownership table built once per packed_info), so every
+//   * the flat element range is cut into tiles of NFA_SEG_TILE element offsets and at most SEG_TILE_ROWS rays; a
+//     tile OWNS the rays whose chunk starts inside it (ownership table built once per packed_info), so every
 //     ray is scanned start-to-end by exactly one wave: no cross-workgroup carry, no atomics,
-//     deterministic results, load balance independent of the ray-length distribution;
+//     deterministic results that do not depend on the tiling, load balance independent of the ray-length
+//     distribution (empty rays included); the tiles that own many rays are taken by a launch's first waves;
 //   * a wave walks its element range in 256-element steps, 16 B per lane per array (coalesced
 //     1 KiB wave loads/stores); everything that is uniform over the wave (tile bounds, step base,
 //     loop control) lives in scalar registers;
