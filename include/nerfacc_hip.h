@@ -221,13 +221,12 @@ int nfa_grid_rebinarize(const float *occs, int32_t n_grids, const int32_t *res, 
 
 /* Ownership table for the flat segmented kernels: the element range is cut into n_tiles tiles of
  * tile_elems element offsets, and after every 256 rays (nfa_seg_plan picks tile_elems and n_tiles); a tile OWNS the rays whose chunk starts
- * inside it.  tiles holds nfa_seg_table_rows(n_tiles) int64 pairs: (n_tiles + 1) {first ray, first element} entries + the list.  Requires
+ * inside it.  tiles holds nfa_seg_table_rows(n_tiles) int64 pairs: the (n_tiles + 1) {first ray, first element} entries.  Requires
  * contiguous chunks (starts[r+1] == starts[r] + cnts[r]); flags[0] is set to 1 when they are not,
  * in which case the caller must use the *_generic entry points (flags may be NULL for a packed_info the
  * caller knows to be contiguous: no check result, and no memset launch). */
 void nfa_seg_plan(int64_t n_elems, int64_t n_rays, int64_t *tile_elems, int64_t *n_tiles);
-/* int64 PAIRS the caller allocates for `tiles`: the n_tiles + 1 ownership entries, then a counter and a list of the
- * tiles that own very many rays (a launch's first waves take those, so that none of them is the last to start). */
+/* int64 PAIRS the caller allocates for `tiles` (n_tiles + 1 today; ask instead of assuming). */
 int64_t nfa_seg_table_rows(int64_t n_tiles);
 int nfa_seg_build_tiles(const int64_t *packed_info /*[n_rays,2]*/, int64_t n_rays, int64_t n_elems,
                         int64_t tile_elems, int64_t n_tiles, int64_t *tiles /*[2*(n_tiles+1)]*/,

@@ -23,7 +23,7 @@ class SegInfo:
     packed_info: Tensor          # int64 [n_rays, 2], contiguous
     n_rays: int
     n_elems: int
-    tiles: Optional[Tensor]      # int64 [nfa_seg_table_rows(n_tiles), 2]: {first ray, first element} x (n_tiles + 1), then the heavy-tile list; None when chunks are not contiguous
+    tiles: Optional[Tensor]      # int64 [nfa_seg_table_rows(n_tiles), 2]: {first ray, first element} per tile + the end sentinel; None when chunks are not contiguous
     contiguous: bool             # starts[r+1] == starts[r] + cnts[r]  (flat kernels usable)
     sorted_indices: bool = True  # for infos derived from ray_indices
     n_tiles: int = 0

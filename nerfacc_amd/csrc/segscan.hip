@@ -128,37 +128,10 @@ __global__ __launch_bounds__(256) void seg_build_tiles_kernel(const int64_t *__r
     }
 }
 
-// Tiles that own very many rays go first.  A tile covers ~1024 elements however many rays start in it, and in image
-// regions where almost every ray is empty a tile owns thousands of rows of packed_info (the bench's cfg 2: median 7 rows
-// per tile, 99.9th percentile 1 000-1 300, maximum 8 500-8 800), which its one wave walks 64 at a time: 130 us for the
-// heaviest against 43 us for an ordinary tile.  Dispatched in index order such a tile can start last and the whole launch
-// waits for it (fused fwd 322 us instead of 235 us with cfg 4's 256^3 grid; what is slow in such a tile is one dependent
-// load per window of rows, and with more than RAY_CAP rays the backward's per-element gathers).  So the table carries,
-// behind the n_tiles + 1 tile entries, a counter and a list of up to SEG_HEAVY_MAX heavy tiles; the first SEG_HEAVY_MAX
-// waves of a launch take the listed tiles, the others take the tiles in index order and skip the listed ones (flag bit
-// in .x).
-#ifndef NFA_SEG_HEAVY_MAX
-#define NFA_SEG_HEAVY_MAX 4096
-#endif
-#ifndef NFA_SEG_HEAVY_ROWS
-#define NFA_SEG_HEAVY_ROWS 128   /* measured: 1024 / 512 / 256 / 128 rows -> fused bwd 287 / 283 / 278 / 275 us on cfg 2 */
-#endif
-constexpr int SEG_HEAVY_MAX = NFA_SEG_HEAVY_MAX;
-constexpr int64_t SEG_HEAVY_ROWS = NFA_SEG_HEAVY_ROWS;
-constexpr int64_t SEG_LISTED = (int64_t)1 << 62;
-__host__ __device__ inline int64_t seg_table_rows(int64_t n_tiles) { return n_tiles + 2 + SEG_HEAVY_MAX / 2; }
-
-__global__ __launch_bounds__(256) void seg_mark_heavy_kernel(longlong2 *__restrict__ table, int64_t n_tiles)
-{
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tiles) return;
-    const int64_t r0 = table[t].x & ~SEG_LISTED, r1 = table[t + 1].x & ~SEG_LISTED;   // (a neighbour may be setting its flag)
-    if (r1 - r0 < SEG_HEAVY_ROWS) return;
-    const unsigned long long slot = atomicAdd(reinterpret_cast<unsigned long long *>(&table[n_tiles + 1].x), 1ull);
-    if (slot >= (unsigned long long)SEG_HEAVY_MAX) return;   // more heavy tiles than the list holds: the rest stay in index order
-    reinterpret_cast<int64_t *>(table + n_tiles + 2)[slot] = t;
-    atomicOr(reinterpret_cast<unsigned long long *>(&table[t].x), (unsigned long long)SEG_LISTED);
-}
+// (A list of the tiles that own many rays, taken by a launch's first waves so that none of them starts last, was the first
+// remedy for row-heavy tiles -- fused fwd 264 -> 237 us on cfg 2 -- and became useless, slightly harmful, once a tile could
+// not own more than SEG_TILE_ROWS rays; removed.)
+__host__ __device__ inline int64_t seg_table_rows(int64_t n_tiles) { return n_tiles + 1; }
 
 // ------------------------------------------------------------------------------------------
 // 16-byte vector helpers (addresses are 16 B aligned when VEC is true)
@@ -464,7 +437,7 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
     constexpr int NCH = Op::NCH;
     const int lane = lane_id();
     const int alane = DIR > 0 ? lane : 63 - lane;  // lane in address order
-    const longlong2 t_lo = tiles[tile], t_hi = tiles[tile + 1];   // (.x may carry the SEG_LISTED flag in bit 62: the ray index is its low 32 bits)
+    const longlong2 t_lo = tiles[tile], t_hi = tiles[tile + 1];
     const int32_t r_lo = __builtin_amdgcn_readfirstlane((int32_t)t_lo.x), r_hi = __builtin_amdgcn_readfirstlane((int32_t)t_hi.x);
     if (r_lo >= r_hi) return;
     const int32_t n_own = r_hi - r_lo;
@@ -695,18 +668,8 @@ __global__ __launch_bounds__(64 * SEG_WAVES_PER_BLOCK, Op::MIN_WAVES_PER_EU) voi
     constexpr int RL = Op::RAY_LDS_FLOATS > 0 ? Op::RAY_LDS_FLOATS : 4;
     __shared__ __attribute__((aligned(16))) float ray_all[SEG_WAVES_PER_BLOCK * RL];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t w = (int64_t)blockIdx.x * SEG_WAVES_PER_BLOCK + wave;
-    int64_t tile;
-    if (w < SEG_HEAVY_MAX) {   // the launch's first waves: the listed heavy tiles
-        const int64_t n_heavy = tiles[n_tiles + 1].x;
-        if (w >= n_heavy) return;
-        tile = reinterpret_cast<const int64_t *>(tiles + n_tiles + 2)[w];
-    } else {
-        tile = w - SEG_HEAVY_MAX;
-        if (tile >= n_tiles) return;
-        if (tiles[tile].x & SEG_LISTED) return;
-    }
-    tile = uniform64(tile);
+    const int64_t tile = (int64_t)blockIdx.x * SEG_WAVES_PER_BLOCK + wave;
+    if (tile >= n_tiles) return;
     seg_run_tile<DIR, PIPE>(op, packed_info, tiles, n_rays, tile, hid_all + wave * SEG_CHUNK, ray_all + wave * RL);
 }
 
@@ -715,7 +678,7 @@ static void launch_seg(const Op &op, const int64_t *packed_info, const int64_t *
                        hipStream_t s)
 {
     const longlong2 *tiles = reinterpret_cast<const longlong2 *>(tiles_raw);
-    const unsigned grid = (unsigned)ceil_div64(n_tiles + SEG_HEAVY_MAX, SEG_WAVES_PER_BLOCK);
+    const unsigned grid = (unsigned)ceil_div64(n_tiles, SEG_WAVES_PER_BLOCK);
     // NFA_SEG_PIPE (compile time): 0 = a step's loads are requested when the step starts; 1 = one step ahead, before the
     // previous step's compute (its registers cost occupancy: slower on every op); 2 = one step ahead, between the previous
     // step's compute and its stores.
@@ -1878,9 +1841,6 @@ int nfa_seg_build_tiles(const int64_t *packed_info, int64_t n_rays, int64_t n_el
     if (flags && hipMemsetAsync(flags, 0, sizeof(int32_t), s) != hipSuccess) { set_error("seg_build_tiles: memset failed"); return NFA_EHIP; }
     hipLaunchKernelGGL(seg_build_tiles_kernel, dim3(grid_1d(n_rays + 1, 256)), dim3(256), 0, s, packed_info, n_rays,
                        n_elems, tile_elems, n_tiles, reinterpret_cast<longlong2 *>(tiles), flags);
-    // the heavy-tile list behind the n_tiles + 1 entries (the table holds nfa_seg_table_rows(n_tiles) pairs)
-    if (hipMemsetAsync(tiles + 2 * (n_tiles + 1), 0, 2 * sizeof(int64_t), s) != hipSuccess) { set_error("seg_build_tiles: memset failed"); return NFA_EHIP; }
-    hipLaunchKernelGGL(seg_mark_heavy_kernel, dim3(grid_1d(n_tiles, 256)), dim3(256), 0, s, reinterpret_cast<longlong2 *>(tiles), n_tiles);
     NFA_CHECK_LAUNCH("seg_build_tiles");
     return NFA_OK;
 }
