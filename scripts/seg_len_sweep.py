@@ -27,8 +27,12 @@ def run(cnt, tag):
     def bwd():
         B.call("nfa_render_fused_bwd", B.ptr(ts), B.ptr(te), B.ptr(rgb), B.ptr(tr), B.ptr(al), B.ptr(gc), None, None, None, None, None,
                B.ptr(seg.packed_info), B.ptr(seg.tiles), seg.n_tiles, R, n, B.ptr(gs), B.ptr(gr), B.stream())
+    vis_m = torch.empty(n, dtype=torch.uint8, device=dev); vis_c = torch.empty(R, dtype=torch.int64, device=dev)
+    def vis():
+        B.call("nfa_render_visibility", B.ptr(ts), B.ptr(te), B.ptr(sg), None, 1e-4, 0.0, B.ptr(seg.packed_info), B.ptr(seg.tiles),
+               seg.n_tiles, R, n, B.ptr(vis_m), B.ptr(vis_c), B.stream())
     out = []
-    for f in (fwd, bwd):
+    for f in (fwd, bwd, vis):
         for _ in range(3): f()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -36,26 +40,16 @@ def run(cnt, tag):
         for _ in range(10): f()
         e1.record(); torch.cuda.synchronize()
         out.append(e0.elapsed_time(e1) / 10 * 1e3)
-    print(f"{tag:34s} rays {R:9d} samples {n:10d}  fwd {out[0]:7.1f} us  bwd {out[1]:7.1f} us   per Msample {out[0]/n*1e6:6.2f} {out[1]/n*1e6:6.2f}", flush=True)
+    print(f"{tag:34s} rays {R:9d} samples {n:10d}  fwd {out[0]:7.1f} us  bwd {out[1]:7.1f} us  vis {out[2]:7.1f} us", flush=True)
 
 import bench
-w = bench.make_workload(dev, res=256)
-bench.run_step(w)
-cnt = torch.bincount(w["last"][0], minlength=w["n_rays"]).cpu().numpy()
-del w
-torch.cuda.empty_cache()
-run(cnt, "bench rays, 256^3 grid")
-ne = cnt[cnt > 0]; nz = int((cnt == 0).sum())
-run(ne, "  without the empty rays")
-run(np.concatenate([ne, np.zeros(nz, np.int64)]), "  empties moved to the end")
-run(np.concatenate([np.zeros(nz, np.int64), ne]), "  empties moved to the front")
-# empties spread evenly: one after every k-th non-empty ray
-k = max(1, ne.size // nz)
-ev = np.insert(ne, np.arange(k, k * nz + 1, k)[:nz].clip(max=ne.size), 0)
-run(ev, f"  empties spread evenly (every {k} rays)")
-# runs of empties as in the bench but the non-empty rays replaced by uniform 38
-u = cnt.copy(); u[u > 0] = 38
-run(u, "  same empties, other rays uniform 38")
-# run-length stats of the empties
-z = (cnt == 0).astype(np.int8); d = np.diff(np.concatenate([[0], z, [0]])); st = np.where(d == 1)[0]; en = np.where(d == -1)[0]; rl = en - st
-print("empty runs:", rl.size, "mean", rl.mean(), "pct", np.percentile(rl, [50, 90, 99, 100]).tolist(), flush=True)
+for res in (128, 256):
+    w = bench.make_workload(dev, res=res)
+    bench.run_step(w)
+    cnt = torch.bincount(w["last"][0], minlength=w["n_rays"]).cpu().numpy()
+    del w
+    torch.cuda.empty_cache()
+    run(cnt, f"bench rays, {res}^3 grid")
+    run(cnt[cnt > 0], "  without the empty rays")
+for L in (4, 16, 31, 32, 64, 1024):
+    run(np.full(M // L, L), f"uniform {L}")
