@@ -374,6 +374,17 @@ class OccGridEstimator(AbstractEstimator):
         self._occs_mean_cache = None
 
 
+_PINNED_READ = __import__("os").environ.get("NERFACC_AMD_PINNED_READ", "1") != "0"
+_PINNED_TOTALS: dict = {}
+
+
+def _pinned_total(dev) -> Tensor:
+    buf = _PINNED_TOTALS.get(dev.index)
+    if buf is None:
+        buf = _PINNED_TOTALS[dev.index] = torch.empty(1, dtype=torch.int64, pin_memory=True)
+    return buf
+
+
 def _compact(seg: SegInfo, vis: Tensor, cnts: Tensor, t_starts: Tensor, t_ends: Tensor):
     """``x[masks]`` for the sampler's three arrays in one pass (ref :216-220), given the mask and
     the per-ray visible counts.  One device->host read (the output size).  Returns None when no
@@ -383,7 +394,15 @@ def _compact(seg: SegInfo, vis: Tensor, cnts: Tensor, t_starts: Tensor, t_ends: 
     with torch.cuda.device(dev):
         total = torch.empty(1, dtype=torch.int64, device=dev)
         out_starts = _exclusive_cumsum(cnts, total)
-        m = int(total.item())
+        if _PINNED_READ:
+            # the output size through pinned host memory and an event: no staging copy kernel, no implicit device sync
+            host = _pinned_total(dev)
+            host.copy_(total, non_blocking=True)
+            done = torch.cuda.Event(); done.record()
+            done.synchronize()
+            m = int(host[0])
+        else:
+            m = int(total.item())
         if m == n:  # every sample is visible: x[masks] would be a copy of x
             return None
         ri = torch.empty(m, dtype=torch.int64, device=dev)
