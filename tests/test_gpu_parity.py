@@ -1086,6 +1086,43 @@ def test_traversal_fuzz_bit_exact(dev, oracle):
             assert (ri.cpu().numpy() == rsm["ray_indices"][keep]).all() and (ts.cpu().numpy() == L).all() and (te.cpu().numpy() == Rr).all(), case
 
 
+def test_rows_dense_region_many_tiny_rays(dev):
+    """Thousands of rays of 0, 1 or 2 samples (an image region where almost nothing is hit): far more rays than elements
+    per 1024-element range, so tiles end on the 256-ray bound.  `rendering` forward and backward against the closed form
+    for such rays, and bit-identical to the same batch without its empty rays."""
+    rng = np.random.default_rng(202)
+    R = 60_000
+    cnt = rng.choice([0, 0, 0, 1, 1, 2], R).astype(np.int64)
+    cnt[1000:9000] = 0                                   # a long gap inside
+    n = int(cnt.sum())
+    ray = np.repeat(np.arange(R), cnt)
+    first = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    k = np.arange(n) - first[ray]                        # 0 or 1: position inside the ray
+    ts = rng.uniform(0.5, 1.0, n).astype(np.float32) + k.astype(np.float32); te = ts + np.float32(0.25)
+    sg = rng.uniform(0.0, 8.0, n).astype(np.float32); rgb = rng.random((n, 3)).astype(np.float32)
+    gw = rng.random((R, 3)).astype(np.float32)
+    def run(ri_np, n_rays, g_np):
+        s = T(sg, dev).requires_grad_(True); c = T(rgb, dev).requires_grad_(True)
+        out = na.rendering(T(ts, dev), T(te, dev), torch.from_numpy(ri_np).to(dev), n_rays=n_rays,
+                           rgb_sigma_fn=lambda a, b, r: (c, s))
+        (out[0] * T(g_np, dev)).sum().backward()
+        return out, s.grad, c.grad
+    full, gs, gc = run(ray, R, gw)
+    # closed form (float64): alpha_k = 1 - exp(-sigma_k delta_k), T_0 = 1, T_1 = exp(-sigma_0 delta_0)
+    d64 = (te - ts).astype(np.float64); a64 = 1 - np.exp(-sg.astype(np.float64) * d64)
+    prev = np.where(k > 0, np.roll(sg.astype(np.float64) * d64, 1), 0.0)
+    w64 = np.exp(-prev) * a64
+    col = np.zeros((R, 3)); np.add.at(col, ray, w64[:, None] * rgb.astype(np.float64))
+    assert np.abs(full[0].detach().cpu().numpy() - col).max() < 2e-6
+    assert np.abs(full[3]["weights"].detach().cpu().numpy() - w64).max() < 2e-6
+    assert np.abs(gc.cpu().numpy() - w64[:, None] * gw[ray].astype(np.float64)).max() < 2e-6
+    has = cnt > 0
+    rows = np.nonzero(has)[0]
+    comp, gs_c, gc_c = run(np.repeat(np.arange(rows.size), cnt[rows]), rows.size, gw[rows])
+    assert torch.equal(full[0][torch.from_numpy(rows).to(dev)], comp[0]) and bool((full[0][torch.from_numpy(~has).to(dev)] == 0).all())
+    assert torch.equal(gs, gs_c) and torch.equal(gc, gc_c)
+
+
 def test_compact_samples_consecutive_and_arbitrary_output_offsets(dev):
     """nfa_compact_samples through the C ABI: with the running-sum offsets the sampler passes (kept samples of a step are
     consecutive outputs: packed in LDS, written as vectors) and with per-ray output blocks in REVERSE ray order (not
