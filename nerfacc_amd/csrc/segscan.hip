@@ -64,9 +64,6 @@ constexpr int SEG_CHUNK = 64 * SE;      // elements per wave step
 #define NFA_SEG_TILE_ROWS 256
 #endif
 constexpr int64_t SEG_TILE_ROWS = NFA_SEG_TILE_ROWS;
-#ifndef NFA_SEG_SEARCH_MIN_ROWS
-#define NFA_SEG_SEARCH_MIN_ROWS 2048
-#endif
 #ifndef NFA_SEG_WINDOW_PREFETCH
 #define NFA_SEG_WINDOW_PREFETCH 0   /* measured: neutral on cfg 2 (the row-heavy tiles are dispatched first instead), compaction 10 % slower on cfg 5 */
 #endif
@@ -556,36 +553,9 @@ __device__ __forceinline__ void seg_run_tile(Op &op, const int64_t *__restrict__
             const int cnt = __builtin_popcountll(__ballot(take));
             v_next += cnt;
             if (v_next == win_base + 64 && v_next < n_own) {
-                // A window of 64 empty rows: the rays of a finished / background region all "start" at the same
-                // element and belong to this tile however many they are (0.5 M in a test-mode image).  Rows are
-                // sorted by start and of the rows with one start only the last can be non-empty, so the end of the
-                // run is found by a 64-ary search on the starts (4 dependent loads for 16 M rows) instead of
-                // walking it one window -- one dependent load -- at a time.
-                // (only for LONG runs: each probe round is a dependent load, so on a run of a few windows the search costs more
-                // than walking it -- the next window is already on its way; rays interleaved with runs of 64-500 empty ones
-                // made the fused passes 20 % slower through this path)
-                if (cnt == 64 && __ballot(take && win_n > 0) == 0ull && n_own - v_next >= NFA_SEG_SEARCH_MIN_ROWS) {
-                    const int64_t S = uniform64(__shfl(win_s, 63, 64));
-                    int32_t lo = v_next, hi = n_own;  // first v in [lo, hi] whose row is past the run
-                    while (hi - lo > 0) {
-                        const int32_t span = hi - lo;
-                        const int32_t probe = lo + (int32_t)(((int64_t)span * (lane + 1)) / 65);  // lo <= probe < hi, non-decreasing in lane
-                        const int64_t pray = DIR > 0 ? (int64_t)r_lo + probe : (int64_t)r_hi - 1 - probe;
-                        const int64_t ps = packed_info[2 * pray];
-                        const bool in_run = DIR > 0 ? ps <= S : ps >= S;  // a prefix of the probes (starts are monotone)
-                        const int k = __builtin_popcountll(__ballot(in_run));
-                        const int32_t p_last_in = k > 0 ? __shfl(probe, k - 1, 64) : lo - 1;
-                        const int32_t p_first_out = k < 64 ? __shfl(probe, k, 64) : hi;
-                        lo = p_last_in + 1;
-                        hi = p_first_out;
-                    }
-                    // forward: the last row with this start may be the non-empty one, it is left to the normal path
-                    const int32_t v_jump = DIR > 0 ? lo - 1 : lo;
-                    if (v_jump > v_next) {
-                        for (int32_t u = v_next + lane; u < v_jump; u += 64) op.empty_ray(DIR > 0 ? r_lo + u : r_hi - 1 - u);
-                        v_next = v_jump;
-                    }
-                }
+                // (A tile owns at most SEG_TILE_ROWS rows, i.e. a few windows: long runs of empty rays -- the background of an
+                //  image, the finished rays of the test-mode loop -- are spread over many tiles and walked in parallel.  The
+                //  64-ary search that used to skip such runs inside one tile is gone with the tiles that needed it.)
                 win_base = v_next;
                 load_window();
                 continue;

@@ -126,8 +126,8 @@ def test_automatic_ray_binning_decision(dev):
 
 def test_long_runs_of_empty_rays(dev):
     """Blocks of hundreds to hundreds of thousands of rays without samples (finished rays of the test-mode loop,
-    background pixels of an image-order batch): the engine jumps over them by a search on the row starts instead of
-    walking them.  Every packed op, forward and reverse scans and the fused rendering passes with gradients, must give
+    background pixels of an image-order batch): a tile ends after 256 rays, so such a block is spread over many tiles
+    instead of being walked by one wave.  Every packed op, forward and reverse scans and the fused rendering passes with gradients, must give
     for the rays that have samples exactly what it gives on the batch without the empty rays, and zeros elsewhere."""
     g = torch.Generator(device=dev); g.manual_seed(11)
     R = 300_000
