@@ -73,6 +73,9 @@ constexpr int64_t SEG_TILE_ROWS = NFA_SEG_TILE_ROWS;
 #ifndef NFA_BWD_PIPE
 #define NFA_BWD_PIPE 1
 #endif
+#ifndef NFA_VIS_EXP_FREE
+#define NFA_VIS_EXP_FREE 1
+#endif
 #ifndef NFA_VIS_PIPE
 #define NFA_VIS_PIPE 0
 #endif
@@ -991,6 +994,10 @@ struct VisibilityOp {
     struct Raw { F4 s, pf, a, b; };
     const float *ts, *te, *val, *prefix;
     float eps, thre;
+    // Density without a prefix: T = exp(-S) >= eps is decided on S (the scanned sum) wherever S is clearly on one side of
+    // -ln(eps); only inside a band of a few ulps around it is exp evaluated (same result as evaluating it everywhere: exp
+    // is computed with the library's own expf there).  s_lo / s_hi come from the host.
+    float s_lo, s_hi;
     uint8_t *vis;
     int64_t *cnts;
     float x0[SE], a4[SE], pf[SE];
@@ -1020,9 +1027,20 @@ struct VisibilityOp {
     __device__ __forceinline__ float x(int j, int) const { return x0[j]; }
     __device__ __forceinline__ void emit(int j, int64_t, bool valid, bool is_head, int, int, const float *, const float prev[1])
     {
-        float T = DENSITY ? expf(-(is_head ? 0.0f : prev[0])) : (is_head ? 1.0f : prev[0]);
-        if (prefix) T *= pf[j];
-        bool v = T >= eps;
+        bool v;
+        if (DENSITY && NFA_VIS_EXP_FREE && !prefix) {
+            const float S = is_head ? 0.0f : prev[0];
+            v = S <= s_lo;
+            const bool band = S > s_lo && S < s_hi;
+            if (__ballot(band) != 0ull) {   // wave-uniform, rare
+                asm volatile("; transmittance near the threshold" ::: "memory");
+                if (band) v = expf(-S) >= eps;
+            }
+        } else {
+            float T = DENSITY ? expf(-(is_head ? 0.0f : prev[0])) : (is_head ? 1.0f : prev[0]);
+            if (prefix) T *= pf[j];
+            v = T >= eps;
+        }
         if (thre > 0.0f) v = v && (a4[j] >= thre);
         m[j] = (valid && v) ? 1 : 0;
     }
@@ -2025,12 +2043,21 @@ int nfa_render_visibility(const float *t_starts, const float *t_ends, const floa
         NFA_REQUIRE(sigmas_or_alphas && vis, "render_visibility: null pointer");
         const bool density = t_starts != nullptr;
         NFA_REQUIRE(!density || t_ends, "render_visibility: t_ends is null");
+        // S = -ln(eps) is where exp(-S) crosses eps; expf is good to a couple of ulps, the band is +-2e-5 relative (~20 ulps)
+        float s_lo, s_hi;
+        if (early_stop_eps > 0.0f) {
+            const double L = -log((double)early_stop_eps);
+            const double w = 2e-5 * (L > 1.0 ? L : 1.0);
+            s_lo = (float)(L - w); s_hi = (float)(L + w);
+        } else {   // every transmittance >= eps (exp(-S) is never negative; a NaN sum stays invisible as before)
+            s_lo = INFINITY; s_hi = INFINITY;
+        }
         // the uchar4 mask store needs 4-byte alignment of vis, the float loads 16
         const bool vec = all_aligned16(t_starts, t_ends, sigmas_or_alphas, prefix_trans) &&
                          (reinterpret_cast<uintptr_t>(vis) & 3) == 0;
 #define NFA_VIS(DN, V, CN)                                                                                 \
     do { VisibilityOp<DN, V, CN> op; op.ts = t_starts; op.te = t_ends; op.val = sigmas_or_alphas; op.prefix = prefix_trans; \
-         op.eps = early_stop_eps; op.thre = alpha_thre; op.vis = vis; op.cnts = vis_cnts;                    \
+         op.eps = early_stop_eps; op.thre = alpha_thre; op.vis = vis; op.cnts = vis_cnts; op.s_lo = s_lo; op.s_hi = s_hi; \
          launch_seg<1>(op, packed_info, tiles, n_rays, n_tiles, s); } while (0)
 #define NFA_VIS2(DN, V) do { if (vis_cnts) NFA_VIS(DN, V, true); else NFA_VIS(DN, V, false); } while (0)
         if (density) { if (vec) NFA_VIS2(true, true); else NFA_VIS2(true, false); }
