@@ -1693,3 +1693,20 @@ def test_propnet_step_captures_into_a_hipgraph():
                            env=dict(os.environ, GB_R="8192", GB_EAGER_FIRST="1"))
         assert r.returncode == 0 and f"OK {piece} True" in r.stdout, (piece, r.returncode, r.stdout[-300:], r.stderr[-300:])
 
+
+
+def test_results_do_not_depend_on_the_tiling():
+    """The packed ops (rendering forward / backward, visibility, weights, accumulation, scans) on twelve random ragged
+    batches -- empty rays, runs of tiny rays, rays of thousands of samples -- give the same bits whatever the tile size:
+    the library reads NFA_SEG_TILE once per process, so each size runs in a child process (scripts/tiling_invariance.py)
+    and the digests of all outputs are compared."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "tiling_invariance.py")
+    digests = []
+    for tile in ("256", "1024", "3072"):
+        r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, NFA_SEG_TILE=tile))
+        assert r.returncode == 0 and "digest " in r.stdout, (tile, r.returncode, r.stdout[-300:], r.stderr[-300:])
+        digests.append(r.stdout.strip().splitlines()[-1])
+    assert digests[0] == digests[1] == digests[2], digests
