@@ -17,4 +17,6 @@ timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv 
 for cfg in cfg2_compacting cfg2_random cfg3 cfg5; do
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_${cfg}_trace -- python $R/bench.py --only $cfg --steps 12 > $OUT/${TAG}_${cfg}_trace.log 2>&1
 done
+# cfg 4's grid (256^3 shell10, the workload of bench.py --gpus N > 1) on one GPU
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_cfg4_256_trace -- python $R/bench.py --res 256 --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-pipelined --no-extras > $OUT/${TAG}_cfg4_256_trace.log 2>&1
 echo "profiles collected for $TAG"

@@ -62,7 +62,7 @@ for k, v in sorted(out.items(), key=lambda kv: -(kv[1]["avg_us"] or 0))[:12]:
     print(f"  {v['avg_us']:8.1f} us  {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB  {v['hbm_GBps']:8.1f} GB/s  {k[:70]}")
 
 # secondary configurations: kernel-trace stats only
-for cfg in ("cfg2_compacting", "cfg2_random", "cfg3", "cfg5"):
+for cfg in ("cfg2_compacting", "cfg2_random", "cfg3", "cfg5", "cfg4_256"):
     f = glob.glob(os.path.join(src, f"{tag}_{cfg}_trace/*/*_kernel_stats.csv"))
     if not f:
         continue
