@@ -351,6 +351,23 @@ class KernelTimer:
             timer.records.append((key, e0, e1))
 
         B.call = timed_call
+        self._orig_group = B.call_group
+
+        def timed_group(name, fn):
+            # one logical op issued as several launches on two streams: bracket the group on the calling stream (its last
+            # instruction there is the wait for the other stream) and keep the per-call events out of it
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            spin_lib.bf_spin(4000, torch.cuda.current_stream().cuda_stream)
+            e0.record()
+            B.call = timer._orig
+            try:
+                fn()
+            finally:
+                B.call = timed_call
+            e1.record()
+            timer.records.append((name, e0, e1))
+
+        B.call_group = timed_group
         for mod in list(sys.modules.values()):
             if getattr(mod, "__name__", "").startswith("nerfacc_amd") and getattr(mod, "B", None) is B:
                 pass  # modules reach call() through the B namespace, nothing else to patch
@@ -358,6 +375,7 @@ class KernelTimer:
     def uninstall(self):
         from nerfacc_amd import _backend as B
         B.call = self._orig
+        B.call_group = self._orig_group
 
     def summary(self, steps):
         torch.cuda.synchronize()
@@ -377,6 +395,7 @@ def algorithmic_bytes(R, M, Mv, res, G=1):
         "nfa_traverse_grids[mode=0]": R * (24 + 8) + grid + R * 8,                 # rays + planes, grid, counts
         "nfa_traverse_grids[mode=1]": R * (24 + 8) + grid + M * (4 + 4 + 8) + R * 16,  # + samples, packed_info
         "nfa_traverse_runs": R * (24 + 8) + grid + R * 8,                            # one DDA walk: rays, grid, counts
+        "nfa_traverse_onepass": R * (24 + 8) + grid + M * (4 + 4 + 8) + R * 16,      # B_trav: walk and expansion at the same time (two streams)
         "nfa_traverse_cone_runs": R * (24 + 8) + grid + R * 8,
         "nfa_expand_runs": M * (4 + 4 + 8) + R * 16,                                 # the sampler's output, once
         "nfa_expand_cone_runs": M * (4 + 4 + 8) + R * 16,
@@ -394,7 +413,7 @@ def algorithmic_bytes(R, M, Mv, res, G=1):
 
 
 #: what bounds each native call: the walk is bound by instruction issue, everything else streams
-KERNEL_BOUND = {"nfa_traverse_runs": "issue", "nfa_traverse_cone_runs": "issue", "nfa_traverse_grids[mode=0]": "issue",
+KERNEL_BOUND = {"nfa_traverse_runs": "issue", "nfa_traverse_onepass": "issue", "nfa_traverse_cone_runs": "issue", "nfa_traverse_grids[mode=0]": "issue",
                 "nfa_traverse_grids[mode=1]": "issue"}
 
 
@@ -794,8 +813,10 @@ def main():
             kernels = kernel_table(ksum, ab)
             # Op-level view: one logical op of the reference API may be several launches here.
             groups = {
-                "traverse_grids (nfa_traverse_runs + nfa_expand_runs [+ nfa_traverse_grids fill of overflow rays])":
-                    ["nfa_traverse_runs", "nfa_expand_runs", "nfa_traverse_grids[mode=0]", "nfa_traverse_grids[mode=1]"],
+                "traverse_grids (nfa_traverse_onepass: walk and expansion at the same time on two streams, offsets by look-back; or "
+                "nfa_traverse_runs + cumsum + nfa_expand_runs [+ nfa_traverse_grids fill of overflow rays])":
+                    ["nfa_traverse_onepass", "nfa_traverse_runs", "nfa_exclusive_cumsum_pairs_stats_i64", "nfa_expand_runs",
+                     "nfa_traverse_grids[mode=0]", "nfa_traverse_grids[mode=1]"],
                 "rendering fwd (render_weight_from_density + 3 accumulations, one pass)": ["nfa_render_fused_fwd"],
                 "rendering bwd (3 accumulations + render_weight_from_density, one pass)": ["nfa_render_fused_bwd"],
                 "render_weight_from_density fwd": ["nfa_render_from_density_fwd"],
@@ -823,7 +844,7 @@ def main():
                 pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
             except Exception:
                 pass
-            sym = {"nfa_traverse_runs": "walk_kernel", "nfa_expand_runs": "expand_runs_kernel",
+            sym = {"nfa_traverse_runs": "walk_kernel<", "nfa_expand_runs": "expand_runs_kernel",
                    "nfa_render_from_density_fwd": "DensityFwdOp", "nfa_render_from_density_bwd": "DensityBwdOp",
                    "nfa_render_accumulate_fwd": "RenderAccumOp", "nfa_render_accumulate_bwd": "RenderAccumBwdOp",
                    "nfa_render_fused_fwd": "RenderFusedFwdOp", "nfa_render_fused_bwd": "RenderFusedBwdOp",
