@@ -135,8 +135,9 @@ class OccGridEstimator(AbstractEstimator):
         -- rays rewritten in place after a prefetch (the usual double-buffer pattern) no longer match."""
         def tid(t):
             return None if t is None else (t.data_ptr(), tuple(t.shape), t._version)
+        # (the grid also by object identity: a re-assigned ``binaries`` may reuse the old one's address at version 0)
         return (tid(rays_o), tid(rays_d), tid(t_min), tid(t_max), float(near_plane), float(far_plane),
-                float(render_step_size), bool(stratified), float(cone_angle), tid(self.binaries))
+                float(render_step_size), bool(stratified), float(cone_angle), tid(self.binaries), id(self.binaries))
 
     @torch.no_grad()
     def prefetch_traversal(
@@ -298,6 +299,12 @@ class OccGridEstimator(AbstractEstimator):
             out.append(torch.cat([uni, occ], dim=0))
         return out
 
+    #: Process group over which :meth:`_update` keeps the grid identical on all ranks (``None``: no communication, the
+    #: reference's behaviour -- it is single-device).  OPT-IN, because it makes every call of ``update_every_n_steps`` /
+    #: ``_update`` a COLLECTIVE: all ranks of the group must call it at the same steps (same ``n``, same ``training`` flag),
+    #: with estimators that describe the same scene.  Extension: the reference has no such attribute.
+    sync_group = None
+
     @torch.no_grad()
     def _update(self, step: int, occ_eval_fn: Callable, occ_thre: float = 0.01, ema_decay: float = 0.95,
                 warmup_steps: int = 256) -> None:
@@ -305,20 +312,34 @@ class OccGridEstimator(AbstractEstimator):
 
         On a ROCm device the three stages are native passes (csrc/gridupd.hip): cell ids + jitter -> positions, the EMA /
         max scatter, and a device-side threshold + binarisation that writes the ``torch.bool`` buffer (the serialised
-        view) together with the traversal's bit-packed copy.  With ``torch.distributed`` initialised on several ranks the
-        occupancies are MAX-all-reduced before the threshold, so every rank ends with the same ``binaries`` whatever
-        cells it sampled (the reference is single-device)."""
+        view) together with the traversal's bit-packed copy.
+
+        With :attr:`sync_group` set, the ranks of that group end every update with the same ``occs`` / ``binaries`` whatever
+        cells each of them sampled: the per-cell maximum of the occupancies the ranks evaluated is MAX-all-reduced
+        and the decay is applied to the UNION of the sampled cells -- ``occs = max(occs * decay, max over ranks of occ)``
+        wherever some rank sampled the cell -- so the grid is pruned as fast as on one device (a MAX over the ranks' already
+        updated ``occs`` would decay a cell only when every rank happened to sample it).  One all-reduce of ``occs``' size."""
         if step < warmup_steps:
             lvl_indices = self._get_all_cells()
         else:
             lvl_indices = self._sample_uniform_and_occupied_cells(self.cells_per_lvl // 4)
-        for lvl, indices in enumerate(lvl_indices):
-            jitter = torch.rand((indices.shape[0], self.DIM), dtype=torch.float32, device=indices.device)   # ref :385
-            x = self._cell_points(lvl, indices, jitter)
-            occ = occ_eval_fn(x).squeeze(-1)
-            self._ema_update(lvl, indices, occ, ema_decay)
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            torch.distributed.all_reduce(self.occs, op=torch.distributed.ReduceOp.MAX)
+        group = self.sync_group
+        if group is not None and torch.distributed.get_world_size(group) > 1:
+            cand = torch.full_like(self.occs, float("-inf"))     # per cell: the largest occupancy this rank evaluated
+            for lvl, indices in enumerate(lvl_indices):
+                jitter = torch.rand((indices.shape[0], self.DIM), dtype=torch.float32, device=indices.device)   # ref :385
+                occ = occ_eval_fn(self._cell_points(lvl, indices, jitter)).squeeze(-1).to(torch.float32)
+                cand.scatter_reduce_(0, lvl * self.cells_per_lvl + indices, occ, reduce="amax", include_self=True)
+            torch.distributed.all_reduce(cand, op=torch.distributed.ReduceOp.MAX, group=group)
+            sampled = cand > float("-inf")
+            self.occs = torch.where(sampled, torch.maximum(self.occs * ema_decay, cand), self.occs)
+            self._occs_mean_cache = None
+        else:
+            for lvl, indices in enumerate(lvl_indices):
+                jitter = torch.rand((indices.shape[0], self.DIM), dtype=torch.float32, device=indices.device)   # ref :385
+                x = self._cell_points(lvl, indices, jitter)
+                occ = occ_eval_fn(x).squeeze(-1)
+                self._ema_update(lvl, indices, occ, ema_decay)
         self._rebinarize(occ_thre)
 
     def _cell_points(self, lvl: int, indices: Tensor, jitter: Tensor) -> Tensor:
@@ -350,15 +371,20 @@ class OccGridEstimator(AbstractEstimator):
         self._occs_mean_cache = None   # (the kernel wrote through the raw pointer: the version counter did not move)
 
     def _rebinarize(self, occ_thre: float) -> None:
-        """``binaries = occs > clamp(mean(occs[occs >= 0]), max=occ_thre)`` (ref :403-404)."""
+        """``binaries = occs > clamp(mean(occs[occs >= 0]), max=occ_thre)`` (ref :403-404).
+
+        The native pass accumulates the mean in fp64 and rounds it to fp32 once; the reference's ``torch.mean`` is an fp32
+        tree reduction whose order differs between its own CPU and CUDA backends, so the threshold is defined only up to
+        an ulp there too: cells whose occupancy equals the threshold to within that ulp may fall on either side (the grid
+        tests compare ``binaries`` away from the threshold's edge, ``tests/test_gpu_parity.py::test_grid_update_kernels_vs_oracle``)."""
         if not self.occs.is_cuda:
             thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre)
             self.binaries = (self.occs > thre).view(self.binaries.shape)
             return
-        from ..grid import WALK_MAX_RES
+        from ..grid import _walk_supported
         dev = self.occs.device
         shape = tuple(self.binaries.shape)
-        if max(shape[1:]) > WALK_MAX_RES:   # beyond the packed walk's range: the reference's expression
+        if not _walk_supported(self.binaries):   # beyond the packed walk's range: the reference's expression
             thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre)
             self.binaries = (self.occs > thre).view(self.binaries.shape)
             return

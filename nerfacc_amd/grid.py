@@ -184,7 +184,7 @@ def traverse_grids(
             # masks (grid.cu:401-403, examples/utils.py:362-365).
             iv_starts = _exclusive_cumsum(iv_cnts, totals[0:1])
             sm_starts = _exclusive_cumsum(sm_cnts, totals[1:2])
-        elif float(step_size) > 0.0 and float(cone_angle) == 0.0 and max(binaries.shape[1:]) <= WALK_MAX_RES:
+        elif float(step_size) > 0.0 and float(cone_angle) == 0.0 and _walk_supported(binaries):
             # constant step: ONE walk (run records) + two coalesced expansions instead of the reference's count and
             # fill passes (grid.cu:405-471); rays with more than MAX_RUNS runs are filled by the serial kernel.
             iv_cnts, sm_cnts = torch.empty(n_rays, **i64), torch.empty(n_rays, **i64)
@@ -282,6 +282,16 @@ def _get_bricks(binaries: Tensor):
 
 
 WALK_MAX_RES = 512  # cells per axis the run-length walk's packed step counters cover (csrc/walk.hip)
+
+
+def _walk_supported(binaries: Tensor) -> bool:
+    """The run-length walk's limits (csrc/walk.hip): at most 512 cells per axis, and the bit-interleaved cell index of all
+    levels together below 2^31 (``n_grids << bits``; asked from the library, which owns the layout); grids beyond take
+    the generic kernels of ``nfa_traverse_grids``."""
+    if max(binaries.shape[1:]) > WALK_MAX_RES:
+        return False
+    res = (C.c_int32 * 3)(*binaries.shape[1:])
+    return int(B.load().nfa_walk_bits_words(binaries.shape[0], res)) * 32 < (1 << 31)
 
 
 def _get_walk_bits(binaries: Tensor) -> Tensor:
@@ -429,7 +439,7 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
     rays get no samples, every other ray at most ``traverse_steps_limit``.
     """
     limit = -1 if traverse_steps_limit is None else int(traverse_steps_limit)
-    use_runs = float(step_size) > 0.0 and float(cone_angle) == 0.0 and max(binaries.shape[1:]) <= WALK_MAX_RES
+    use_runs = float(step_size) > 0.0 and float(cone_angle) == 0.0 and _walk_supported(binaries)
     # distance-dependent steps: run records from the count pass + a coalesced expansion instead of a second walk
     use_cone_runs = CONE_RUNS and float(step_size) > 0.0 and float(cone_angle) > 0.0
     if not use_runs and (rays_mask is not None or limit > 0):

@@ -143,13 +143,19 @@ def _importance_sampling_packed(intervals: RayIntervals, cdfs: Tensor, counts: T
         n_rays, per = pi.shape[0], 0
     counts = counts.reshape(-1).to(torch.int64).contiguous()
     assert counts.shape[0] == n_rays, "n_intervals_per_ray must have one entry per ray"
+    # validated BEFORE anything is sized from them: no negative count, and no samples asked of a ray without input
+    # intervals (the kernel has nothing to resample there and would leave the ray's output range unwritten)
+    if n_rays:
+        empty_in = (pi[:, 1] < 2) if pi is not None else torch.full((n_rays,), per < 2, dtype=torch.bool, device=dev)
+        bad = torch.stack([(counts < 0).any(), ((counts > 0) & empty_in).any()]).tolist()
+        assert not bad[0], "negative sample count"
+        assert not bad[1], "n_intervals_per_ray asks for samples on a ray that has no input interval"
     with torch.cuda.device(dev):
         totals = torch.empty(2, dtype=torch.int64, device=dev)
         iv_counts = (counts + 1) * (counts > 0)                     # pdf.cu:341-342
         sm_packed = _cumsum_packed(counts, totals[0:1])
         iv_packed = _cumsum_packed(iv_counts, totals[1:2])
         n_sm, n_iv = (int(v) for v in totals.tolist())             # the one device->host read (data_spec.hpp:91)
-        assert int(counts.min()) >= 0 if n_rays else True, "negative sample count"
         sm_vals = torch.empty(n_sm, dtype=torch.float32, device=dev)
         sm_ri = torch.empty(n_sm, dtype=torch.int64, device=dev)
         iv_vals = torch.empty(n_iv, dtype=torch.float32, device=dev)

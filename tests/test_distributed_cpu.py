@@ -42,21 +42,31 @@ def _worker(rank, world, port, q):
     # same torch.bool grid (here 32^3; the bench uses 256^3)
     shared = bench.shared_grid(torch.device("cpu"), 32, "shell10", rank, w)
     grid_sha = __import__("hashlib").sha256(shared.numpy().tobytes()).hexdigest()
-    # grid maintenance across ranks: every rank updates its occupancies from its own samples (here: its own field),
-    # OccGridEstimator._update MAX-all-reduces them before the threshold -> identical binaries everywhere
+    # grid maintenance across ranks: every rank updates its occupancies from its own samples (here: its own field); with
+    # OccGridEstimator.sync_group set (opt-in: it makes _update a collective) the evaluated occupancies are MAX-all-reduced
+    # and the decay is applied to the union of the sampled cells -> identical occs / binaries everywhere
     import nerfacc_amd as na
     torch.manual_seed(100 + rank)
     est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=12, levels=1)
+    assert est.sync_group is None                       # the default communicates nothing (the reference is single-device)
     est._update(step=0, occ_eval_fn=lambda x: (x[:, rank:rank + 1] > 0).float() * 0.5, occ_thre=0.01, ema_decay=0.95)
-    upd_sha = __import__("hashlib").sha256(est.binaries.numpy().tobytes()).hexdigest()
-    upd_frac = float(est.binaries.float().mean())
+    local_frac = float(est.binaries.float().mean())     # one half-space: this rank's own field only
+    est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=12, levels=1)
+    est.sync_group = torch.distributed.group.WORLD
+    est._update(step=0, occ_eval_fn=lambda x: (x[:, rank:rank + 1] > 0).float() * 0.5, occ_thre=0.01, ema_decay=0.95)
+    # a second update after the warm-up: every rank samples DIFFERENT cells (its own RNG) and evaluates an empty field; the
+    # union of the sampled cells must decay on every rank alike
+    est._update(step=1000, occ_eval_fn=lambda x: torch.zeros_like(x[:, :1]), occ_thre=0.01, ema_decay=0.5, warmup_steps=256)
+    upd_sha = __import__("hashlib").sha256(est.binaries.numpy().tobytes() + est.occs.numpy().tobytes()).hexdigest()
+    upd_frac = float((est.occs > 0).float().mean())
+    decayed = float(((est.occs > 0) & (est.occs < 0.5)).float().mean())
     g, n = _local_grad(rank)
     p = torch.nn.Parameter(torch.zeros(2, dtype=torch.float64))
     p.grad = torch.tensor([g, float(n)], dtype=torch.float64)
     bench.allreduce_grads([p], w)
     torch.distributed.barrier()
     dt = bench.max_over_ranks(0.1 * (rank + 1), w)
-    q.put((rank, p.grad.tolist(), dt, grid_sha, tuple(shared.shape), upd_sha, upd_frac))
+    q.put((rank, p.grad.tolist(), dt, grid_sha, tuple(shared.shape), upd_sha, upd_frac, local_frac, decayed))
     torch.distributed.destroy_process_group()
 
 
@@ -76,9 +86,11 @@ def test_two_rank_gradient_allreduce_matches_union_batch():
     sys.path.insert(0, ROOT)
     import bench
     want = __import__("hashlib").sha256(bench.make_grid(32, "shell10").tobytes()).hexdigest()
-    assert res[0][5] == res[1][5]                               # same binaries after the MAX-all-reduced update ...
+    assert res[0][5] == res[1][5]                               # same occs and binaries after the synchronised updates ...
     assert 0.70 < res[0][6] < 0.80                              # ... = the union of the two half-spaces (x > 0) | (y > 0)
-    for rank, grad, dt, grid_sha, shape, _, _ in res:
+    assert all(0.45 < r[7] < 0.55 for r in res)                # without sync_group a rank sees its own half-space only
+    assert res[0][8] == res[1][8] and res[0][8] > 0.2           # the cells either rank sampled in the second update decayed on both
+    for rank, grad, dt, grid_sha, shape, _, _, _, _ in res:
         assert grid_sha == want and shape == (1, 32, 32, 32)   # identical binaries on every rank (= rank 0's grid)
         assert abs(grad[0] - (g0 + g1)) < 1e-9 * max(1.0, abs(g0 + g1))
         assert grad[1] == n0 + n1
