@@ -519,7 +519,7 @@ def extra_cfg3(dev, R, steps, field="native"):
             "native_ms_per_step": sum(v["ms_per_step"] for v in ks.values()), "kernels": kernels}
 
 
-def extra_cfg5(dev, R, steps, res=512, G=4):
+def extra_cfg5(dev, R, steps, res=512, G=4, parity=True, train=True):
     """BASELINE cfg 5: G nested res^3 levels, R rays from inside the level-0 box, step 1e-3, cone 0.004, near 0.2,
     alpha_thre 1e-2, early_stop_eps 1e-4: train-mode sampling + rendering fwd + bwd."""
     import nerfacc_amd as na
@@ -547,19 +547,99 @@ def extra_cfg5(dev, R, steps, res=512, G=4):
         params.grad = None
         colors.sum().backward()
         last["m"] = ri.numel()
+        last["out"] = (ri, ts, te, colors)
         return ri.numel()
 
-    dt, ks, m = timed_steps(step, steps, 2)
-    ri, ts, te, pi = na.grid._traverse_samples(rays_o, rays_d, est.binaries, est.aabbs, torch.full((R,), 0.2, device=dev),
-                                               torch.full((R,), 1e10, device=dev), 1e-3, 0.004)
-    M = int(ri.numel())
-    del ri, ts, te, pi
-    kernels = kernel_table(ks, algorithmic_bytes(R, M, int(m), res, G))
-    return {"workload": f"cfg5: {G} nested {res}^3 levels, R={R} rays from inside, step 1e-3, cone 0.004, near 0.2, "
-                        f"alpha_thre 1e-2, sampling + rendering fwd + bwd",
-            "ms_per_step": dt * 1e3, "rays_per_s": R / dt, "samples_before_compaction": M, "samples_after_compaction": int(m),
-            "native_ms_per_step": sum(v["ms_per_step"] for v in ks.values()),
-            "kernels": {k: {kk: vv for kk, vv in v.items() if kk != "launches_per_step"} for k, v in kernels.items()}}
+    out = {"workload": f"cfg5: {G} nested {res}^3 levels, R={R} rays from inside, step 1e-3, cone 0.004, near 0.2, "
+                       f"alpha_thre 1e-2, sampling + rendering fwd + bwd"}
+    if train:
+        dt, ks, m = timed_steps(step, steps, 2)
+        ri, ts, te, pi = na.grid._traverse_samples(rays_o, rays_d, est.binaries, est.aabbs, torch.full((R,), 0.2, device=dev),
+                                                   torch.full((R,), 1e10, device=dev), 1e-3, 0.004)
+        M = int(ri.numel())
+        del ri, ts, te, pi
+        kernels = kernel_table(ks, algorithmic_bytes(R, M, int(m), res, G))
+        out.update({"ms_per_step": dt * 1e3, "rays_per_s": R / dt, "samples_before_compaction": M, "samples_after_compaction": int(m),
+                    "native_ms_per_step": sum(v["ms_per_step"] for v in ks.values()),
+                    "kernels": {k: {kk: vv for kk, vv in v.items() if kk != "launches_per_step"} for k, v in kernels.items()}})
+    # ---- the a12 test-mode loop on the same scene (SURVEY 8d cfg 5: "run both sampling (train) and the test-mode loop")
+    from nerfacc_amd.marching import render_rays_test_mode
+    tm_kw = dict(near_plane=0.2, render_step_size=1e-3, cone_angle=0.004, alpha_thre=1e-2, early_stop_eps=1e-4)
+    with torch.no_grad():
+        render_rays_test_mode(1024, fld.rgb_sigma_fn, est, rays_o, rays_d, **tm_kw)            # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_img = max(1, steps // 2)
+        for _ in range(n_img):
+            rgb_t, opa_t, dep_t, total_t = render_rays_test_mode(1024, fld.rgb_sigma_fn, est, rays_o, rays_d, **tm_kw)
+        torch.cuda.synchronize()
+        dt_img = (time.perf_counter() - t0) / n_img
+    out["test_mode_loop"] = {"workload": f"render_rays_test_mode (examples/utils.py:252-425), max_samples 1024, the same {R} rays",
+                             "ms_per_image": dt_img * 1e3, "rays_per_s": R / dt_img, "total_samples": int(total_t)}
+    # ---- parity at full size: every `stride`-th ray of the timed batch restated by the oracle
+    if parity and train:
+        try:
+            out.update(_cfg5_parity(dev, est, fld, o, d, last, R, tm_kw))
+        except Exception as e:  # the check must never cost the timing
+            out["parity_error"] = repr(e)
+    return out
+
+
+def _cfg5_parity(dev, est, fld, o, d, last, R, tm_kw, stride=256):
+    """cfg 5 after its timed loop: every 256th ray of the timed batch restated by the oracle -- (ray_indices, t_starts, t_ends)
+    bit for bit (guard band on the visibility thresholds, oracle/check.py), colours within 1e-5; the test-mode loop on a
+    2048-ray subset against oracle.test_mode_loop; and the oracle's time for that sample as cfg 5's CPU baseline."""
+    from oracle import check as OC
+    from oracle import oracle as O
+    from nerfacc_amd.marching import render_rays_test_mode
+    O.build()
+    b = est.binaries.cpu().numpy()
+    ab = est.aabbs.cpu().numpy()
+    sel = np.arange(0, R, stride)
+    os_, ds_ = np.ascontiguousarray(o[sel]), np.ascontiguousarray(d[sel])
+    sig = lambda ts, te, ri: (np.float32(fld.sigma_scale) * (4.0 * (0.5 + 0.5 * np.sin(20.0 * (ts + te))))).astype(np.float32)
+    occs_mean = float(b.mean())
+    t0 = time.perf_counter()
+    (ori, ots, ote), (fri, fts, fte, fpi) = O.occgrid_sampling(os_, ds_, b, ab, sigma_fn=sig, near_plane=0.2, render_step_size=1e-3,
+                                                               cone_angle=0.004, alpha_thre=1e-2, early_stop_eps=1e-4,
+                                                               occs_mean=occs_mean, return_all=True)
+    s_o = sig(ots, ote, ori)
+    oc, oo, od, _ = O.rendering(ots, ote, ori, sel.size, np.repeat(ots[:, None], 3, 1), sigmas=s_o)
+    g_w = np.repeat(ots[:, None], 3, 1).sum(-1)
+    O.render_weight_from_density_backward(ots, ote, s_o, O.pack_info(ori, sel.size), g_w)
+    t_cpu = time.perf_counter() - t0
+    tr, al = O.render_transmittance_from_density(fts, fte, sig(fts, fte, fri), fpi)
+    ri, ts, te, colors = last["out"]
+    keep = (ri % stride) == 0
+    got = ((ri[keep] // stride).cpu().numpy(), ts[keep].cpu().numpy(), te[keep].cpu().numpy())
+    ok, info = OC.compare_sampling(got, (ori, ots, ote), (fri, fts, fte), tr, al, early_stop_eps=1e-4, alpha_thre=min(1e-2, occs_mean))
+    cg = colors.detach()[torch.from_numpy(sel).to(dev)].cpu().numpy()
+    scale = max(1.0, float(np.abs(oc).max()))
+    # colours of the rays none of whose samples lies on a visibility threshold's guard band (such a sample may be kept or
+    # dropped, which changes its ray's colour; oracle/check.py)
+    near = (np.abs(tr - np.float32(1e-4)) < 1e-6) | (np.abs(al - np.float32(min(1e-2, occs_mean))) < 1e-6)
+    clean = np.ones(sel.size, bool); clean[np.unique(fri[near])] = False
+    cerr = float(np.abs(cg - oc)[clean].max())
+    info.update(rays=int(sel.size), rays_compared_for_colours=int(clean.sum()), colors_max_abs_err=cerr, colors_tolerance=1e-5 * scale)
+    ok = ok and cerr <= 1e-5 * scale
+    res = {"parity_checked": bool(ok), "parity": info,
+           "cpu_baseline": {"value": sel.size / t_cpu, "unit": "rays/s", "cores": O.max_threads(), "kind": "port", "cpu_model": cpu_model(),
+                            "sample": f"every {stride}th ray of the batch ({sel.size} rays, {int(fri.size)} samples before / {int(ori.size)} after "
+                                      f"compaction), one pass of sampling + rendering forward + backward, {t_cpu:.1f} s"}}
+    # test-mode loop, 2048-ray subset (the schedule depends on the number of rays, so the subset is its own image)
+    sub = np.arange(0, R, R // 2048)[:2048]
+    o2, d2 = np.ascontiguousarray(o[sub]), np.ascontiguousarray(d[sub])
+    with torch.no_grad():
+        rgb, opa, dep, total = render_rays_test_mode(1024, fld.rgb_sigma_fn, est, torch.from_numpy(o2).to(dev), torch.from_numpy(d2).to(dev), **tm_kw)
+    field_np = lambda ts, te, ri: (np.repeat((ts * np.float32(1.0))[:, None], 3, 1).astype(np.float32), sig(ts, te, ri))
+    orgb, oopa, odep, ototal, tinfo = O.test_mode_loop(1024, field_np, o2, d2, b, ab, **tm_kw)
+    e_rgb = float(np.abs(rgb.cpu().numpy() - orgb).max()); e_opa = float(np.abs(opa.cpu().numpy() - oopa).max())
+    guarded = int(tinfo["guard_rays"].sum())
+    tm_ok = (total == ototal or guarded > 0) and e_rgb <= 2e-5 * max(1.0, float(np.abs(orgb).max())) and e_opa <= 2e-5
+    res["test_mode_parity"] = {"checked": bool(tm_ok), "rays": int(sub.size), "total_samples": int(total), "oracle_total_samples": int(ototal),
+                               "rays_on_the_termination_threshold": guarded, "rgb_max_abs_err": e_rgb, "opacity_max_abs_err": e_opa,
+                               "iterations": int(tinfo["iterations"])}
+    return res
 
 
 # ----------------------------------------------------------------------------- CPU baseline (oracle, bounded sample) + parity
@@ -678,7 +758,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the second (software-pipelined) timed loop")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary configurations (cfg2 variants, cfg3, cfg5)")
-    ap.add_argument("--only", default="", choices=["", "cfg2_compacting", "cfg2_random", "cfg3", "cfg5"],
+    ap.add_argument("--only", default="", choices=["", "cfg2_compacting", "cfg2_random", "cfg3", "cfg5", "cfg5_testmode"],
                     help="run ONE secondary configuration alone and print its object (for rocprofv3 passes: profiles/<round>_<cfg>_*)")
     args = ap.parse_args()
 
@@ -702,7 +782,8 @@ def main():
         fn = {"cfg2_compacting": lambda: extra_cfg2_variant(dev, args, sigma_scale=16.0),
               "cfg2_random": lambda: extra_cfg2_variant(dev, args, rays="random"),
               "cfg3": lambda: extra_cfg3(dev, 1 << 20, max(3, args.steps // 4), args.field),
-              "cfg5": lambda: extra_cfg5(dev, 1 << 21, max(2, args.steps // 6))}[args.only]
+              "cfg5": lambda: extra_cfg5(dev, 1 << 21, max(2, args.steps // 6)),
+              "cfg5_testmode": lambda: extra_cfg5(dev, 1 << 21, max(2, args.steps // 6), train=False)}[args.only]
         print(json.dumps({args.only: fn()}))
         return
 

@@ -436,6 +436,67 @@ def occgrid_sampling(rays_o, rays_d, binaries, aabbs, sigma_fn=None, alpha_fn=No
 
 
 # --------------------------------------------------------------------------- proposal-network sampling
+def test_mode_loop(max_samples, rgb_sigma_fn, rays_o, rays_d, binaries, aabbs, near_plane=0.0, far_plane=1e10,
+                   render_step_size=1e-3, render_bkgd=None, cone_angle=0.0, alpha_thre=0.0, early_stop_eps=1e-4,
+                   guard=1e-5):
+    """The caller harness ``render_image_with_occgrid_test`` (ref: examples/utils.py:252-425) restated
+    on this oracle's ``traverse_grids(over_allocate=True, rays_mask, traverse_steps_limit)``:
+
+        n_samples = max(min(num_rays // n_alive, 64), min_samples)            (:338; min_samples 1, or 4 with a cone :312)
+        traverse the alive rays for at most n_samples steps from the previous termination planes     (:342-360, :407)
+        weights with prefix_trans = 1 - opacity[ray_indices]                    (:370-377)
+        alpha_thre mask, in-place accumulation of rgb / opacity / depth         (:379-405)
+        alive = (opacity <= 1 - early_stop_eps) & (samples taken == n_samples)  (:409-414)
+        final blend with the background, depth / max(opacity, eps)             (:417-422)
+
+    ``rgb_sigma_fn(t_starts, t_ends, ray_indices) -> (rgbs (N, 3), sigmas (N,))`` in numpy.  Returns ``(rgb, opacity, depth,
+    total_samples, info)``; ``info["guard_rays"]``: rays whose opacity came within ``guard`` of the early-termination
+    threshold at the end of some iteration -- for those a last-ulp difference of ``exp`` decides whether the ray stays
+    alive (and, through ``n_alive``, may shift everybody's schedule); a comparison is exact only when there is none."""
+    rays_o, rays_d = _f32(rays_o), _f32(rays_d)
+    n = rays_o.shape[0]
+    opacity = np.zeros((n, 1), np.float32); depth = np.zeros((n, 1), np.float32); rgb = np.zeros((n, 3), np.float32)
+    mask = np.ones(n, bool)
+    min_samples = 1 if cone_angle == 0 else 4
+    near = np.full(n, near_plane, np.float32); far = np.full(n, far_plane, np.float32)
+    t_mins, t_maxs, hits = ray_aabb_intersect(rays_o, rays_d, aabbs)
+    t_sorted, t_indices = sort_intersections(t_mins, t_maxs)
+    it = total = iters = 0
+    guard_rays = np.zeros(n, bool)
+    per_ray = np.zeros(n, np.int64)
+    thre = np.float32(1 - early_stop_eps)
+    while it < max_samples:
+        n_alive = int(mask.sum())
+        if n_alive == 0:
+            break
+        ns = max(min(n // n_alive, 64), min_samples)
+        it += ns
+        iters += 1
+        iv, sm, term = traverse_grids(rays_o, rays_d, binaries, aabbs, near, far, render_step_size, cone_angle, ns, True, mask,
+                                      t_sorted, t_indices, hits)
+        ts, te = iv["vals"][iv["is_left"]], iv["vals"][iv["is_right"]]
+        ri = sm["ray_indices"][sm["is_valid"]]
+        pi = sm["packed_info"]
+        if len(ri):
+            rgbs, sig = rgb_sigma_fn(ts, te, ri)
+            w, _, al = render_weight_from_density(ts, te, sig, pack_info(ri, n), prefix_trans=1 - opacity[ri, 0])
+            if alpha_thre > 0:
+                v = al >= alpha_thre
+                ri, rgbs, w, ts, te = ri[v], rgbs[v], w[v], ts[v], te[v]
+            np.add.at(rgb, ri, (w[:, None] * rgbs).astype(np.float32))
+            np.add.at(opacity, ri, w[:, None].astype(np.float32))
+            np.add.at(depth, ri, (w[:, None] * ((ts + te)[:, None] / np.float32(2.0))).astype(np.float32))
+            np.add.at(per_ray, ri, 1)
+        near = term
+        guard_rays |= mask & (np.abs(opacity[:, 0] - thre) <= guard)
+        mask = (opacity[:, 0] <= thre) & (pi[:, 1] == ns)
+        total += len(ri)
+    if render_bkgd is not None:
+        rgb = rgb + _f32(render_bkgd) * (1.0 - opacity)
+    depth = depth / np.maximum(opacity, np.finfo(np.float32).eps)
+    return rgb, opacity, depth, total, dict(guard_rays=guard_rays, samples_per_ray=per_ray, iterations=iters)
+
+
 def transform_stot(transform_type, s_vals, t_min, t_max):
     """nerfacc/estimators/prop_net.py:215-229, same fp32 operation order."""
     s = _f32(s_vals)

@@ -1298,48 +1298,6 @@ def test_cuda_compat_module_matches_pybind_surface(dev, oracle):
 
 
 # ----------------------------------------------------------------------------- test-mode marching loop
-def _oracle_test_mode_loop(O, max_samples, rgb_sigma, rays_o, rays_d, binaries, aabbs, near_plane, far_plane, step,
-                           bkgd, cone_angle, alpha_thre, early_stop_eps):
-    """numpy restatement of examples/utils.py:252-425 on the oracle's traverse_grids(over_allocate=True)."""
-    n = rays_o.shape[0]
-    opacity = np.zeros((n, 1), np.float32); depth = np.zeros((n, 1), np.float32); rgb = np.zeros((n, 3), np.float32)
-    mask = np.ones(n, bool)
-    min_samples = 1 if cone_angle == 0 else 4
-    near = np.full(n, near_plane, np.float32); far = np.full(n, far_plane, np.float32)
-    t_mins, t_maxs, hits = O.ray_aabb_intersect(rays_o, rays_d, aabbs)
-    t_sorted, t_indices = O.sort_intersections(t_mins, t_maxs)
-    it = total = 0
-    min_margin = np.inf
-    while it < max_samples:
-        n_alive = int(mask.sum())
-        if n_alive == 0:
-            break
-        ns = max(min(n // n_alive, 64), min_samples)
-        it += ns
-        iv, sm, term = O.traverse_grids(rays_o, rays_d, binaries, aabbs, near, far, step, cone_angle, ns, True, mask,
-                                        t_sorted, t_indices, hits)
-        ts, te = iv["vals"][iv["is_left"]], iv["vals"][iv["is_right"]]
-        ri = sm["ray_indices"][sm["is_valid"]]
-        pi = sm["packed_info"]
-        if len(ri):
-            rgbs, sig = rgb_sigma(ts, te, ri)
-            w, _, al = O.render_weight_from_density(ts, te, sig, O.pack_info(ri, n), prefix_trans=1 - opacity[ri, 0])
-            if alpha_thre > 0:
-                v = al >= alpha_thre
-                ri, rgbs, w, ts, te = ri[v], rgbs[v], w[v], ts[v], te[v]
-            np.add.at(rgb, ri, (w[:, None] * rgbs).astype(np.float32))
-            np.add.at(opacity, ri, w[:, None].astype(np.float32))
-            np.add.at(depth, ri, (w[:, None] * ((ts + te)[:, None] / np.float32(2.0))).astype(np.float32))
-        near = term
-        alive_op = opacity[:, 0] <= 1 - early_stop_eps
-        min_margin = min(min_margin, float(np.abs(opacity[mask, 0] - (1 - early_stop_eps)).min()))
-        mask = alive_op & (pi[:, 1] == ns)
-        total += len(ri)
-    rgb = rgb + bkgd * (1.0 - opacity)
-    depth = depth / np.maximum(opacity, np.finfo(np.float32).eps)
-    return rgb, opacity, depth, total, min_margin
-
-
 @pytest.mark.parametrize("levels,cone,alpha_thre", [(1, 0.0, 0.0), (2, 0.0, 0.02), (2, 0.004, 0.0)])
 def test_test_mode_marching_loop(dev, oracle, levels, cone, alpha_thre):
     from nerfacc_amd.marching import render_rays_test_mode
@@ -1367,15 +1325,101 @@ def test_test_mode_marching_loop(dev, oracle, levels, cone, alpha_thre):
     rgb, opa, dep, total = render_rays_test_mode(600, field_t, est, T(o, dev), T(d, dev), near_plane=0.05, far_plane=1e10,
                                                  render_step_size=step, render_bkgd=T(bk, dev), cone_angle=cone,
                                                  alpha_thre=alpha_thre, early_stop_eps=1e-3)
-    orgb, oopa, odep, ototal, margin = _oracle_test_mode_loop(oracle, 600, field_np, o, d, b, est.aabbs.cpu().numpy(), 0.05, 1e10,
-                                                              step, bk, cone, alpha_thre, 1e-3)
+    orgb, oopa, odep, ototal, info = oracle.test_mode_loop(600, field_np, o, d, b, est.aabbs.cpu().numpy(), 0.05, 1e10, step, bk,
+                                                           cone, alpha_thre, 1e-3, guard=2e-6)
     assert ototal > 10000
-    if margin > 1e-5:  # no ray sits on the early-termination threshold: the schedules are identical
-        assert total == ototal
-    assert abs(total - ototal) <= 64 * 4
+    # Rays that end an iteration within 2e-6 of the early-termination threshold (opacities agree to ~1e-7; near the threshold
+    # a sample moves the opacity by ~1e-4, so a few percent of the rays pass that close) may live one iteration longer on
+    # one side: at most 64 samples each.  Every other ray is identical, and without such rays so is the sample count.
+    g = info["guard_rays"]
+    assert g.mean() < 0.1
+    assert abs(total - ototal) <= 64 * int(g.sum())
+    k = torch.from_numpy(~g).to(dev)
+    assert_close(opa[k], oopa[~g], atol=2e-5, rtol=1e-5); assert_close(rgb[k], orgb[~g], atol=2e-5, rtol=1e-5)
+    assert_close(dep[k], odep[~g], atol=1e-4, rtol=1e-4)
+    assert (opa.max() <= 1.0 + 1e-5) and (opa.min() >= 0)
+
+
+def _cfg5_scene(dev, res=512, levels=4, seed=5):
+    """BASELINE cfg 5's scene (bench.extra_cfg5): nested levels, a shell r in (0.5, 0.66) of each level's own box + 2 % speckle."""
+    est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=res, levels=levels).to(dev)
+    ax = (torch.arange(res, device=dev, dtype=torch.float32) + 0.5) / res * 2 - 1
+    r = torch.sqrt(ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :] ** 2)
+    shell = (r > 0.5) & (r < 0.66)
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    b = torch.stack([shell | (torch.rand((res, res, res), device=dev, generator=g) < 0.02) for _ in range(levels)])
+    est.binaries = b
+    est.occs = b.reshape(-1).float()
+    return est
+
+
+def _cfg5_field_np(ts, te, ri):
+    tm = (ts + te) * np.float32(0.5)
+    sig = (np.float32(6.0) * (np.float32(0.5) + np.float32(0.5) * np.sin(np.float32(11.0) * tm))).astype(np.float32)
+    rgbs = np.stack([np.float32(0.5) + np.float32(0.5) * np.cos(tm), (ri % 5).astype(np.float32) / np.float32(5.0),
+                     np.full_like(tm, 0.25)], -1).astype(np.float32)
+    return rgbs, sig
+
+
+def _cfg5_field_t(ts, te, ri):
+    tm = (ts + te) * 0.5
+    return (torch.stack([0.5 + 0.5 * torch.cos(tm), (ri % 5).float() / 5.0, torch.full_like(tm, 0.25)], -1),
+            6.0 * (0.5 + 0.5 * torch.sin(11.0 * tm)))
+
+
+def test_cfg5_regime_sampling_bit_exact(dev, oracle):
+    """BASELINE cfg 5 at its real grid: 4 nested 512^3 levels (64 MiB bit copy, the walk's resolution limit, the brick grid of
+    the cone kernels), rays from inside the level-0 box, step 1e-3, cone 0.004, near 0.2, alpha_thre 1e-2, early_stop_eps
+    1e-4 (ref: examples/train_ngp_nerf_occ.py:64-75) -- OccGridEstimator.sampling against the oracle bit for bit (guard
+    band on the visibility thresholds as everywhere), with the cone angle (run records of the count pass + recurrence
+    expansion) and without it (run-length walk through 4 levels)."""
+    from oracle import check as OC
+    est = _cfg5_scene(dev)
+    b = est.binaries.cpu().numpy()
+    ab = est.aabbs.cpu().numpy()
+    rng = np.random.default_rng(55)
+    R = 3000
+    o = (rng.random((R, 3)).astype(np.float32) - 0.5)
+    d = rng.standard_normal((R, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    sig_np = lambda ts, te, ri: _cfg5_field_np(ts, te, ri)[1]
+    sig_t = lambda ts, te, ri: _cfg5_field_t(ts, te, ri)[1]
+    for cone in (0.004, 0.0):
+        a_thre = 1e-2 if cone > 0 else 2e-3      # (constant 1e-3 steps: opacities stay below 1e-2 in this field)
+        kw = dict(near_plane=0.2, render_step_size=1e-3, cone_angle=cone, alpha_thre=a_thre, early_stop_eps=1e-4)
+        ri, ts, te = est.sampling(T(o, dev), T(d, dev), sigma_fn=sig_t, **kw)
+        (ori, ots, ote), (fri, fts, fte, fpi) = oracle.occgrid_sampling(o, d, b, ab, sigma_fn=sig_np, occs_mean=float(b.mean()),
+                                                                         return_all=True, **kw)
+        assert fri.size > 300_000 and 0 < ori.size < fri.size               # the regime: ~190 samples per ray, two thirds of them dropped
+        tr, al = oracle.render_transmittance_from_density(fts, fte, sig_np(fts, fte, fri), fpi)
+        ok, info = OC.compare_sampling((ri.cpu().numpy(), ts.cpu().numpy(), te.cpu().numpy()), (ori, ots, ote), (fri, fts, fte), tr, al,
+                                       early_stop_eps=1e-4, alpha_thre=min(a_thre, float(b.mean())))
+        assert ok, (cone, info)
+        # the traversal alone: every sample, bit for bit
+        ria, tsa, tea = est.sampling(T(o, dev), T(d, dev), near_plane=0.2, render_step_size=1e-3, cone_angle=cone)
+        assert (ria.cpu().numpy() == fri).all() and (tsa.cpu().numpy() == fts).all() and (tea.cpu().numpy() == fte).all(), cone
+
+
+def test_cfg5_regime_test_mode_loop(dev, oracle):
+    """SURVEY 8 row a12 at cfg 5's regime (4 nested 512^3 levels, cone 0.004, max_samples 1024): render_rays_test_mode against
+    the oracle's restatement of examples/utils.py:252-425 -- the same sample count (no ray of the committed case sits on the
+    early-termination threshold) and images within 2e-5."""
+    from nerfacc_amd.marching import render_rays_test_mode
+    est = _cfg5_scene(dev)
+    b = est.binaries.cpu().numpy()
+    ab = est.aabbs.cpu().numpy()
+    rng = np.random.default_rng(56)
+    R = 1200
+    o = (rng.random((R, 3)).astype(np.float32) - 0.5)
+    d = rng.standard_normal((R, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    bk = np.array([0.1, 0.3, 0.5], np.float32)
+    kw = dict(near_plane=0.2, far_plane=1e10, render_step_size=1e-3, cone_angle=0.004, alpha_thre=1e-2, early_stop_eps=1e-4)
+    rgb, opa, dep, total = render_rays_test_mode(1024, _cfg5_field_t, est, T(o, dev), T(d, dev), render_bkgd=T(bk, dev), **kw)
+    orgb, oopa, odep, ototal, info = oracle.test_mode_loop(1024, _cfg5_field_np, o, d, b, ab, render_bkgd=bk, guard=2e-6, **kw)
+    assert ototal > 100_000 and info["iterations"] > 20
+    assert not info["guard_rays"].any()
+    assert total == ototal
     assert_close(opa, oopa, atol=2e-5, rtol=1e-5); assert_close(rgb, orgb, atol=2e-5, rtol=1e-5)
     assert_close(dep, odep, atol=1e-4, rtol=1e-4)
-    assert (opa.max() <= 1.0 + 1e-5) and (opa.min() >= 0)
 
 
 def test_full_size_bit_exact_vs_oracle(dev, oracle):

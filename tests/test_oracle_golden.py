@@ -149,3 +149,39 @@ def test_grid_maintenance_vs_reference_fixture(oracle):
     marked = oracle.mark_invisible_cells(np.zeros_like(g["occs_marked"]), res, g["sd_aabbs"], g["K"], g["c2w"], int(g["W"]), int(g["H"]),
                                          float(g["near"]))
     assert int((marked != g["occs_marked"]).sum()) <= 8
+
+
+def test_oracle_test_mode_loop_consistent_with_one_shot_rendering(oracle):
+    """The oracle's restatement of the test-mode marching loop (examples/utils.py:252-425; the reference's own harness
+    needs its CUDA extension, so this row is pinned through the pinned pieces it is composed of and through the
+    reference's own property, tests/test_grid.py:72-131: marching in chunks == marching in one go).  With early
+    termination and the opacity threshold off, the loop must visit exactly the one-shot traversal's samples and blend the
+    same image (the chunked prefix transmittance is the one-shot transmittance); with them on, rays stop early and the
+    image stays within the threshold's worth of the full one."""
+    rng = np.random.default_rng(3)
+    n, res, step = 300, 24, 0.02
+    o = (rng.random((n, 3)).astype(np.float32) - 0.5) * 3.0
+    d = rng.standard_normal((n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    b = rng.random((2, res, res, res)) < 0.3
+    ab = np.array([[-1, -1, -1, 1, 1, 1], [-2, -2, -2, 2, 2, 2]], np.float32)
+    bk = np.array([0.2, 0.4, 0.6], np.float32)
+
+    def field(ts, te, ri):
+        tm = (ts + te) * np.float32(0.5)
+        sig = (np.float32(3.0) * (np.float32(0.5) + np.float32(0.5) * np.sin(np.float32(5.0) * tm))).astype(np.float32)
+        return np.stack([tm * np.float32(0.1), np.full_like(tm, 0.5), (ri % 3).astype(np.float32) / 3], -1).astype(np.float32), sig
+
+    for cone in (0.0, 0.01):
+        rgb, opa, dep, total, info = oracle.test_mode_loop(100000, field, o, d, b, ab, near_plane=0.05, render_step_size=step,
+                                                           render_bkgd=bk, cone_angle=cone, early_stop_eps=0.0)
+        ri, ts, te = oracle.occgrid_sampling(o, d, b, ab, near_plane=0.05, render_step_size=step, cone_angle=cone)
+        assert total == ri.size and (info["samples_per_ray"] == np.bincount(ri, minlength=n)).all() and total > 5000
+        rgbs, sig = field(ts, te, ri)
+        c1, o1, d1, _ = oracle.rendering(ts, te, ri, n, rgbs, sigmas=sig, render_bkgd=bk)
+        assert np.allclose(rgb, c1, atol=2e-5) and np.allclose(opa, o1, atol=2e-5) and np.allclose(dep, d1, atol=2e-4)
+        dense = lambda ts, te, ri: (field(ts, te, ri)[0], field(ts, te, ri)[1] * np.float32(40.0))
+        rgb_f, opa_f, _, total_f, _ = oracle.test_mode_loop(100000, dense, o, d, b, ab, near_plane=0.05, render_step_size=step,
+                                                            render_bkgd=bk, cone_angle=cone, early_stop_eps=0.0)
+        rgb_e, opa_e, _, total_e, _ = oracle.test_mode_loop(100000, dense, o, d, b, ab, near_plane=0.05, render_step_size=step,
+                                                            render_bkgd=bk, cone_angle=cone, early_stop_eps=0.05)
+        assert total_e < total_f and np.abs(rgb_e - rgb_f).max() < 0.06 and (opa_e <= opa_f + 1e-6).all()
