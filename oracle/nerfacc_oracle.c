@@ -112,6 +112,8 @@ typedef struct {
     uint8_t *is_valid;    /* [n] or NULL */
     int64_t *chunk_starts;/* [n_rays] (read in fill pass) */
     int64_t *chunk_cnts;  /* [n_rays] (written)  NULL => spec disabled */
+    float *t_starts;      /* [n] or NULL: samples only -- the values the sampler takes from the interval stream, */
+    float *t_ends;        /*   intervals.vals[is_left] / [is_right] (estimators/occ_grid.py:174-175), written directly */
 } orc_segments;
 
 static inline float calc_dt(float t, float cone_angle, float dt_min, float dt_max)
@@ -240,9 +242,10 @@ static void traverse_one_ray(
                     }
                     if (has_sm && !first_pass) {
                         int64_t idx = chunk_start_bin + n_samples;
-                        sm->vals[idx] = (t_next + t_last) * 0.5f;
+                        if (sm->vals) sm->vals[idx] = (t_next + t_last) * 0.5f;
                         sm->ray_indices[idx] = tid;
-                        sm->is_valid[idx] = 1;
+                        if (sm->is_valid) sm->is_valid[idx] = 1;
+                        if (sm->t_starts) { sm->t_starts[idx] = t_last; sm->t_ends[idx] = t_next; }
                     }
                     n_samples++;
                     continuous = 1;
@@ -278,8 +281,8 @@ ORC_API int orc_traverse_grids_pass(
     int64_t *sm_chunk_starts, int64_t *sm_chunk_cnts,
     float *terminate_planes)
 {
-    orc_segments iv = {iv_vals, iv_ray_indices, iv_is_left, iv_is_right, NULL, iv_chunk_starts, iv_chunk_cnts};
-    orc_segments sm = {sm_vals, sm_ray_indices, NULL, NULL, sm_is_valid, sm_chunk_starts, sm_chunk_cnts};
+    orc_segments iv = {iv_vals, iv_ray_indices, iv_is_left, iv_is_right, NULL, iv_chunk_starts, iv_chunk_cnts, NULL, NULL};
+    orc_segments sm = {sm_vals, sm_ray_indices, NULL, NULL, sm_is_valid, sm_chunk_starts, sm_chunk_cnts, NULL, NULL};
 #pragma omp parallel for schedule(dynamic, 256)
     for (int64_t tid = 0; tid < n_rays; ++tid) {
         if (rays_mask && !rays_mask[tid]) continue; /* grid.cu:100 */
@@ -510,6 +513,103 @@ ORC_API int orc_searchsorted(
         int64_t l = clamp64(p - 1, base, last), rr = clamp64(p, base, last);
         if (q_batched) { ids_left[tid] = l - base; ids_right[tid] = rr - base; }
         else { ids_left[tid] = l; ids_right[tid] = rr; }
+    }
+    return 0;
+}
+
+
+/* ------------------------------------------------------------------------ */
+/* bench.py's CPU baseline: one whole step of the hot path with every stage parallel over rays (the numpy front end's
+ * elementwise passes -- sin, exp, boolean indexing over tens of millions of samples -- run on one thread whatever
+ * OMP_NUM_THREADS says).  Same semantics as the composition oracle.occgrid_sampling + oracle.rendering + the analytic
+ * backward of bench._oracle_step, with the per-ray scans done serially in fp32 instead of in the reference's 32-element
+ * tiles (tests/test_oracle_golden.py checks the two against each other: identical samples outside the visibility
+ * threshold's guard band, colours and gradients within 1e-5).  Three calls, the two prefix sums in between are the
+ * caller's:
+ *   orc_step_count    traversal count pass, samples only (grid.cu:405-431)
+ *   orc_step_fill     fill pass writing (t_start, t_end) directly (grid.cu:432-471 + occ_grid.py:174-175), the bench
+ *                     field's density sigma = scale * 4 (1/2 + 1/2 sin(20 (ts + te))), visibility mask
+ *                     T >= early_stop_eps (volrend.py:474-480; alpha_thre = 0) and the kept count per ray
+ *   orc_step_render   compaction (occ_grid.py:216-220), weights (volrend.py:358-362), colours with rgb = t_start
+ *                     (volrend.py:483-547), and the backward of colours.sum() to the densities      */
+ORC_API int orc_step_count(
+    int64_t n_rays, const float *rays_o, const float *rays_d, int32_t n_grids, const int32_t *res, const uint8_t *binaries,
+    const float *aabbs, const uint8_t *hits, const float *t_sorted, const int64_t *t_indices, const float *near_planes,
+    const float *far_planes, float step_size, float cone_angle, int64_t *sm_cnts)
+{
+    orc_segments iv = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL};
+    orc_segments sm = {NULL, NULL, NULL, NULL, NULL, NULL, sm_cnts, NULL, NULL};
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t tid = 0; tid < n_rays; ++tid)
+        traverse_one_ray(tid, rays_o, rays_d, n_grids, res, binaries, aabbs, hits, t_sorted, t_indices, near_planes[tid],
+                         far_planes[tid], step_size, cone_angle, -1, 1, &iv, &sm, NULL);
+    return 0;
+}
+
+ORC_API int orc_step_fill(
+    int64_t n_rays, const float *rays_o, const float *rays_d, int32_t n_grids, const int32_t *res, const uint8_t *binaries,
+    const float *aabbs, const uint8_t *hits, const float *t_sorted, const int64_t *t_indices, const float *near_planes,
+    const float *far_planes, float step_size, float cone_angle, int64_t *sm_starts, int64_t *sm_cnts,
+    float sigma_scale, float early_stop_eps,
+    int64_t *ray_indices, float *t_starts, float *t_ends, uint8_t *vis, int64_t *kept_cnts)
+{
+    orc_segments iv = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL};
+    orc_segments sm = {NULL, ray_indices, NULL, NULL, NULL, sm_starts, sm_cnts, t_starts, t_ends};
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t tid = 0; tid < n_rays; ++tid) {
+        traverse_one_ray(tid, rays_o, rays_d, n_grids, res, binaries, aabbs, hits, t_sorted, t_indices, near_planes[tid],
+                         far_planes[tid], step_size, cone_angle, -1, 0, &iv, &sm, NULL);
+        const int64_t s = sm_starts[tid], n = sm_cnts[tid];
+        float acc = 0.0f;   /* exclusive sum of sigma * delta */
+        int64_t kept = 0;
+        for (int64_t k = s; k < s + n; ++k) {
+            const float sig = sigma_scale * (4.0f * (0.5f + 0.5f * sinf(20.0f * (t_starts[k] + t_ends[k]))));
+            const float T = expf(-acc);
+            const uint8_t v = T >= early_stop_eps;
+            vis[k] = v; kept += v;
+            acc += sig * (t_ends[k] - t_starts[k]);
+        }
+        kept_cnts[tid] = kept;
+    }
+    return 0;
+}
+
+ORC_API int orc_step_render(
+    int64_t n_rays, const int64_t *sm_starts, const int64_t *sm_cnts, const float *t_starts, const float *t_ends,
+    const uint8_t *vis, const int64_t *kept_starts, float sigma_scale,
+    int64_t *k_ray_indices, float *k_t_starts, float *k_t_ends, float *colors /*[n_rays,3]*/, float *g_sigma)
+{
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t tid = 0; tid < n_rays; ++tid) {
+        const int64_t s = sm_starts[tid], n = sm_cnts[tid];
+        int64_t o = kept_starts[tid];
+        const int64_t o0 = o;
+        for (int64_t k = s; k < s + n; ++k)
+            if (vis[k]) { k_ray_indices[o] = tid; k_t_starts[o] = t_starts[k]; k_t_ends[o] = t_ends[k]; ++o; }
+        /* forward: w = T alpha, colour += w * rgb with rgb = (ts, ts, ts) */
+        float acc = 0.0f, c = 0.0f;
+        for (int64_t k = o0; k < o; ++k) {
+            const float ts = k_t_starts[k], te = k_t_ends[k];
+            const float sig = sigma_scale * (4.0f * (0.5f + 0.5f * sinf(20.0f * (ts + te))));
+            const float x = sig * (te - ts);
+            const float T = expf(-acc), alpha = 1.0f - expf(-x);
+            c += T * alpha * ts;
+            acc += x;
+        }
+        colors[3 * tid] = colors[3 * tid + 1] = colors[3 * tid + 2] = c;
+        /* backward of sum(colours): g_w = 3 ts; g_sigma_k = delta (g_w T (1 - alpha) - sum_{i > k} g_w_i w_i) */
+        float suffix = 0.0f;
+        float acc_b = acc;
+        for (int64_t k = o - 1; k >= o0; --k) {
+            const float ts = k_t_starts[k], te = k_t_ends[k];
+            const float sig = sigma_scale * (4.0f * (0.5f + 0.5f * sinf(20.0f * (ts + te))));
+            const float x = sig * (te - ts);
+            acc_b -= x;                       /* sum over j < k (recomputed backwards; forward order would need a stack) */
+            const float T = expf(-acc_b), em = expf(-x);
+            const float gw = 3.0f * ts;
+            g_sigma[k] = (te - ts) * (gw * T * em - suffix);
+            suffix += gw * T * (1.0f - em);
+        }
     }
     return 0;
 }

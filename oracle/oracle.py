@@ -435,6 +435,39 @@ def occgrid_sampling(rays_o, rays_d, binaries, aabbs, sigma_fn=None, alpha_fn=No
     return ray_indices, t_starts, t_ends
 
 
+def bench_step(rays_o, rays_d, binaries, aabbs, render_step_size, sigma_scale=1.0, early_stop_eps=1e-4, near_plane=0.0,
+               far_plane=1e10, cone_angle=0.0):
+    """bench.py's CPU baseline: one whole step (sampling with the bench's analytic density -> rendering forward -> backward
+    of ``colors.sum()``), every stage an OpenMP loop over rays (``orc_step_count / _fill / _render``: see the C file).
+    Returns ``(ray_indices, t_starts, t_ends) kept, n_samples_before_compaction, colors (n, 3), g_sigma (M',)``."""
+    rays_o, rays_d, aabbs = _f32(rays_o), _f32(rays_d), _f32(aabbs)
+    binaries = _u8(binaries)
+    n = rays_o.shape[0]
+    res = np.asarray(binaries.shape[1:], dtype=np.int32)
+    G = binaries.shape[0]
+    t_mins, t_maxs, hits = ray_aabb_intersect(rays_o, rays_d, aabbs)
+    t_sorted, t_indices = sort_intersections(t_mins, t_maxs)
+    near = np.full(n, near_plane, np.float32); far = np.full(n, far_plane, np.float32)
+    hits8 = _u8(hits)
+    geo = (C.c_int64(n), _p(rays_o), _p(rays_d), C.c_int32(G), _p(res), _p(binaries), _p(aabbs), _p(hits8), _p(t_sorted),
+           _p(t_indices), _p(near), _p(far), C.c_float(render_step_size), C.c_float(cone_angle))
+    cnts = np.empty(n, np.int64)
+    lib().orc_step_count(*geo, _p(cnts))
+    starts = np.cumsum(cnts) - cnts
+    M = int(starts[-1] + cnts[-1]) if n else 0
+    ri = np.empty(M, np.int64); ts = np.empty(M, np.float32); te = np.empty(M, np.float32)
+    vis = np.empty(M, np.uint8); kept = np.empty(n, np.int64)
+    lib().orc_step_fill(*geo, _p(starts), _p(cnts), C.c_float(sigma_scale), C.c_float(early_stop_eps), _p(ri), _p(ts), _p(te),
+                        _p(vis), _p(kept))
+    kstarts = np.cumsum(kept) - kept
+    Mk = int(kstarts[-1] + kept[-1]) if n else 0
+    kri = np.empty(Mk, np.int64); kts = np.empty(Mk, np.float32); kte = np.empty(Mk, np.float32)
+    colors = np.empty((n, 3), np.float32); gsig = np.empty(Mk, np.float32)
+    lib().orc_step_render(C.c_int64(n), _p(starts), _p(cnts), _p(ts), _p(te), _p(vis), _p(kstarts), C.c_float(sigma_scale),
+                          _p(kri), _p(kts), _p(kte), _p(colors), _p(gsig))
+    return (kri, kts, kte), M, colors, gsig
+
+
 # --------------------------------------------------------------------------- proposal-network sampling
 def test_mode_loop(max_samples, rgb_sigma_fn, rays_o, rays_d, binaries, aabbs, near_plane=0.0, far_plane=1e10,
                    render_step_size=1e-3, render_bkgd=None, cone_angle=0.0, alpha_thre=0.0, early_stop_eps=1e-4,

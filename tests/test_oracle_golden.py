@@ -185,3 +185,27 @@ def test_oracle_test_mode_loop_consistent_with_one_shot_rendering(oracle):
         rgb_e, opa_e, _, total_e, _ = oracle.test_mode_loop(100000, dense, o, d, b, ab, near_plane=0.05, render_step_size=step,
                                                             render_bkgd=bk, cone_angle=cone, early_stop_eps=0.05)
         assert total_e < total_f and np.abs(rgb_e - rgb_f).max() < 0.06 and (opa_e <= opa_f + 1e-6).all()
+
+
+def test_threaded_bench_step_agrees_with_the_pinned_composition(oracle):
+    """oracle.bench_step (bench.py's timed CPU baseline: every stage an OpenMP loop over rays, per-ray serial scans) against
+    the composition of the pinned oracle functions (bench._oracle_step): the same samples -- traversal bit for bit,
+    visibility identical outside the threshold's guard band -- colours and density gradients within 1e-5."""
+    import bench
+    o, d = bench.make_rays(64 * 64, "image")
+    b = bench.make_grid(32, "shell10")
+    aabb = np.array([[-1, -1, -1, 1, 1, 1]], np.float32)
+    step = 2 * 3 ** 0.5 / 256
+    for scale in (1.0, 16.0):
+        kept, full, colors, gsig, sig = bench._oracle_step(oracle, o, d, b, aabb, step, scale)
+        (ri, ts, te), M, col2, g2 = oracle.bench_step(o, d, b, aabb, step, scale)
+        assert M == full[0].size and M > 20000
+        tr, _ = oracle.render_transmittance_from_density(full[1], full[2], sig(full[1], full[2], full[0]), full[3])
+        guard = np.abs(tr - np.float32(1e-4)) < 1e-6
+        if not guard.any():
+            assert (ri == kept[0]).all() and (ts == kept[1]).all() and (te == kept[2]).all()
+            assert np.allclose(col2, colors, atol=1e-5) and np.allclose(g2, gsig, atol=1e-5, rtol=1e-4)
+        else:
+            assert abs(ri.size - kept[0].size) <= int(guard.sum())
+        if scale == 16.0:
+            assert kept[0].size < M          # early termination bites
