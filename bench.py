@@ -987,6 +987,7 @@ def main():
             out["roofline"] = {"bound": rated[dom]["bound"] if rated[dom]["bound"] != "issue" else "hbm", "kernel": dom,
                                "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a / HBM_PEAK_GBPS,
                                "traffic": rated[dom].get("hbm_traffic_bytes"),
+                               "traffic_source": rated[dom].get("hbm_traffic_source"),
                                "ms_per_launch": rated[dom]["ms_per_launch"],
                                "algorithmic_bytes_per_launch": rated[dom]["algorithmic_bytes_per_launch"],
                                "limiter": rated[dom]["bound"]}

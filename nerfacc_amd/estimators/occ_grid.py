@@ -288,15 +288,52 @@ class OccGridEstimator(AbstractEstimator):
 
     @torch.no_grad()
     def _sample_uniform_and_occupied_cells(self, n: int) -> List[Tensor]:
-        """Per level: n uniformly drawn (visible) cells plus up to n occupied cells (ref :345-366)."""
+        """Per level: n uniformly drawn (visible) cells plus the occupied cells -- all of them, or n drawn with replacement
+        when there are more than n (ref :345-366).
+
+        The reference filters with a boolean index and a ``nonzero`` per level (each a device synchronisation, three per
+        level).  Here the two selections are stable compactions by prefix sum + scatter for all levels at once, with ONE
+        host read (the levels' output sizes); same cells in the same order as the reference's expressions."""
+        if self.occs.is_cuda:
+            return self._sample_cells_one_read(n)
+        dev, L, cells = self.occs.device, self.levels, self.cells_per_lvl
         out = []
-        for lvl in range(self.levels):
-            uni = torch.randint(self.cells_per_lvl, (n,), device=self.device)
-            uni = uni[self.occs[lvl * self.cells_per_lvl + uni] >= 0.0]
+        for lvl in range(L):   # (CPU tensors: the reference's expressions)
+            uni = torch.randint(cells, (n,), device=dev)
+            uni = uni[self.occs[lvl * cells + uni] >= 0.0]
             occ = torch.nonzero(self.binaries[lvl].flatten())[:, 0]
             if n < len(occ):
-                occ = occ[torch.randint(len(occ), (n,), device=self.device)]
+                occ = occ[torch.randint(len(occ), (n,), device=dev)]
             out.append(torch.cat([uni, occ], dim=0))
+        return out
+
+    @torch.no_grad()
+    def _sample_cells_one_read(self, n: int) -> List[Tensor]:
+        dev, L, cells = self.occs.device, self.levels, self.cells_per_lvl
+        uni = torch.randint(cells, (L, n), device=dev)                                     # ref :350
+        uni_ok = self.occs.view(L, cells).gather(1, uni) >= 0.0                             # ref :352-353
+        uni_pos = torch.cumsum(uni_ok, dim=1)                                               # 1-based slot of every kept draw
+        occ_flag = self.binaries.view(L, cells)
+        occ_pos = torch.cumsum(occ_flag, dim=1)
+        sizes = torch.stack([uni_pos[:, -1], occ_pos[:, -1]], dim=1).tolist()              # the one device -> host read
+        out = []
+        cell_ids = torch.arange(cells, device=dev)
+        for lvl, (n_uni, n_occ) in enumerate(sizes):
+            n_uni, n_occ = int(n_uni), int(n_occ)
+            if n < n_occ:   # ref :356-360: n of the occupied cells, drawn with replacement = the k-th occupied cell for random k
+                k = torch.randint(n_occ, (n,), device=dev)
+                occ = torch.searchsorted(occ_pos[lvl], k + 1)                               # first cell whose count reaches k + 1
+                n_take = n
+            else:
+                occ, n_take = None, n_occ
+            res = torch.empty(n_uni + n_take + 1, dtype=torch.int64, device=dev)            # (+1: the slot dropped entries land in)
+            dump = n_uni + n_take
+            res.scatter_(0, torch.where(uni_ok[lvl], uni_pos[lvl] - 1, dump), uni[lvl])
+            if occ is None:
+                res.scatter_(0, torch.where(occ_flag[lvl], n_uni + occ_pos[lvl] - 1, dump), cell_ids)
+            else:
+                res[n_uni:dump] = occ
+            out.append(res[:dump])
         return out
 
     #: Process group over which :meth:`_update` keeps the grid identical on all ranks (``None``: no communication, the

@@ -4,7 +4,7 @@
 # with trace domains other than kernel-trace).  Outputs land in gpurun_out/<tag>_*; summarise with
 # scripts/summarize_profiles.py, which writes the files committed under profiles/.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT

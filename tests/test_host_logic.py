@@ -115,3 +115,45 @@ def test_reference_state_dict_loads_and_mark_invisible_cells_cpu():
     est.occs.zero_()
     est.mark_invisible_cells(torch.from_numpy(g["K"]), torch.from_numpy(g["c2w"]), int(g["W"]), int(g["H"]), near_plane=float(g["near"]))
     assert int((est.occs.numpy() != g["occs_marked"]).sum()) <= 4
+
+
+def test_cell_selection_without_nonzero_matches_the_reference_expressions():
+    """OccGridEstimator._sample_uniform_and_occupied_cells on a device (ref estimators/occ_grid.py:345-366): stable compactions
+    by prefix sum + scatter with one host read for all levels.  Same cells in the same order as the reference's boolean
+    index + nonzero when every occupied cell is taken (same RNG stream: no selector draws); with more occupied cells than
+    n, n draws among the occupied cells."""
+    import torch
+    import nerfacc_amd as na
+    est = na.OccGridEstimator([-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=8, levels=3)
+    torch.manual_seed(0)
+    occs = torch.rand(3 * 512) - 0.3
+    occs[occs < 0] = -1.0                                  # cells no camera sees
+    est.occs = occs
+    est.binaries = torch.rand(3, 8, 8, 8) < 0.2
+    n_occ = est.binaries.view(3, -1).sum(1)
+    n = int(n_occ.max()) + 5                               # all occupied cells are taken on every level
+    torch.manual_seed(7)
+    got = est._sample_cells_one_read(n)
+    torch.manual_seed(7)
+    for lvl in range(3):
+        uni = torch.randint(512, (n,))
+        uni = uni[est.occs[lvl * 512 + uni] >= 0.0]
+        want = torch.cat([uni, torch.nonzero(est.binaries[lvl].flatten())[:, 0]])
+        assert torch.equal(got[lvl], want), lvl
+    n = 20                                                   # fewer than the occupied cells: n of them, with replacement
+    torch.manual_seed(9)
+    got = est._sample_cells_one_read(n)
+    for lvl in range(3):
+        n_uni = got[lvl].numel() - n
+        assert 0 < n_uni <= n and (est.occs[lvl * 512 + got[lvl][:n_uni]] >= 0).all()
+        assert est.binaries[lvl].flatten()[got[lvl][n_uni:]].all()
+    est.binaries = torch.zeros_like(est.binaries)           # nothing occupied
+    assert all(g.numel() <= 5 and g.numel() > 0 for g in est._sample_cells_one_read(5))
+
+
+def test_walk_limits_are_mirrored_on_the_host():
+    import torch
+    from nerfacc_amd import grid as G
+    ok = lambda shape: G._walk_supported(torch.empty(shape, dtype=torch.bool, device="meta"))
+    assert ok((1, 128, 128, 128)) and ok((4, 512, 512, 512)) and ok((8, 512, 512, 512)) and ok((1, 1, 1, 1))
+    assert not ok((16, 512, 512, 512)) and not ok((1, 600, 4, 4))
