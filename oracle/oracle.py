@@ -435,34 +435,51 @@ def occgrid_sampling(rays_o, rays_d, binaries, aabbs, sigma_fn=None, alpha_fn=No
     return ray_indices, t_starts, t_ends
 
 
+_STEP_BUFFERS: dict = {}
+
+
 def bench_step(rays_o, rays_d, binaries, aabbs, render_step_size, sigma_scale=1.0, early_stop_eps=1e-4, near_plane=0.0,
                far_plane=1e10, cone_angle=0.0):
     """bench.py's CPU baseline: one whole step (sampling with the bench's analytic density -> rendering forward -> backward
     of ``colors.sum()``), every stage an OpenMP loop over rays (``orc_step_count / _fill / _render``: see the C file).
-    Returns ``(ray_indices, t_starts, t_ends) kept, n_samples_before_compaction, colors (n, 3), g_sigma (M',)``."""
+    Returns ``(ray_indices, t_starts, t_ends) kept, n_samples_before_compaction, colors (n, 3), g_sigma (M',)`` -- views of
+    buffers the next call overwrites."""
     rays_o, rays_d, aabbs = _f32(rays_o), _f32(rays_d), _f32(aabbs)
     binaries = _u8(binaries)
     n = rays_o.shape[0]
     res = np.asarray(binaries.shape[1:], dtype=np.int32)
     G = binaries.shape[0]
     t_mins, t_maxs, hits = ray_aabb_intersect(rays_o, rays_d, aabbs)
-    t_sorted, t_indices = sort_intersections(t_mins, t_maxs)
+    if G == 1 and not (t_mins > t_maxs).any():      # one grid: the stable sort of (t_min, t_max) is the identity
+        t_sorted = np.concatenate([t_mins, t_maxs], axis=-1)
+        t_indices = np.broadcast_to(np.arange(2, dtype=np.int64), (n, 2)).copy()
+    else:
+        t_sorted, t_indices = sort_intersections(t_mins, t_maxs)
     near = np.full(n, near_plane, np.float32); far = np.full(n, far_plane, np.float32)
     hits8 = _u8(hits)
     geo = (C.c_int64(n), _p(rays_o), _p(rays_d), C.c_int32(G), _p(res), _p(binaries), _p(aabbs), _p(hits8), _p(t_sorted),
            _p(t_indices), _p(near), _p(far), C.c_float(render_step_size), C.c_float(cone_angle))
-    cnts = np.empty(n, np.int64)
+
+    def buf(name, size, dtype):
+        """output arrays are kept between calls (a timing loop would otherwise spend its time in page faults: half a
+        gigabyte of fresh pages per pass, first touched by all threads at once)"""
+        a = _STEP_BUFFERS.get(name)
+        if a is None or a.size < size or a.dtype != dtype:
+            a = _STEP_BUFFERS[name] = np.empty(max(size, 1), dtype)
+        return a[:size]
+
+    cnts = buf("cnts", n, np.int64)
     lib().orc_step_count(*geo, _p(cnts))
     starts = np.cumsum(cnts) - cnts
     M = int(starts[-1] + cnts[-1]) if n else 0
-    ri = np.empty(M, np.int64); ts = np.empty(M, np.float32); te = np.empty(M, np.float32)
-    vis = np.empty(M, np.uint8); kept = np.empty(n, np.int64)
+    ri, ts, te = buf("ri", M, np.int64), buf("ts", M, np.float32), buf("te", M, np.float32)
+    vis, kept = buf("vis", M, np.uint8), buf("kept", n, np.int64)
     lib().orc_step_fill(*geo, _p(starts), _p(cnts), C.c_float(sigma_scale), C.c_float(early_stop_eps), _p(ri), _p(ts), _p(te),
                         _p(vis), _p(kept))
     kstarts = np.cumsum(kept) - kept
     Mk = int(kstarts[-1] + kept[-1]) if n else 0
-    kri = np.empty(Mk, np.int64); kts = np.empty(Mk, np.float32); kte = np.empty(Mk, np.float32)
-    colors = np.empty((n, 3), np.float32); gsig = np.empty(Mk, np.float32)
+    kri, kts, kte = buf("kri", Mk, np.int64), buf("kts", Mk, np.float32), buf("kte", Mk, np.float32)
+    colors, gsig = buf("colors", 3 * n, np.float32).reshape(n, 3), buf("gsig", Mk, np.float32)
     lib().orc_step_render(C.c_int64(n), _p(starts), _p(cnts), _p(ts), _p(te), _p(vis), _p(kstarts), C.c_float(sigma_scale),
                           _p(kri), _p(kts), _p(kte), _p(colors), _p(gsig))
     return (kri, kts, kte), M, colors, gsig
