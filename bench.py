@@ -560,6 +560,8 @@ def extra_cfg5(dev, R, steps, res=512, G=4, parity=True, train=True):
     b = torch.stack([shell | (torch.rand((res, res, res), device=dev, generator=g) < 0.02) for _ in range(G)])
     est.binaries = b
     est.occs = b.reshape(-1).float()
+    if os.environ.get("NFA_BENCH_CFG5_BIN", "") in ("0", "1"):                      # (A/B of the ray binning; default: the library decides)
+        est.bin_rays = os.environ["NFA_BENCH_CFG5_BIN"] == "1"
     del r, shell
     o = (rng.random((R, 3)).astype(np.float32) - 0.5)                               # inside the level-0 box
     d = rng.standard_normal((R, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)

@@ -191,6 +191,14 @@ int nfa_traverse_onepass_walk(const nfa_traverse_args *args, const uint32_t *bit
  * the order.  scratch: 1024 + n_rays bytes. */
 int nfa_bin_rays(const float *rays_o, const float *rays_d, int64_t n_rays, const float *box, int32_t *order,
                  void *scratch, nfa_stream_t stream);
+/* The same for nested levels (aabbs[n_grids][6], finest first; e.g. rays that start inside the finest box): the key is the
+ * number of cell boundaries the ray crosses from near_plane on, summed over the levels (the length inside level l but
+ * outside level l - 1, times sum_k |d_k| res_k / extent_k).  ray_order of nfa_traverse_cone_runs / nfa_traverse_runs. */
+int nfa_bin_rays_levels(const float *rays_o, const float *rays_d, int64_t n_rays, const float *aabbs, int32_t n_grids,
+                        const int32_t *res, float near_plane, int32_t *order, void *scratch,
+                        uint64_t *coherence /* [2] or NULL, zeroed by the caller: += sum over groups of 64 consecutive rays of
+                        the group's largest key, += sum of the keys (64 * [0] / [1]: how much longer a wave of neighbouring
+                        rays walks than its average ray) */, nfa_stream_t stream);
 /* capacity: number of elements the output arrays hold; nothing is written at or beyond it (a caller that allocated the
  * outputs before the total was known to the host re-runs the expansion if the total turns out larger). */
 int nfa_expand_runs(int64_t n_rays, float step_size, const int32_t *run_cnts, const uint64_t *runs,
@@ -214,7 +222,8 @@ int nfa_fill_ray_indices(int64_t n_rays, const int64_t *packed_info /*[n_rays,2]
  *                           most 63 steps), so the values are bit-identical to the marching loop's, and the second DDA
  *                           walk of the fill pass is replaced by coalesced stores. */
 int nfa_traverse_cone_runs(const nfa_traverse_args *args, int32_t *run_cnts, uint64_t *runs, int32_t max_runs,
-                           int32_t *overflow_count, nfa_stream_t stream);
+                           int32_t *overflow_count, const int32_t *ray_order /* lane -> ray assignment or NULL */,
+                           nfa_stream_t stream);
 int nfa_expand_cone_runs(int64_t n_rays, float step_size, float cone_angle, const int32_t *run_cnts,
                          const uint64_t *runs, int32_t max_runs, const int64_t *packed_info, float *t_starts,
                          float *t_ends, int64_t *ray_indices, nfa_stream_t stream);

@@ -83,23 +83,75 @@ __device__ __forceinline__ int ray_bin(const float *__restrict__ rays_o, const f
     return b < 1 ? 1 : (b > BIN_COUNT - 1 ? BIN_COUNT - 1 : b);
 }
 
+// The same for nested levels (rays that start inside the finest box and leave through the coarser ones): the key is the
+// number of cell boundaries the ray crosses, sum over levels of (length inside level l but outside level l - 1) x
+// sum_k |d_k| res_k / extent_k, from the near plane on.  box: [n_grids][6], finest first.
+__device__ __forceinline__ int ray_bin_levels(const float *__restrict__ rays_o, const float *__restrict__ rays_d, int64_t r,
+                                              const float *__restrict__ boxes, int32_t n_grids, const int32_t *res3, float near,
+                                              float inv_cells_max)
+{
+    const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+    const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+    float cells = 0.f, inner = 0.f;     // inner: length of the ray inside the previous (finer) box
+    for (int32_t l = 0; l < n_grids; ++l) {
+        const float *box = boxes + 6 * l;
+        float tmin = -INFINITY, tmax = INFINITY, dens = 0.f;
+        bool hit = true;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const float inv = 1.0f / d[ax];
+            float lo = (box[ax] - o[ax]) * inv, hi = (box[3 + ax] - o[ax]) * inv;
+            if (lo > hi) { const float t = lo; lo = hi; hi = t; }
+            if (!(lo <= hi)) hit = false;
+            tmin = fmaxf(tmin, lo); tmax = fminf(tmax, hi);
+            dens += fabsf(d[ax]) * (float)res3[ax] / (box[3 + ax] - box[ax]);
+        }
+        tmin = fmaxf(tmin, near);
+        const float len = (hit && tmin < tmax) ? tmax - tmin : 0.f;
+        cells += fmaxf(len - inner, 0.f) * dens;
+        inner = fmaxf(len, inner);
+    }
+    if (!(cells > 0.f)) return 0;
+    const int b = 1 + (int)(cells * inv_cells_max * (float)(BIN_COUNT - 1));
+    return b < 1 ? 1 : (b > BIN_COUNT - 1 ? BIN_COUNT - 1 : b);
+}
+
+struct BinLevels { const float *boxes; int32_t n_grids; int32_t res[3]; float near; float inv_cells_max; unsigned long long *stats; };
+
 // Every workgroup owns one contiguous range of rays in both passes, so the global histogram / cursors see 256 atomics
 // per workgroup (not per 256 rays), and inside a workgroup the counting is LDS atomics.
+template <bool LEVELS>
 __global__ __launch_bounds__(256) void bin_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                         int64_t n_rays, int64_t per_block, const float *__restrict__ box,
-                                                        uint8_t *__restrict__ bins, int32_t *__restrict__ hist)
+                                                        uint8_t *__restrict__ bins, int32_t *__restrict__ hist, const BinLevels lv)
 {
     __shared__ int32_t h[BIN_COUNT];
     h[threadIdx.x] = 0;
     __syncthreads();
     const int64_t r_lo = (int64_t)blockIdx.x * per_block, r_hi = min(r_lo + per_block, n_rays);
-    for (int64_t r = r_lo + threadIdx.x; r < r_hi; r += blockDim.x) {
-        const int b = ray_bin(rays_o, rays_d, r, box);
-        bins[r] = (uint8_t)b;
-        atomicAdd(&h[b], 1);
+    uint32_t w_max = 0u, w_sum = 0u;   // coherence of the key: per 64 consecutive rays, the largest bin and the sum of the bins
+    for (int64_t r0 = r_lo; r0 < r_hi; r0 += blockDim.x) {
+        const int64_t r = r0 + threadIdx.x;
+        int b = 0;
+        if (r < r_hi) {
+            b = LEVELS ? ray_bin_levels(rays_o, rays_d, r, lv.boxes, lv.n_grids, lv.res, lv.near, lv.inv_cells_max)
+                       : ray_bin(rays_o, rays_d, r, box);
+            bins[r] = (uint8_t)b;
+            atomicAdd(&h[b], 1);
+        }
+        if (LEVELS && lv.stats) {
+            int32_t m = b, t = b;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { m = max(m, __shfl_xor(m, off, 64)); t += __shfl_xor(t, off, 64); }
+            w_max += (uint32_t)m; w_sum += (uint32_t)t;
+        }
     }
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+    if (LEVELS && lv.stats && lane_id() == 0) {
+        atomicAdd(&lv.stats[0], (unsigned long long)w_max);
+        atomicAdd(&lv.stats[1], (unsigned long long)w_sum);
+    }
 }
 
 // one workgroup: exclusive scan of the histogram in place (-> first output slot of every bin)
@@ -540,10 +592,35 @@ int nfa_bin_rays(const float *rays_o, const float *rays_d, int64_t n_rays, const
     int64_t per_block = ceil_div64(n_rays, 512);  // up to 512 workgroups (two per CU), at least 1024 rays each
     if (per_block < 1024) per_block = 1024;
     const unsigned grid = (unsigned)ceil_div64(n_rays, per_block);
-    hipLaunchKernelGGL(bin_count_kernel, dim3(grid), dim3(256), 0, s, rays_o, rays_d, n_rays, per_block, box, bins, hist);
+    hipLaunchKernelGGL(bin_count_kernel<false>, dim3(grid), dim3(256), 0, s, rays_o, rays_d, n_rays, per_block, box, bins, hist, BinLevels{});
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, s, hist);
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(grid), dim3(256), 0, s, bins, n_rays, per_block, hist, order);
     NFA_CHECK_LAUNCH("bin_rays");
+    return NFA_OK;
+}
+
+int nfa_bin_rays_levels(const float *rays_o, const float *rays_d, int64_t n_rays, const float *aabbs, int32_t n_grids,
+                        const int32_t *res, float near_plane, int32_t *order, void *scratch, uint64_t *coherence, nfa_stream_t stream)
+{
+    NFA_REQUIRE(n_rays >= 0 && n_rays < ((int64_t)1 << 31), "bin_rays_levels: n_rays out of range");
+    if (n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(rays_o && rays_d && aabbs && res && order && scratch && n_grids >= 1, "bin_rays_levels: bad arguments");
+    hipStream_t s = as_stream(stream);
+    int32_t *hist = reinterpret_cast<int32_t *>(scratch);                      // [BIN_COUNT]
+    uint8_t *bins = reinterpret_cast<uint8_t *>(hist + BIN_COUNT);             // [n_rays]
+    if (hipMemsetAsync(hist, 0, sizeof(int32_t) * BIN_COUNT, s) != hipSuccess) { set_error("bin_rays_levels: memset failed"); return NFA_EHIP; }
+    int64_t per_block = ceil_div64(n_rays, 512);
+    if (per_block < 1024) per_block = 1024;
+    const unsigned grid = (unsigned)ceil_div64(n_rays, per_block);
+    BinLevels lv;
+    lv.boxes = aabbs; lv.n_grids = n_grids; lv.res[0] = res[0]; lv.res[1] = res[1]; lv.res[2] = res[2];
+    lv.near = near_plane;
+    lv.stats = reinterpret_cast<unsigned long long *>(coherence);
+    lv.inv_cells_max = 1.0f / ((float)n_grids * (float)(res[0] + res[1] + res[2]));   // a ray crosses at most that many boundaries
+    hipLaunchKernelGGL(bin_count_kernel<true>, dim3(grid), dim3(256), 0, s, rays_o, rays_d, n_rays, per_block, nullptr, bins, hist, lv);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, s, hist);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(grid), dim3(256), 0, s, bins, n_rays, per_block, hist, order);
+    NFA_CHECK_LAUNCH("bin_rays_levels");
     return NFA_OK;
 }
 

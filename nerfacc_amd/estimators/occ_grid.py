@@ -124,11 +124,14 @@ class OccGridEstimator(AbstractEstimator):
         if stratified:
             near_planes = near_planes + torch.rand_like(near_planes) * render_step_size
         use_bins = self.bin_rays
-        if use_bins is None:  # automatic: decided by the coherence the previous batches showed; re-measured now and then
-            use_bins = self._walk_stats.get("max_over_mean", 1.0) > 5.0 and rays_o.shape[0] >= 65536  # image order: 1.6-2.5, random rays: ~12
+        if use_bins is None and not cone_angle > 0.0:
+            # automatic: decided by the coherence the previous batches showed (sample counts of 64 neighbouring rays; image
+            # order: 1.6-2.5, random rays: ~12).  With a cone angle the walk decides itself, from the coherence of its own
+            # binning key (cells crossed): None is passed on.
+            use_bins = self._walk_stats.get("max_over_mean", 1.0) > 5.0 and rays_o.shape[0] >= 65536
         return _traverse_samples(rays_o, rays_d, self.binaries, self.aabbs, near_planes, far_planes, render_step_size,
-                                 cone_angle, near_hint=near_plane, bin_rays=bool(use_bins), stats_sink=self._walk_stats,
-                                 speculate=speculate)
+                                 cone_angle, near_hint=near_plane, bin_rays=None if use_bins is None else bool(use_bins),
+                                 stats_sink=self._walk_stats, speculate=speculate)
 
     def _traversal_key(self, rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified, cone_angle):
         """Identity of everything the geometric half of ``sampling`` reads: tensors by (address, shape, version counter)

@@ -61,6 +61,29 @@ def test_binned_ray_assignment_same_results(dev):
         ref = na.grid._traverse_samples(ro, rd, b, ab, near, far, 4e-3, 0.0, return_terminate=True, **kw)
         got = na.grid._traverse_samples(ro, rd, b, ab, near, far, 4e-3, 0.0, return_terminate=True, bin_rays=True, **kw)
         assert ref[0].numel() > 30_000 and all(torch.equal(x, y) for x, y in zip(ref, got))
+    # distance-dependent steps through nested levels (the cone-angle walk: nfa_bin_rays_levels, key = cell boundaries crossed
+    # summed over the levels): rays from inside the finest box, same results with and without the binned assignment
+    est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=32, levels=3).to(dev)
+    b3 = T(rng.random((3, 32, 32, 32)) < 0.15, dev)
+    oi = T((rng.random((R, 3)).astype(np.float32) - 0.5), dev)
+    nearc = torch.full((R,), 0.1, device=dev)
+    ref = na.grid._traverse_samples(oi, rd, b3, est.aabbs, nearc, far, 6e-3, 0.01, near_hint=0.1)
+    got = na.grid._traverse_samples(oi, rd, b3, est.aabbs, nearc, far, 6e-3, 0.01, near_hint=0.1, bin_rays=True)
+    assert ref[0].numel() > 100_000 and all(torch.equal(x, y) for x, y in zip(ref, got))
+    order = torch.empty(R, dtype=torch.int32, device=dev)
+    import ctypes as C
+    coh = torch.zeros(2, dtype=torch.int64, device=dev)
+    B.call("nfa_bin_rays_levels", B.ptr(oi), B.ptr(rd), R, B.ptr(est.aabbs), 3, (C.c_int32 * 3)(32, 32, 32), 0.1, B.ptr(order),
+           B.ptr(scratch), B.ptr(coh), B.stream())
+    assert 1.2 < 64.0 * float(coh[0]) / float(coh[1]) < 4.0                              # unrelated rays: a wave's longest ray vs its mean
+    assert torch.equal(torch.sort(order.long())[0], torch.arange(R, device=dev))          # a permutation
+    # rays in walk order cross more and more cells: path length inside the finest box (res / extent = 16 boundaries per unit
+    # length and axis) + outside it (8, 4 per unit), roughly
+    tmin, tmax, hit = na.ray_aabb_intersect(oi, rd, est.aabbs)
+    seg = (tmax - tmin.clamp_min(0.1)).clamp_min(0)
+    cells = (seg[:, 0] * 16 + (seg[:, 1] - seg[:, 0]) * 8 + (seg[:, 2] - seg[:, 1]) * 4)[order.long()]
+    q = R // 4
+    assert cells[:q].mean() < cells[q:2 * q].mean() < cells[2 * q:3 * q].mean() < cells[3 * q:].mean()
 
 
 def test_degenerate_batches(dev):
