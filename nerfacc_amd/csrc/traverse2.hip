@@ -402,11 +402,13 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_intervals_kernel(int64_t 
     __shared__ float s_t0[EXP_WPB][EXP_QMAX];
     __shared__ uint8_t s_cont[EXP_WPB][EXP_QMAX];
     __shared__ __attribute__((aligned(16))) int32_t s_own[EXP_WPB][256 + 4];  // + look-ahead slot for the chunk's last edge
+    __shared__ __attribute__((aligned(16))) uint32_t s_mask[EXP_WPB][128];   // the chunk's is_left / is_right bytes, 4 per lane
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     uint32_t *pos = s_pos[wave];
     float *t0s = s_t0[wave];
     uint8_t *conts = s_cont[wave];
     int32_t *slot = s_own[wave];
+    uint32_t *mbytes = s_mask[wave];
     const int64_t n_batches = ceil_div64(n_rays, EXP_RPW);
     for (int64_t batch = (int64_t)blockIdx.x * EXP_WPB + wave; batch < n_batches; batch += (int64_t)gridDim.x * EXP_WPB) {
         const int64_t r0 = batch * EXP_RPW;
@@ -533,16 +535,39 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_intervals_kernel(int64_t 
                     l4[k] = (cs[k + 1] || pa + 1 >= W1) ? 0 : 1;
                     valid[k] = true;
                 }
-                if (vec && valid[0] && valid[1] && valid[2] && valid[3]) {
-                    *reinterpret_cast<float4 *>(vals + p0) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+                // The two mask streams are 1 byte per edge: written 4 bytes per lane they were 256-byte store instructions and
+                // the kernel ran at 2.0 TB/s (244 us for cfg 2's 34 M edges).  The lanes' mask bytes go through LDS and leave
+                // 16 bytes per lane: lanes 0-15 store is_left, lanes 16-31 is_right, a 16-edge group each -- where all 16 edges
+                // of the group belong to this batch (a group cut by the batch's window is written byte by byte).
+                const bool all4 = valid[0] && valid[1] && valid[2] && valid[3];
+                const unsigned long long full4 = __ballot(all4);
+                const bool group_full = vec && ((full4 >> (4 * (lane >> 2))) & 0xFull) == 0xFull;
+                mbytes[lane] = (uint32_t)l4[0] | ((uint32_t)l4[1] << 8) | ((uint32_t)l4[2] << 16) | ((uint32_t)l4[3] << 24);
+                mbytes[64 + lane] = (uint32_t)r4[0] | ((uint32_t)r4[1] << 8) | ((uint32_t)r4[2] << 16) | ((uint32_t)r4[3] << 24);
+                __builtin_amdgcn_wave_barrier();
+                if (vec && lane < 32) {
+                    const int g = lane & 15, which = lane >> 4;
+                    if (((full4 >> (4 * g)) & 0xFull) == 0xFull) {
+                        const uint4 mv = *reinterpret_cast<const uint4 *>(mbytes + 64 * which + 4 * g);
+                        typedef unsigned int nfa_v4u __attribute__((ext_vector_type(4)));
+                        nfa_v4u v = {mv.x, mv.y, mv.z, mv.w};
+                        __builtin_nontemporal_store(v, reinterpret_cast<nfa_v4u *>((which ? is_right : is_left) + cb + 16 * g));
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (vec && all4) {
+                    store_f4<NFA_NT_EXPAND>(vals + p0, v4[0], v4[1], v4[2], v4[3]);
                     store_l2<NFA_NT_EXPAND>(ray_indices + p0, ri4[0], ri4[1]);
                     store_l2<NFA_NT_EXPAND>(ray_indices + p0 + 2, ri4[2], ri4[3]);
-                    *reinterpret_cast<uchar4 *>(is_left + p0) = make_uchar4(l4[0], l4[1], l4[2], l4[3]);
-                    *reinterpret_cast<uchar4 *>(is_right + p0) = make_uchar4(r4[0], r4[1], r4[2], r4[3]);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (valid[k]) { vals[p0 + k] = v4[k]; ray_indices[p0 + k] = ri4[k]; is_left[p0 + k] = l4[k]; is_right[p0 + k] = r4[k]; }
+                        if (valid[k]) { vals[p0 + k] = v4[k]; ray_indices[p0 + k] = ri4[k]; }
+                }
+                if (!group_full) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (valid[k]) { is_left[p0 + k] = l4[k]; is_right[p0 + k] = r4[k]; }
                 }
             }
         }
@@ -694,8 +719,8 @@ int nfa_expand_intervals(int64_t n_rays, float step_size, const int32_t *run_cnt
                 "expand_intervals: null pointer");
     NFA_REQUIRE(max_runs >= 1 && max_runs * EXP_RPW <= EXP_QMAX, "expand_intervals: max_runs must be in [1, 32]");
     NFA_REQUIRE(step_size > 0.0f, "expand_intervals: step_size must be > 0");
-    const int vec = ((reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(ray_indices)) & 15) == 0 &&
-                    ((reinterpret_cast<uintptr_t>(is_left) | reinterpret_cast<uintptr_t>(is_right)) & 3) == 0;
+    const int vec = ((reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(ray_indices) | reinterpret_cast<uintptr_t>(is_left) |
+                      reinterpret_cast<uintptr_t>(is_right)) & 15) == 0;
     const unsigned grid = grid_1d(ceil_div64(n_rays, EXP_RPW) * 64, 64 * EXP_WPB, 1 << 22);
     hipLaunchKernelGGL(expand_intervals_kernel, dim3(grid), dim3(64 * EXP_WPB), 0, as_stream(stream), n_rays, step_size, run_cnts,
                        reinterpret_cast<const unsigned long long *>(runs), max_runs,
