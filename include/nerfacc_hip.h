@@ -329,11 +329,14 @@ int nfa_render_visibility(const float *t_starts, const float *t_ends, const floa
                           const float *prefix_trans, float early_stop_eps, float alpha_thre,
                           const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles, int64_t n_rays,
                           int64_t n_elems, uint8_t *vis, int64_t *vis_cnts, nfa_stream_t stream);
-/* Boolean-mask compaction of (ray_indices, t_starts, t_ends) with known per-ray output offsets. */
+/* Boolean-mask compaction of (ray_indices, t_starts, t_ends) with known per-ray output offsets (ref: estimators/
+ * occ_grid.py:216-220, three boolean-index gathers).  capacity: elements the output arrays hold; nothing is written at or
+ * beyond it (a caller that sized them from the previous batch, before this batch's total reached the host, repeats the call
+ * into larger arrays when the total turns out larger). */
 int nfa_compact_samples(const uint8_t *vis, const float *t_starts, const float *t_ends,
                         const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles, const int64_t *out_starts,
                         int64_t n_rays, int64_t n_elems, int64_t *out_ray_indices,
-                        float *out_t_starts, float *out_t_ends, nfa_stream_t stream);
+                        float *out_t_starts, float *out_t_ends, int64_t capacity, nfa_stream_t stream);
 
 /* out[r, :] (+)= sum_i w_i * values[i, :] over ray r's chunk, deterministic order.
  * values NULL => D = 1 and out = sum w.  accumulate != 0 adds to `out` (accumulate_along_rays_).

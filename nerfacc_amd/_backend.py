@@ -85,7 +85,7 @@ _SIGS = {
     "nfa_density_cdf_rows_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp],
     "nfa_render_from_alpha_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp],
     "nfa_render_visibility": [_vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],
-    "nfa_compact_samples": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
+    "nfa_compact_samples": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp],
     "nfa_accumulate_along_rays": [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _i64, _int, _vp, _vp],
     "nfa_accumulate_along_rays_atomic": [_vp, _vp, _i32, _vp, _i64, _i64, _vp, _vp],
     "nfa_accumulate_along_rays_bwd": [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],

@@ -1113,6 +1113,7 @@ struct CompactOp : OpBase1 {
     const int64_t *out_starts;
     int64_t *o_ri;
     float *o_ts, *o_te;
+    int64_t cap = (int64_t)1 << 62;   // elements the output arrays hold (a caller that sized them before the total was known)
     float *stage = nullptr;
     const int64_t *s_start = nullptr;
     int32_t g_lo = 0, g_n = 0;
@@ -1201,7 +1202,7 @@ struct CompactOp : OpBase1 {
                     if (o < (uint32_t)SEG_CHUNK) { s_ts[o] = a[j]; s_te[o] = b[j]; s_ri[o] = er[j]; }
                 }
             __builtin_amdgcn_wave_barrier();
-            const int n = (int)span;
+            const int n = (int)max((int64_t)0, min(span, cap - base));   // nothing at or beyond the capacity
             float *g_ts = o_ts + base, *g_te = o_te + base;
             int64_t *g_ri = o_ri + base;
             for (int o = 4 * lane; o < n; o += 256) {
@@ -1221,7 +1222,7 @@ struct CompactOp : OpBase1 {
         } else {
 #pragma unroll
             for (int j = 0; j < SE; ++j)
-                if (keep[j]) { o_ri[dst[j]] = er[j]; o_ts[dst[j]] = a[j]; o_te[dst[j]] = b[j]; }
+                if (keep[j] && dst[j] < cap) { o_ri[dst[j]] = er[j]; o_ts[dst[j]] = a[j]; o_te[dst[j]] = b[j]; }
         }
     }
 };
@@ -2073,16 +2074,17 @@ int nfa_render_visibility(const float *t_starts, const float *t_ends, const floa
 
 int nfa_compact_samples(const uint8_t *vis, const float *t_starts, const float *t_ends, const int64_t *packed_info,
                         const int64_t *tiles, int64_t n_tiles, const int64_t *out_starts, int64_t n_rays, int64_t n_elems,
-                        int64_t *out_ray_indices, float *out_t_starts, float *out_t_ends, nfa_stream_t stream)
+                        int64_t *out_ray_indices, float *out_t_starts, float *out_t_ends, int64_t capacity, nfa_stream_t stream)
 {
     SEG_COMMON_CHECKS("compact_samples");
     if (n_elems == 0) return NFA_OK;
     NFA_REQUIRE(vis && t_starts && t_ends && out_starts, "compact_samples: null input");
+    NFA_REQUIRE(capacity >= 0, "compact_samples: negative capacity");
     hipStream_t s = as_stream(stream);
     const bool vec = all_aligned16(t_starts, t_ends);
 #define NFA_CP(V)                                                                                          \
     do { CompactOp<V> op; op.vis = vis; op.vis_vec = (reinterpret_cast<uintptr_t>(vis) & 3) == 0; op.ts = t_starts; op.te = t_ends; op.out_starts = out_starts;       \
-         op.o_ri = out_ray_indices; op.o_ts = out_t_starts; op.o_te = out_t_ends;                           \
+         op.o_ri = out_ray_indices; op.o_ts = out_t_starts; op.o_te = out_t_ends; op.cap = capacity;        \
          launch_seg<1>(op, packed_info, tiles, n_rays, n_tiles, s); } while (0)
     if (vec) NFA_CP(true); else NFA_CP(false);
 #undef NFA_CP

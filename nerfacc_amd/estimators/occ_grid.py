@@ -451,32 +451,73 @@ def _pinned_total(dev) -> Tensor:
     return buf
 
 
+#: kept fraction of the previous batch per (n_rays, device): decides whether the next compaction is launched before its size
+#: is known to the host
+_KEPT_FRACTION: dict = {}
+_SPECULATE_COMPACTION = __import__("os").environ.get("NERFACC_AMD_SPECULATE_COMPACTION", "1") != "0"
+
+
 def _compact(seg: SegInfo, vis: Tensor, cnts: Tensor, t_starts: Tensor, t_ends: Tensor):
-    """``x[masks]`` for the sampler's three arrays in one pass (ref :216-220), given the mask and
-    the per-ray visible counts.  One device->host read (the output size).  Returns None when no
-    sample is dropped (the caller keeps its arrays: same values as the boolean-index copy)."""
+    """``x[masks]`` for the sampler's three arrays in one pass (ref :216-220), given the mask and the per-ray visible counts.
+    Returns None when no sample is dropped (the caller keeps its arrays: same values as the boolean-index copy).
+
+    One device->host read (the output size).  When the previous batch of this shape dropped samples, the compaction is
+    launched BEFORE that read, into arrays sized from the previous batch's kept fraction: the size travels on a side stream
+    that waits for the cumsum only, the host reads it while the compaction runs, and the launches that follow queue up behind
+    it -- no idle GPU between the read and the next kernel (a total above the capacity: the pass wrote nothing beyond it and is
+    repeated into arrays of the right size).  When the previous batch kept everything (early termination that never
+    bites), nothing is launched speculatively: a compaction that copies every sample would cost more than the read."""
     dev = t_starts.device
     n = t_starts.numel()
+    key = (seg.n_rays, dev.index)
     with torch.cuda.device(dev):
         total = torch.empty(1, dtype=torch.int64, device=dev)
         out_starts = _exclusive_cumsum(cnts, total)
-        if _PINNED_READ:
+        frac = _KEPT_FRACTION.get(key, 1.0) if _SPECULATE_COMPACTION else 1.0
+        host = _pinned_total(dev)
+        ri = ts = te = None
+        cap = 0
+
+        def run(ri, ts, te, capacity):
+            B.call("nfa_compact_samples", B.ptr(vis), B.ptr(t_starts), B.ptr(t_ends), B.ptr(seg.packed_info),
+                   B.ptr(seg.tiles), seg.n_tiles, B.ptr(out_starts), seg.n_rays, n, B.ptr(ri), B.ptr(ts), B.ptr(te), capacity, B.stream())
+
+        if frac < 1.0 and n > 0:
+            cap = min(n, ((int(n * min(1.0, frac * 1.03)) + 8192) // 4096) * 4096)
+            main = torch.cuda.current_stream()
+            ready = torch.cuda.Event(); ready.record(main)
+            from ..grid import _side_stream
+            side = _side_stream(dev)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                host.copy_(total, non_blocking=True)
+                done = torch.cuda.Event(); done.record(side)
+            ri = torch.empty(cap, dtype=torch.int64, device=dev)
+            ts = torch.empty(cap, dtype=torch.float32, device=dev)
+            te = torch.empty(cap, dtype=torch.float32, device=dev)
+            run(ri, ts, te, cap)
+            done.synchronize()
+            m = int(host[0])
+        elif _PINNED_READ:
             # the output size through pinned host memory and an event: no staging copy kernel, no implicit device sync
-            host = _pinned_total(dev)
             host.copy_(total, non_blocking=True)
             done = torch.cuda.Event(); done.record()
             done.synchronize()
             m = int(host[0])
         else:
             m = int(total.item())
+        if n > 0:
+            _KEPT_FRACTION[key] = m / n
         if m == n:  # every sample is visible: x[masks] would be a copy of x
             return None
-        ri = torch.empty(m, dtype=torch.int64, device=dev)
-        ts = torch.empty(m, dtype=torch.float32, device=dev)
-        te = torch.empty(m, dtype=torch.float32, device=dev)
-        if m > 0:
-            B.call("nfa_compact_samples", B.ptr(vis), B.ptr(t_starts), B.ptr(t_ends), B.ptr(seg.packed_info),
-                   B.ptr(seg.tiles), seg.n_tiles, B.ptr(out_starts), seg.n_rays, n, B.ptr(ri), B.ptr(ts), B.ptr(te), B.stream())
+        if cap > 0 and m <= cap:
+            ri, ts, te = ri[:m], ts[:m], te[:m]
+        else:
+            ri = torch.empty(m, dtype=torch.int64, device=dev)
+            ts = torch.empty(m, dtype=torch.float32, device=dev)
+            te = torch.empty(m, dtype=torch.float32, device=dev)
+            if m > 0:
+                run(ri, ts, te, m)
         packed = torch.stack([out_starts, cnts], dim=-1)
     info = tag_trusted(packed, m)
     tag_ray_indices(ri, seg.n_rays, info)

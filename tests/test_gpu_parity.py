@@ -1171,7 +1171,7 @@ def test_compact_samples_consecutive_and_arbitrary_output_offsets(dev):
             o_ts = torch.full((m,), -1.0, device=dev); o_te = torch.full((m,), -1.0, device=dev)
             d = [torch.from_numpy(x).to(dev) for x in (vis, ts, te, starts)]
             B.call("nfa_compact_samples", B.ptr(d[0]), B.ptr(d[1]), B.ptr(d[2]), B.ptr(seg.packed_info), B.ptr(seg.tiles),
-                   seg.n_tiles, B.ptr(d[3]), R, n, B.ptr(o_ri), B.ptr(o_ts), B.ptr(o_te), B.stream())
+                   seg.n_tiles, B.ptr(d[3]), R, n, B.ptr(o_ri), B.ptr(o_ts), B.ptr(o_te), m, B.stream())
             k = vis != 0
             rank = np.concatenate([np.arange(c) for c in kept]) if m else np.zeros(0, np.int64)
             want_pos = starts[ray[k]] + rank
@@ -1179,6 +1179,13 @@ def test_compact_samples_consecutive_and_arbitrary_output_offsets(dev):
             e_ri[want_pos] = ray[k]; e_ts[want_pos] = ts[k]; e_te[want_pos] = te[k]
             assert np.array_equal(o_ri.cpu().numpy(), e_ri) and np.array_equal(o_ts.cpu().numpy(), e_ts)
             assert np.array_equal(o_te.cpu().numpy(), e_te)
+            # a capacity below the total (outputs sized before the total was known): nothing at or beyond it is written
+            cap = max(m * 2 // 3, 1)
+            o_ri.fill_(-1); o_ts.fill_(-1.0); o_te.fill_(-1.0)
+            B.call("nfa_compact_samples", B.ptr(d[0]), B.ptr(d[1]), B.ptr(d[2]), B.ptr(seg.packed_info), B.ptr(seg.tiles),
+                   seg.n_tiles, B.ptr(d[3]), R, n, B.ptr(o_ri), B.ptr(o_ts), B.ptr(o_te), cap, B.stream())
+            assert np.array_equal(o_ri.cpu().numpy()[:cap], e_ri[:cap]) and np.array_equal(o_te.cpu().numpy()[:cap], e_te[:cap])
+            assert (o_ri[cap:] == -1).all() and (o_ts[cap:] == -1.0).all() and (o_te[cap:] == -1.0).all()
 
 
 def test_cdf_rows_fused_with_the_transmittance_pass(dev):
@@ -1769,6 +1776,36 @@ def test_onepass_traversal_equals_two_launches_and_oracle(dev, oracle):
         _onepass_traversal_cases(dev, oracle)
     finally:
         G.ONEPASS = saved
+
+
+def test_speculative_compaction_capacity(dev):
+    """The sampler launches the compaction into arrays sized from the PREVIOUS batch's kept fraction before the host has read
+    this batch's size (estimators/occ_grid.py: _compact): batches that keep more than that capacity, fewer, everything
+    (no compaction at all) and nothing must return exactly what the read-then-compact order returns."""
+    from nerfacc_amd.estimators import occ_grid as OG
+    import bench
+    rng = np.random.default_rng(8)
+    R = 20_000
+    o = (rng.random((R, 3)) * 3 - 1.5).astype(np.float32)
+    d = rng.standard_normal((R, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=64).to(dev)
+    est.binaries = T(bench.make_grid(64, "shell10"), dev)
+    est.occs = est.binaries.reshape(-1).float()
+    ro, rd = T(o, dev), T(d, dev)
+    saved = OG._SPECULATE_COMPACTION
+    try:
+        fracs = []
+        for scale in (30.0, 3.0, 300.0, 0.0, 100.0, 1e6, 30.0):     # kept fraction goes up (over capacity), down, to 1, ~0, back
+            fn = lambda ts, te, ri: torch.full_like(ts, scale)
+            OG._SPECULATE_COMPACTION = False
+            ref = est.sampling(ro, rd, sigma_fn=fn, render_step_size=5e-3, early_stop_eps=1e-2)
+            OG._SPECULATE_COMPACTION = True
+            got = est.sampling(ro, rd, sigma_fn=fn, render_step_size=5e-3, early_stop_eps=1e-2)
+            assert all(torch.equal(x, y) for x, y in zip(ref, got)) and got[0].is_contiguous(), scale
+            fracs.append(got[0].numel())
+        assert fracs[1] > 1.5 * fracs[0] and fracs[2] < fracs[0] and fracs[3] == max(fracs) and fracs[5] < fracs[4]
+    finally:
+        OG._SPECULATE_COMPACTION = saved
 
 
 def test_walk_survives_degenerate_rays(dev, oracle):
