@@ -8,6 +8,7 @@ ops are hand-written HIP kernels for gfx950 in ``libnerfacc_hip.so`` (C ABI:
 from .data_specs import RayIntervals, RaySamples
 from .estimators.occ_grid import OccGridEstimator
 from .estimators.prop_net import PropNetEstimator
+from .graphs import CapturedStep  # extension (hipGraph replay of fixed-shape steps); not part of the reference's 20 names
 from .grid import ray_aabb_intersect, traverse_grids
 from .pack import pack_info
 from .pdf import importance_sampling, searchsorted

@@ -42,6 +42,16 @@ class PropNetEstimator(AbstractEstimator):
         self.scheduler = scheduler
         self.prop_cache: List = []
 
+    def capture(self, step_fn: Callable, warmup: int = 3):
+        """A fixed-shape training step of this estimator (``sampling`` with ``requires_grad`` -> the user's rendering ->
+        ``compute_loss`` -> ``torch.autograd.grad``, all inside ``step_fn()``) as ONE hipGraph launch: returns a
+        :class:`nerfacc_amd.graphs.CapturedStep`; calling it replays the step and returns ``step_fn``'s (static) outputs,
+        identical to the eager step's.  The batched path has no host synchronisation, which is what makes this possible
+        (the reference's does: ``.item()`` in its scans' host code).  Extension: no counterpart upstream.  The proposal
+        cache is consumed inside the step, as in the eager order ``sampling`` -> ``compute_loss``."""
+        from ..graphs import CapturedStep
+        return CapturedStep(step_fn, warmup=warmup)
+
     @torch.no_grad()
     def sampling(
         self,

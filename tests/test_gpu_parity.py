@@ -1871,6 +1871,41 @@ def test_propnet_step_captures_into_a_hipgraph():
 
 
 
+def test_captured_propnet_step_replays_identically(dev):
+    """PropNetEstimator.capture: the fixed-shape step (level loop, batched transmittance, proposal loss, its gradient) as one
+    hipGraph launch (nerfacc_amd.CapturedStep) -- every replay returns exactly the eager step's outputs, also after the
+    tensors the step reads were rewritten in place.  In a child process: a capture that fails takes its process down."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+import nerfacc_amd as na
+dev = torch.device("cuda:0")
+R = 4096
+p = torch.nn.Parameter(torch.tensor([3.0, 4.0], device=dev))
+shift = torch.zeros(1, device=dev)
+est = na.PropNetEstimator().to(dev)
+prop = lambda ts, te: torch.exp(-((ts + te) * 0.5 - p[1] - shift) ** 2) * p[0]
+fine = lambda ts, te: torch.exp(-((ts + te) * 0.5 - 4.0) ** 2 * 2.0) * 5.0
+def step():
+    ts, te = est.sampling([prop, prop], [64, 64], 16, R, 2.0, 6.0, sampling_type="uniform", stratified=False, requires_grad=True)
+    trans, _ = na.render_transmittance_from_density(ts, te, fine(ts, te))
+    loss = est.compute_loss(trans)
+    return ts, te, loss, torch.autograd.grad(loss, [p])[0]
+captured = est.capture(step)
+ok = True
+for k in range(3):
+    shift.fill_(0.1 * k)                      # new data written INTO the tensors the step reads
+    got = [t.clone() for t in captured()]
+    want = step()
+    ok = ok and all(torch.equal(a, b) for a, b in zip(got, want))
+print("OK captured", ok, captured.replays)
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK captured True 3" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-500:])
+
+
 def test_results_do_not_depend_on_the_tiling():
     """The packed ops (rendering forward / backward, visibility, weights, accumulation, scans) on twelve random ragged
     batches -- empty rays, runs of tiny rays, rays of thousands of samples -- give the same bits whatever the tile size:
