@@ -212,7 +212,8 @@ int nfa_fill_ray_indices(int64_t n_rays, const int64_t *packed_info /*[n_rays,2]
                          nfa_stream_t stream);
 /* Sampler path for distance-dependent steps (step_size > 0 and cone_angle > 0; ref grid.cu:207-262 recomputes
  * dt = max(step, t * cone) for every sample, so samples are not arithmetic runs):
- *   nfa_traverse_cone_runs  the count pass of nfa_traverse_grids (args->mode 0, samples only, no limit) that also leaves
+ *   nfa_traverse_cone_runs  the count pass of nfa_traverse_grids (samples only; args->mode 0, or 2 = honour rays_mask and
+ *                           traverse_steps_limit: the test-mode loop's compact form of over_allocate) that also leaves
  *                           run records {t_first:f32 | k_start:31, continues_previous:1} in runs[max_runs][n_rays]
  *                           (slot-major), one per chain of continuous samples and at least one per 64 samples; rays
  *                           with more records are counted in *overflow_count and must be filled with

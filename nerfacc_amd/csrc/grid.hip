@@ -286,6 +286,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(const nfa_traverse_args a
             if (a.terminate_planes) a.terminate_planes[tid] = a.near_planes[tid];
             if (HAS_IV) a.iv_cnts[tid] = 0;
             if (HAS_SM) a.sm_cnts[tid] = 0;
+            if (EMIT == EMIT_RUNS) ro.run_cnts[tid] = 0;
             continue;
         }
         if (a.ray_filter != nullptr && a.ray_filter[tid] <= a.ray_filter_min) continue;
@@ -687,7 +688,8 @@ int nfa_traverse_cone_runs(const nfa_traverse_args *pa, int32_t *run_cnts, uint6
     if (hipMemsetAsync(overflow_count, 0, sizeof(int32_t), s) != hipSuccess) { set_error("traverse_cone_runs: memset failed"); return NFA_EHIP; }
     if (a.n_rays == 0) return NFA_OK;
     NFA_REQUIRE(a.step_size > 0.0f && a.cone_angle > 0.0f, "traverse_cone_runs: needs step_size > 0 and cone_angle > 0");
-    NFA_REQUIRE(a.mode == 0 && a.traverse_steps_limit <= 0, "traverse_cone_runs: mode must be 0 and no traverse_steps_limit");
+    NFA_REQUIRE(a.mode == 0 || a.mode == 2, "traverse_cone_runs: mode must be 0 (all rays) or 2 (rays_mask + traverse_steps_limit)");
+    NFA_REQUIRE(a.mode != 2 || a.traverse_steps_limit > 0, "traverse_steps_limit must be > 0 when over_allocate is true");
     NFA_REQUIRE(a.rays_o && a.rays_d && a.binaries && a.aabbs && a.near_planes && a.far_planes && a.sm_cnts && !a.iv_cnts &&
                     run_cnts && runs, "traverse_cone_runs: null pointer (or interval outputs requested)");
     NFA_REQUIRE(max_runs >= 1 && max_runs <= 32, "traverse_cone_runs: max_runs must be in [1, 32]");

@@ -434,7 +434,8 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
     the two boolean-index syncs.  Constant-step marching (``cone_angle == 0``) takes the
     run-length path: one DDA walk per ray + a fully parallel, coalesced expansion.
 
-    With ``rays_mask`` / ``traverse_steps_limit`` this is the compacted equivalent of the reference's
+    With ``rays_mask`` / ``traverse_steps_limit`` (constant step, or a cone angle with a step limit: mask and limit are honoured
+    inside the walk, which emits the compact arrays directly) this is the compacted equivalent of the reference's
     ``traverse_grids(over_allocate=True, rays_mask=..., traverse_steps_limit=...)`` followed by the
     ``is_left`` / ``is_right`` / ``is_valid`` boolean indexing of examples/utils.py:342-365: masked
     rays get no samples, every other ray at most ``traverse_steps_limit``.
@@ -443,7 +444,7 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
     use_runs = float(step_size) > 0.0 and float(cone_angle) == 0.0 and _walk_supported(binaries)
     # distance-dependent steps: run records from the count pass + a coalesced expansion instead of a second walk
     use_cone_runs = CONE_RUNS and float(step_size) > 0.0 and float(cone_angle) > 0.0
-    if not use_runs and (rays_mask is not None or limit > 0):
+    if (rays_mask is not None or limit > 0) and (not (use_runs or use_cone_runs) or (use_cone_runs and limit <= 0)):
         # marching with a cone angle / per-cell mode: the reference's route (over-allocate + compaction)
         iv, sm, term = traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size, cone_angle,
                                       limit if limit > 0 else None, limit > 0, rays_mask, t_sorted, t_indices, hits)
@@ -470,7 +471,7 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
         meta = torch.zeros(6, dtype=torch.int64, device=dev)
         terminate = torch.empty(n_rays, dtype=torch.float32, device=dev) if return_terminate else None
         a = _traverse_args(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indices, hits, near_planes, far_planes,
-                           step_size, cone_angle, limit, 2 if (use_runs and masked) else 0)
+                           step_size, cone_angle, limit, 2 if ((use_runs or use_cone_runs) and masked) else 0)
         a.sm_cnts = B.ptr(sm_cnts)
         a.terminate_planes = B.ptr(terminate)
         if use_runs:
