@@ -1,0 +1,7 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+rm -rf $OUT/r03_cfg5_testmode_trace
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r03_cfg5_testmode_trace -- python3 $R/bench.py --only cfg5_testmode --steps 12 > $OUT/r03_cfg5_testmode_trace.log 2>&1
+echo rc=$?
+f=$(find $OUT/r03_cfg5_testmode_trace -name "*kernel_stats.csv" | head -1)
+head -16 $f | cut -c1-150
