@@ -41,8 +41,13 @@ constexpr int WK_EV = NFA_WK_EV;           // list slots per ray: 16 KiB of LDS 
 #ifndef NFA_WALK_OP_RL
 #define NFA_WALK_OP_RL 6
 #endif
-static_assert(NFA_WK_EV == 16, "the list-full test is bit 14 of the slot address: 16 slots of 1 KiB");
-constexpr uint32_t WK_FULL = (uint32_t)WK_EV << 10;  // slot address bit that says "the open entry sits in slot WK_EV"
+static_assert(NFA_WK_EV == 16, "the list-full test is one bit of the slot address: 16 slots");
+#ifndef NFA_WALK_LG
+#define NFA_WALK_LG 10   /* log2 of the bytes of one list slot = 4 bytes x threads per workgroup: 10 = 256 threads */
+#endif
+constexpr int WK_LG = NFA_WALK_LG;
+constexpr int WK_THREADS = 1 << (WK_LG - 2);
+constexpr uint32_t WK_FULL = (uint32_t)WK_EV << WK_LG;  // slot address bit that says "the open entry sits in slot WK_EV"
 constexpr uint32_t WK_GUARD = (1u << 9) | (1u << 19) | (1u << 29);
 constexpr int WK_MAX_RES = 512;            // 9-bit step counters
 
@@ -123,7 +128,7 @@ __device__ __forceinline__ void marcher_refresh(Marcher &s, float dt)
 
 // Where a ray's run records go: the first RL of them into the lane's LDS column (the one-pass kernel expands them from
 // there), the others -- all of them with RL == 0 -- into the slot-major global array runs[slot][ray].
-constexpr int WK_REC_STRIDE = 256 * 8;   // bytes between two slots of one lane: [RL][256] records of 8 bytes
+constexpr int WK_REC_STRIDE = WK_THREADS * 8;   // bytes between two slots of one lane: [RL][threads] records of 8 bytes
 // RL == WK_RL_AGENT + k: k LDS slots, and the global array written with agent-scope (write-through) 8-byte stores: the
 // records are read by a wave of another compute unit, possibly behind another L2, while this launch is still running
 // (expand_units_kernel).
@@ -294,8 +299,8 @@ __device__ __forceinline__ void marcher_run(Marcher &s, const char *col /* LDS c
         int32_t type = 0, adv = 1, next_ptype = 0;
         while (k < cnt && !blocked) {
             if (limit > 0 && s.n_samples >= limit) { k = cnt; break; }  // grid.cu:184: nothing moves once the limit is hit
-            const float v0 = *reinterpret_cast<const float *>(col + (k << 10));
-            const float v1 = *reinterpret_cast<const float *>(col + ((k + 1) << 10));   // (slot k + 1 <= WK_EV exists)
+            const float v0 = *reinterpret_cast<const float *>(col + (k << WK_LG));
+            const float v1 = *reinterpret_cast<const float *>(col + ((k + 1) << WK_LG));   // (slot k + 1 <= WK_EV exists)
             const int32_t is_span = (int32_t)((ev_span >> k) & 1u);
             const float tmax_k = is_span ? v1 : s.span_tmax;
             thr = is_span ? v0 : vmin_f32(v0, tmax_k);
@@ -348,7 +353,7 @@ __device__ __forceinline__ void marcher_run(Marcher &s, const char *col /* LDS c
             tried = r == 1;
             if (r == 0) {
                 marcher_general<RL>(s, thr, type, dt, half, limit, p, tid, rec_col);
-                if (is_span_entry(ev_span, k)) s.span_tmax = *reinterpret_cast<const float *>(col + ((k + 1) << 10));
+                if (is_span_entry(ev_span, k)) s.span_tmax = *reinterpret_cast<const float *>(col + ((k + 1) << WK_LG));
                 k += adv; s.ptype = next_ptype;
             }
         }
@@ -458,7 +463,7 @@ __device__ __forceinline__ void walk_cell(float dx, float dy, float dz, uint32_t
     w_cur = bits[i_cur >> 5];
 #endif
     open ^= (int32_t)changed;                 // = the current cell's occupancy
-    ev_addr += changed << 10;                 // the open entry is complete when the occupancy flips
+    ev_addr += changed << WK_LG;                 // the open entry is complete when the occupancy flips
     *reinterpret_cast<float *>(ev_lds + ev_addr) = m;
     m_out = m;
 }
@@ -542,7 +547,7 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
         int32_t finished = 0;
         for (;;) {
             if (!in_span) {
-                const uint32_t used = (ev_addr >> 10) + (uint32_t)has_open;
+                const uint32_t used = (ev_addr >> WK_LG) + (uint32_t)has_open;
                 if (used > (uint32_t)(WK_EV - 2)) break;  // a span start needs two slots and one for its first entry: flush first
                 float this_tmin = 0.f, this_tmax = 0.f;
                 int32_t level = 0;
@@ -573,15 +578,15 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
                 if (!found) { finished = 1; break; }
                 // the open entry of the previous span is complete; then the span start: (this_tmin, this_tmax)
                 uint32_t kk = used;
-                *reinterpret_cast<float *>(col + (kk << 10)) = this_tmin;
-                *reinterpret_cast<float *>(col + ((kk + 1u) << 10)) = this_tmax;
+                *reinterpret_cast<float *>(col + (kk << WK_LG)) = this_tmin;
+                *reinterpret_cast<float *>(col + ((kk + 1u) << WK_LG)) = this_tmax;
                 ev_span |= 1u << kk;
                 walk_span_setup(a, p, o, d, level, this_tmin, this_tmax, sp);
                 const uint32_t idx0 = sp.widx ^ sp.flip;
                 w_cur = bits[idx0 >> 5]; i_cur = idx0;
                 open_type = (int32_t)((w_cur >> (idx0 & 31u)) & 1u);
                 ev_span |= (uint32_t)open_type << (16u + kk);
-                ev_addr = ((kk + 2u) << 10) | lane_off;
+                ev_addr = ((kk + 2u) << WK_LG) | lane_off;
                 has_open = 1;
                 in_span = 1;
             }
@@ -604,7 +609,7 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
             else break;  // list full
         }
         // ---------------- phase 2
-        int32_t cnt = (int32_t)(ev_addr >> 10);
+        int32_t cnt = (int32_t)(ev_addr >> WK_LG);
         if (finished && has_open) { cnt += 1; has_open = 0; }
 #ifndef NFA_WALK_NO_PHASE2
         marcher_run<HAS_LIMIT, RL>(s, col, cnt, ev_span, dt, limit, p, tb, tid, rec_col);
@@ -618,9 +623,9 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
 }
 
 template <bool FUSED, bool HAS_LIMIT>
-NFA_WALK_OCC __global__ __launch_bounds__(256) void walk_kernel(const nfa_traverse_args a, const WalkParams p)
+NFA_WALK_OCC __global__ __launch_bounds__(WK_THREADS) void walk_kernel(const nfa_traverse_args a, const WalkParams p)
 {
-    __shared__ __attribute__((aligned(16))) char ev_lds[(WK_EV + 1) * 1024];   // [WK_EV + 1][256] floats
+    __shared__ __attribute__((aligned(16))) char ev_lds[(WK_EV + 1) << WK_LG];   // [WK_EV + 1][256] floats
     __shared__ ApproachLds tb;
     approach_to_lds(tb, p);
     __syncthreads();
@@ -744,21 +749,21 @@ __device__ __forceinline__ uint32_t wave_ticket(uint32_t *counter)
 }
 
 template <bool FUSED, bool HAS_LIMIT>
-NFA_OP_WALK_OCC __global__ __launch_bounds__(256) void walk_publish_kernel(const nfa_traverse_args a, const WalkParams p, const OnePassParams q)
+NFA_OP_WALK_OCC __global__ __launch_bounds__(WK_THREADS) void walk_publish_kernel(const nfa_traverse_args a, const WalkParams p, const OnePassParams q)
 {
-    __shared__ __attribute__((aligned(16))) char ev_lds[(WK_EV + 1) * 1024];   // [WK_EV + 1][256] floats
+    __shared__ __attribute__((aligned(16))) char ev_lds[(WK_EV + 1) << WK_LG];   // [WK_EV + 1][256] floats
     __shared__ ApproachLds tb;
     // The rays' first OP_RL run records wait in LDS and leave together when the unit is done.  (Stored one by one from the
     // marcher with write-through stores they stalled the walk: the cell loop's wait for its grid word is a wait for
     // every earlier memory operation of the wave, and a write-through store is acknowledged by memory -- microseconds
     // while the expander's write stream saturates it: the walk took 850 us beside the expander instead of 181.)
-    __shared__ __attribute__((aligned(16))) unsigned long long rec_lds[OP_RL * 256];   // [OP_RL][256]
+    __shared__ __attribute__((aligned(16))) unsigned long long rec_lds[OP_RL * WK_THREADS];   // [OP_RL][threads]
     approach_to_lds(tb, p);
     __syncthreads();
     const int lane = lane_id();
     const uint32_t lane_off = 4u * threadIdx.x;
     char *const rec_col = reinterpret_cast<char *>(rec_lds) + 8u * threadIdx.x;
-    const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t unit = (int64_t)blockIdx.x * (WK_THREADS / 64) + (threadIdx.x >> 6);
     if (unit >= q.n_units) return;   // (the whole wave)
     const int64_t tid = unit * 64 + lane;
     const bool active = tid < a.n_rays;
@@ -1116,12 +1121,12 @@ int nfa_traverse_runs(const nfa_traverse_args *pa, const uint32_t *bits, int32_t
     if (near_hint == near_hint) approach_table_build(p.approach, near_hint, a.step_size);
     else p.approach.n = 0;
     const size_t shmem = 0;  // the lists are static LDS
-    const unsigned grid = grid_1d(a.n_rays, 256, 1 << 20);
+    const unsigned grid = grid_1d(a.n_rays, WK_THREADS, 1 << 20);
     const bool lim = a.traverse_steps_limit > 0;
-    if (fused && !lim)      hipLaunchKernelGGL((walk_kernel<true, false>), dim3(grid), dim3(256), shmem, s, a, p);
-    else if (fused)         hipLaunchKernelGGL((walk_kernel<true, true>), dim3(grid), dim3(256), shmem, s, a, p);
-    else if (!lim)          hipLaunchKernelGGL((walk_kernel<false, false>), dim3(grid), dim3(256), shmem, s, a, p);
-    else                    hipLaunchKernelGGL((walk_kernel<false, true>), dim3(grid), dim3(256), shmem, s, a, p);
+    if (fused && !lim)      hipLaunchKernelGGL((walk_kernel<true, false>), dim3(grid), dim3(WK_THREADS), shmem, s, a, p);
+    else if (fused)         hipLaunchKernelGGL((walk_kernel<true, true>), dim3(grid), dim3(WK_THREADS), shmem, s, a, p);
+    else if (!lim)          hipLaunchKernelGGL((walk_kernel<false, false>), dim3(grid), dim3(WK_THREADS), shmem, s, a, p);
+    else                    hipLaunchKernelGGL((walk_kernel<false, true>), dim3(grid), dim3(WK_THREADS), shmem, s, a, p);
     NFA_CHECK_LAUNCH("traverse_runs");
     return NFA_OK;
 }
@@ -1222,12 +1227,13 @@ int nfa_traverse_onepass_walk(const nfa_traverse_args *pa, const uint32_t *bits,
     OnePassParams q;
     onepass_params(q, a.n_rays, scratch);
     hipStream_t s = as_stream(stream);
-    const unsigned grid = (unsigned)((q.n_units + 3) / 4);
+    constexpr int UPW = WK_THREADS / 64;
+    const unsigned grid = (unsigned)((q.n_units + UPW - 1) / UPW);
     const bool lim = a.traverse_steps_limit > 0;
-    if (fused && !lim)      hipLaunchKernelGGL((walk_publish_kernel<true, false>), dim3(grid), dim3(256), 0, s, a, p, q);
-    else if (fused)         hipLaunchKernelGGL((walk_publish_kernel<true, true>), dim3(grid), dim3(256), 0, s, a, p, q);
-    else if (!lim)          hipLaunchKernelGGL((walk_publish_kernel<false, false>), dim3(grid), dim3(256), 0, s, a, p, q);
-    else                    hipLaunchKernelGGL((walk_publish_kernel<false, true>), dim3(grid), dim3(256), 0, s, a, p, q);
+    if (fused && !lim)      hipLaunchKernelGGL((walk_publish_kernel<true, false>), dim3(grid), dim3(WK_THREADS), 0, s, a, p, q);
+    else if (fused)         hipLaunchKernelGGL((walk_publish_kernel<true, true>), dim3(grid), dim3(WK_THREADS), 0, s, a, p, q);
+    else if (!lim)          hipLaunchKernelGGL((walk_publish_kernel<false, false>), dim3(grid), dim3(WK_THREADS), 0, s, a, p, q);
+    else                    hipLaunchKernelGGL((walk_publish_kernel<false, true>), dim3(grid), dim3(WK_THREADS), 0, s, a, p, q);
     NFA_CHECK_LAUNCH("traverse_onepass_walk");
     return NFA_OK;
 }
