@@ -153,9 +153,12 @@ int nfa_pack_bricks(const uint8_t *binaries, int32_t n_grids, const int32_t *res
                     uint32_t *coarse, nfa_stream_t stream);
 int64_t nfa_walk_bits_words(int32_t n_grids, const int32_t *res);
 int nfa_pack_walk_bits(const uint8_t *binaries, int32_t n_grids, const int32_t *res, uint32_t *bits, nfa_stream_t stream);
+/* ray_order[n_order] (NULL: every ray, in index order): the rays to walk and the lane each gets.  n_order < n_rays walks
+ * the listed rays only -- the others' sm_cnts / run_cnts / terminate_planes are left as the caller initialised them (the
+ * test-mode loop lists its alive rays, so that dead rays cost no lanes). */
 int nfa_traverse_runs(const nfa_traverse_args *args, const uint32_t *bits, int32_t *run_cnts, uint64_t *runs,
                       int32_t max_runs, int32_t *overflow_count, float near_hint, const int32_t *ray_order,
-                      nfa_stream_t stream);
+                      int64_t n_order, nfa_stream_t stream);
 /* The sampler's traverse_grids without the serial chain count pass -> cumsum + host read -> fill pass (ref:
  * cuda/csrc/grid.cu:405-471, include/data_spec.hpp:86-96): the walk and the expansion of its run records are two launches
  * that run at the same time on two streams.
@@ -223,8 +226,8 @@ int nfa_fill_ray_indices(int64_t n_rays, const int64_t *packed_info /*[n_rays,2]
  *                           most 63 steps), so the values are bit-identical to the marching loop's, and the second DDA
  *                           walk of the fill pass is replaced by coalesced stores. */
 int nfa_traverse_cone_runs(const nfa_traverse_args *args, int32_t *run_cnts, uint64_t *runs, int32_t max_runs,
-                           int32_t *overflow_count, const int32_t *ray_order /* lane -> ray assignment or NULL */,
-                           nfa_stream_t stream);
+                           int32_t *overflow_count, const int32_t *ray_order /* as for nfa_traverse_runs, or NULL */,
+                           int64_t n_order, nfa_stream_t stream);
 int nfa_expand_cone_runs(int64_t n_rays, float step_size, float cone_angle, const int32_t *run_cnts,
                          const uint64_t *runs, int32_t max_runs, const int64_t *packed_info, float *t_starts,
                          float *t_ends, int64_t *ray_indices, nfa_stream_t stream);

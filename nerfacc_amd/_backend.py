@@ -56,7 +56,7 @@ _SIGS = {
     "nfa_pack_bricks": [_vp, _i32, C.POINTER(_i32), _vp, _vp, _vp],
     "nfa_walk_bits_words": [_i32, C.POINTER(_i32)],
     "nfa_pack_walk_bits": [_vp, _i32, C.POINTER(_i32), _vp, _vp],
-    "nfa_traverse_runs": [C.POINTER(TraverseArgs), _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp],
+    "nfa_traverse_runs": [C.POINTER(TraverseArgs), _vp, _vp, _vp, _i32, _vp, _f32, _vp, _i64, _vp],
     "nfa_traverse_onepass_scratch_words": [_i64],
     "nfa_traverse_onepass_begin": [_i64, _vp, _vp],
     "nfa_traverse_onepass_expand": [_i64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp],
@@ -68,7 +68,7 @@ _SIGS = {
     "nfa_grid_rebinarize": [_vp, _i32, C.POINTER(_i32), _f32, _vp, _vp, _vp, _vp],
     "nfa_expand_runs": [_i64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "nfa_fill_ray_indices": [_i64, _vp, _vp, _vp],
-    "nfa_traverse_cone_runs": [C.POINTER(TraverseArgs), _vp, _vp, _i32, _vp, _vp, _vp],
+    "nfa_traverse_cone_runs": [C.POINTER(TraverseArgs), _vp, _vp, _i32, _vp, _vp, _i64, _vp],
     "nfa_bin_rays_levels": [_vp, _vp, _i64, _vp, _i32, C.POINTER(_i32), _f32, _vp, _vp, _vp, _vp],
     "nfa_expand_cone_runs": [_i64, _f32, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "nfa_expand_intervals": [_i64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -89,6 +89,7 @@ struct RunOut {
     int32_t max_runs;
     int32_t *overflow;          // [1]
     const int32_t *order;       // lane -> ray assignment (nfa_bin_rays / nfa_bin_rays_levels) or NULL
+    int64_t n_order;            // its entries (< n_rays: only the listed rays are walked; the others keep their outputs)
 };
 
 struct RayState {
@@ -276,7 +277,8 @@ __attribute__((amdgpu_waves_per_eu(NFA_TRAVERSE_WAVES, 8)))
 #endif
 __global__ __launch_bounds__(256) void traverse_kernel(const nfa_traverse_args a, const RunOut ro)
 {
-    for (int64_t slot_i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; slot_i < a.n_rays;
+    const int64_t n_walk = (EMIT == EMIT_RUNS && ro.order) ? ro.n_order : a.n_rays;
+    for (int64_t slot_i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; slot_i < n_walk;
          slot_i += (int64_t)blockDim.x * gridDim.x) {
         // (a wave runs as long as its longest ray: with unrelated rays the lanes of a wave get rays of similar length)
         const int64_t tid = (EMIT == EMIT_RUNS && ro.order) ? (int64_t)ro.order[slot_i] : slot_i;
@@ -364,9 +366,9 @@ __global__ __launch_bounds__(256) void traverse_kernel(const nfa_traverse_args a
 }
 
 template <int EMIT, bool HAS_IV, bool HAS_SM>
-static void launch_traverse(const nfa_traverse_args &a, bool fused, hipStream_t s, const RunOut ro = RunOut{nullptr, nullptr, 0, nullptr, nullptr})
+static void launch_traverse(const nfa_traverse_args &a, bool fused, hipStream_t s, const RunOut ro = RunOut{nullptr, nullptr, 0, nullptr, nullptr, 0})
 {
-    const unsigned grid = grid_1d(a.n_rays, 256, 1 << 20);
+    const unsigned grid = grid_1d((EMIT == EMIT_RUNS && ro.order) ? ro.n_order : a.n_rays, 256, 1 << 20);
     if (fused) hipLaunchKernelGGL((traverse_kernel<EMIT, HAS_IV, HAS_SM, true>), dim3(grid), dim3(256), 0, s, a, ro);
     else       hipLaunchKernelGGL((traverse_kernel<EMIT, HAS_IV, HAS_SM, false>), dim3(grid), dim3(256), 0, s, a, ro);
 }
@@ -678,7 +680,7 @@ int nfa_traverse_grids(const nfa_traverse_args *pa, nfa_stream_t stream)
 }
 
 int nfa_traverse_cone_runs(const nfa_traverse_args *pa, int32_t *run_cnts, uint64_t *runs, int32_t max_runs,
-                           int32_t *overflow_count, const int32_t *ray_order, nfa_stream_t stream)
+                           int32_t *overflow_count, const int32_t *ray_order, int64_t n_order, nfa_stream_t stream)
 {
     NFA_REQUIRE(pa != nullptr, "traverse_cone_runs: null args");
     const nfa_traverse_args &a = *pa;
@@ -704,6 +706,9 @@ int nfa_traverse_cone_runs(const nfa_traverse_args *pa, int32_t *run_cnts, uint6
     ro.max_runs = max_runs;
     ro.overflow = overflow_count;
     ro.order = ray_order;
+    ro.n_order = ray_order ? n_order : a.n_rays;
+    NFA_REQUIRE(!ray_order || (n_order >= 0 && n_order <= a.n_rays), "traverse_cone_runs: n_order out of range");
+    if (ray_order && n_order == 0) return NFA_OK;
     launch_traverse<EMIT_RUNS, false, true>(a, fused, s, ro);
     NFA_CHECK_LAUNCH("traverse_cone_runs");
     return NFA_OK;

@@ -81,6 +81,7 @@ struct WalkParams {
     int32_t max_runs;
     int32_t *overflow;           // [1] rays with more runs than max_runs
     const int32_t *order;        // lane -> ray assignment or NULL
+    int64_t n_order;             // entries of `order` (< n_rays: only the listed rays are walked; the others keep their outputs)
     ApproachTable approach;      // march.h; n == 0: none
 };
 
@@ -630,7 +631,8 @@ NFA_WALK_OCC __global__ __launch_bounds__(WK_THREADS) void walk_kernel(const nfa
     approach_to_lds(tb, p);
     __syncthreads();
     const uint32_t lane_off = 4u * threadIdx.x;
-    for (int64_t slot_i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; slot_i < a.n_rays;
+    const int64_t n_walk = p.order ? p.n_order : a.n_rays;
+    for (int64_t slot_i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; slot_i < n_walk;
          slot_i += (int64_t)blockDim.x * gridDim.x) {
         const int64_t tid = p.order ? (int64_t)p.order[slot_i] : slot_i;
         if (a.mode == 2 && a.rays_mask != nullptr && !a.rays_mask[tid]) {
@@ -1085,7 +1087,7 @@ int nfa_pack_walk_bits(const uint8_t *binaries, int32_t n_grids, const int32_t *
 }
 
 int nfa_traverse_runs(const nfa_traverse_args *pa, const uint32_t *bits, int32_t *run_cnts, uint64_t *runs, int32_t max_runs,
-                      int32_t *overflow_count, float near_hint, const int32_t *ray_order, nfa_stream_t stream)
+                      int32_t *overflow_count, float near_hint, const int32_t *ray_order, int64_t n_order, nfa_stream_t stream)
 {
     NFA_REQUIRE(pa != nullptr, "traverse_runs: null args");
     const nfa_traverse_args &a = *pa;
@@ -1116,12 +1118,15 @@ int nfa_traverse_runs(const nfa_traverse_args *pa, const uint32_t *bits, int32_t
     p.n_rays = a.n_rays;
     p.overflow = overflow_count;
     p.order = ray_order;
+    p.n_order = ray_order ? n_order : a.n_rays;
+    NFA_REQUIRE(!ray_order || (n_order >= 0 && n_order <= a.n_rays), "traverse_runs: n_order out of range");
+    if (ray_order && n_order == 0) return NFA_OK;
     // near_hint: the value most (or all) entries of near_planes hold, NaN if unknown.  Rays whose near plane
     // differs bit-wise simply do not use the table.
     if (near_hint == near_hint) approach_table_build(p.approach, near_hint, a.step_size);
     else p.approach.n = 0;
     const size_t shmem = 0;  // the lists are static LDS
-    const unsigned grid = grid_1d(a.n_rays, WK_THREADS, 1 << 20);
+    const unsigned grid = grid_1d(p.n_order, WK_THREADS, 1 << 20);
     const bool lim = a.traverse_steps_limit > 0;
     if (fused && !lim)      hipLaunchKernelGGL((walk_kernel<true, false>), dim3(grid), dim3(WK_THREADS), shmem, s, a, p);
     else if (fused)         hipLaunchKernelGGL((walk_kernel<true, true>), dim3(grid), dim3(WK_THREADS), shmem, s, a, p);
@@ -1222,6 +1227,7 @@ int nfa_traverse_onepass_walk(const nfa_traverse_args *pa, const uint32_t *bits,
     p.n_rays = a.n_rays;
     p.overflow = reinterpret_cast<int32_t *>(scratch + 3);
     p.order = nullptr;
+    p.n_order = a.n_rays;
     if (near_hint == near_hint) approach_table_build(p.approach, near_hint, a.step_size);
     else p.approach.n = 0;
     OnePassParams q;

@@ -196,7 +196,7 @@ def traverse_grids(
             run_cnts = torch.empty(n_rays, dtype=torch.int32, device=dev)
             runs = torch.empty((MAX_RUNS, n_rays), dtype=torch.int64, device=dev)
             B.call("nfa_traverse_runs", C.byref(a), B.ptr(bits), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
-                   B.ptr(meta[2:3]), float("nan") if near_hint is None else near_hint, None, B.stream())
+                   B.ptr(meta[2:3]), float("nan") if near_hint is None else near_hint, None, 0, B.stream())
             iv_packed = _cumsum_packed(iv_cnts, meta[0:1])
             sm_packed = _cumsum_packed(sm_cnts, meta[1:2])
             n_iv, n_sm, n_overflow = (int(v) for v in meta.tolist())  # the one device->host read
@@ -425,7 +425,7 @@ CONE_BIN_THRESHOLD = 1.25   # cone-angle walk: bin the rays when a wave of 64 ne
 @torch.no_grad()
 def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size, cone_angle,
                       rays_mask=None, traverse_steps_limit=None, t_sorted=None, t_indices=None, hits=None,
-                      return_terminate=False, near_hint=None, bin_rays=False, stats_sink=None, speculate=True):
+                      return_terminate=False, near_hint=None, bin_rays=False, stats_sink=None, speculate=True, n_alive=None):
     """Sampler fast path: (ray_indices, t_starts, t_ends, packed_info) straight from the traversal.
 
     Same values as ``intervals.vals[is_left]``, ``intervals.vals[is_right]``,
@@ -438,7 +438,10 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
     inside the walk, which emits the compact arrays directly) this is the compacted equivalent of the reference's
     ``traverse_grids(over_allocate=True, rays_mask=..., traverse_steps_limit=...)`` followed by the
     ``is_left`` / ``is_right`` / ``is_valid`` boolean indexing of examples/utils.py:342-365: masked
-    rays get no samples, every other ray at most ``traverse_steps_limit``.
+    rays get no samples, every other ray at most ``traverse_steps_limit``.  ``n_alive``: the number of True entries of
+    ``rays_mask`` when the caller knows it (the test-mode loop reads it anyway): with fewer than three quarters of the rays
+    alive only those are walked, packed into dense waves -- a dead ray then costs no lane (it used to cost its wave the
+    lane's slot for as long as the wave's longest alive ray walked).
     """
     limit = -1 if traverse_steps_limit is None else int(traverse_steps_limit)
     use_runs = float(step_size) > 0.0 and float(cone_angle) == 0.0 and _walk_supported(binaries)
@@ -466,19 +469,26 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
                                     far_planes, step_size, limit, masked, near_hint, return_terminate, stats_sink, spec_key)
             if out is not None:
                 return out
-        sm_cnts = torch.empty(n_rays, dtype=torch.int64, device=dev)
+        alive = None   # ids of the alive rays, when only they are walked
+        if (rays_mask is not None and n_alive is not None and (use_runs or use_cone_runs) and not binned
+                and 0 <= n_alive and 4 * n_alive < 3 * n_rays):
+            alive = torch.nonzero_static(rays_mask, size=int(n_alive)).view(-1).to(torch.int32)
+            sm_cnts = torch.zeros(n_rays, dtype=torch.int64, device=dev)          # (the rays not listed keep these)
+            terminate = near_planes.clone() if return_terminate else None
+        else:
+            sm_cnts = torch.empty(n_rays, dtype=torch.int64, device=dev)
+            terminate = torch.empty(n_rays, dtype=torch.float32, device=dev) if return_terminate else None
         # [total samples, coherence sums (2), rays with too many runs, coherence sums of the cone walk's cell-count key (2)]
         meta = torch.zeros(6, dtype=torch.int64, device=dev)
-        terminate = torch.empty(n_rays, dtype=torch.float32, device=dev) if return_terminate else None
         a = _traverse_args(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indices, hits, near_planes, far_planes,
                            step_size, cone_angle, limit, 2 if ((use_runs or use_cone_runs) and masked) else 0)
         a.sm_cnts = B.ptr(sm_cnts)
         a.terminate_planes = B.ptr(terminate)
         if use_runs:
             bits = _get_walk_bits(binaries)
-            run_cnts = torch.empty(n_rays, dtype=torch.int32, device=dev)
+            run_cnts = (torch.zeros if alive is not None else torch.empty)(n_rays, dtype=torch.int32, device=dev)
             runs = torch.empty((MAX_RUNS, n_rays), dtype=torch.int64, device=dev)  # slot-major run records
-            order = None
+            order = alive
             if binned:
                 # unrelated rays: lanes of a wave get rays of similar path length (results do not depend on it)
                 order = torch.empty(n_rays, dtype=torch.int32, device=dev)
@@ -487,13 +497,14 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
                        B.stream())
             # near_hint: the scalar near plane when the caller built near_planes from one (accelerator only)
             B.call("nfa_traverse_runs", C.byref(a), B.ptr(bits), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
-                   B.ptr(meta[3:4]), float("nan") if near_hint is None else float(near_hint), B.ptr(order), B.stream())
+                   B.ptr(meta[3:4]), float("nan") if near_hint is None else float(near_hint), B.ptr(order),
+                   0 if order is None else order.numel(), B.stream())
         elif use_cone_runs:
             _get_bricks(binaries)
-            run_cnts = torch.empty(n_rays, dtype=torch.int32, device=dev)
+            run_cnts = (torch.zeros if alive is not None else torch.empty)(n_rays, dtype=torch.int32, device=dev)
             runs = torch.empty((MAX_RUNS, n_rays), dtype=torch.int64, device=dev)
-            order = None
-            if binned or (bin_rays is None and n_rays >= 65536):
+            order = alive
+            if binned or (bin_rays is None and n_rays >= 65536 and alive is None):
                 # Unrelated rays: a wave runs as long as its longest ray, so its lanes get rays that cross about as many cells
                 # (results do not depend on it).  bin_rays None: the key is computed anyway (0.06 ms per 2 M rays beside a walk
                 # of milliseconds) for its coherence measure, and the assignment is used when the PREVIOUS batch's measure
@@ -506,7 +517,7 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
                 if not binned and not (stats_sink is not None and stats_sink.get("cells_max_over_mean", 1.0) > CONE_BIN_THRESHOLD):
                     order = None
             B.call("nfa_traverse_cone_runs", C.byref(a), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS, B.ptr(meta[3:4]), B.ptr(order),
-                   B.stream())
+                   0 if order is None else order.numel(), B.stream())
         else:
             _launch(a)
         packed_info = _cumsum_packed(sm_cnts, meta[0:3], stats=True)

@@ -89,7 +89,7 @@ def render_rays_test_mode(
         ray_indices, t_starts, t_ends, packed_info, termination_planes = _traverse_samples(
             rays_o, rays_d, estimator.binaries, estimator.aabbs, near_planes, far_planes, render_step_size,
             cone_angle, rays_mask=ray_mask, traverse_steps_limit=n_samples, t_sorted=t_sorted, t_indices=t_indices,
-            hits=hits, return_terminate=True, near_hint=near_plane if iter_samples == n_samples else None)
+            hits=hits, return_terminate=True, near_hint=near_plane if iter_samples == n_samples else None, n_alive=n_alive)
 
         n_counted = 0
         if ray_indices.numel() > 0:

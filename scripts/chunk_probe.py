@@ -41,7 +41,7 @@ def run(chunks, overlap):
     e0.record(main)
     evs = []
     for c, (a, sm, rc, runs, meta, pk, scr, ts, te, ri, per, cap) in enumerate(bufs):
-        B.call("nfa_traverse_runs", C.byref(a), B.ptr(bits), B.ptr(rc), B.ptr(runs), 32, B.ptr(meta[3:4]), 0.0, None, main.cuda_stream)
+        B.call("nfa_traverse_runs", C.byref(a), B.ptr(bits), B.ptr(rc), B.ptr(runs), 32, B.ptr(meta[3:4]), 0.0, None, 0, main.cuda_stream)
         st = side if overlap else main
         if overlap:
             ev = torch.cuda.Event(); ev.record(main); side.wait_event(ev)

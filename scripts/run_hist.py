@@ -25,7 +25,7 @@ for res, rays in ((128, "image"), (256, "image"), (128, "random")):
     rc = torch.empty(n, dtype=torch.int32, device=dev)
     runs = torch.empty((32, n), dtype=torch.int64, device=dev)
     ov = torch.zeros(1, dtype=torch.int32, device=dev)
-    B.call("nfa_traverse_runs", C.byref(a), B.ptr(bits), B.ptr(rc), B.ptr(runs), 32, B.ptr(ov), 0.0, None, B.stream())
+    B.call("nfa_traverse_runs", C.byref(a), B.ptr(bits), B.ptr(rc), B.ptr(runs), 32, B.ptr(ov), 0.0, None, 0, B.stream())
     torch.cuda.synchronize()
     c = rc.cpu().numpy()
     s = sm.cpu().numpy()
