@@ -102,21 +102,32 @@ struct RayState {
     int32_t n_runs, run_len;  // EMIT_RUNS: records written, samples in the open record
 };
 
-// One [this_tmin, this_tmax) span inside grid `level`.
-template <int EMIT, bool HAS_IV, bool HAS_SM>
-__device__ __forceinline__ void traverse_span(const nfa_traverse_args &a, int64_t tid, const float o[3],
-                                              const float d[3], const float inv[3], int32_t level,
-                                              float this_tmin, float this_tmax, int64_t iv_base,
-                                              int64_t sm_base, RayState &st, const RunOut &ro)
-{
-    const float eps = 1e-6f;  // grid.cu:95
-    const float step_size = a.step_size, cone = a.cone_angle;
-    const int32_t limit = a.traverse_steps_limit;
-    if (!st.continuous) st.t_last = fast_forward(st.t_last, this_tmin, step_size, cone);
-
-    const float *bmin = a.aabbs + 6 * level, *bmax = bmin + 3;
+// The walk of one [this_tmin, this_tmax) span inside grid `level`, as a resumable pair: span_begin() sets the DDA up,
+// span_cell() visits one cell and says whether the span is over.  traverse_span() runs them back to back (one ray per lane
+// from start to end); traverse_refill_kernel interleaves the cells of different rays on one lane.
+struct SpanState {
     float tdist[3], delta[3];
     int32_t step[3], cur[3], overflow[3];
+    float this_tmax;
+    int32_t level;
+    int32_t cells_left;  // safety cap, never binding for a valid DDA
+};
+
+// 4x4x4 bricks: bit ((x&3)<<4 | (y&3)<<2 | (z&3)) of word ((x>>2)*by + (y>>2))*bz + (z>>2)
+__device__ __forceinline__ int32_t brick_index(const nfa_traverse_args &a, const SpanState &sp)
+{
+    const int32_t by = (a.res[1] + 3) >> 2, bz = (a.res[2] + 3) >> 2, bx = (a.res[0] + 3) >> 2;
+    const int32_t brick_base = sp.level * bx * by * bz;
+    return brick_base + (int32_t)mad_u24(mad_u24((uint32_t)sp.cur[0] >> 2, (uint32_t)by, (uint32_t)sp.cur[1] >> 2), (uint32_t)bz, (uint32_t)sp.cur[2] >> 2);
+}
+
+__device__ __forceinline__ void span_begin(const nfa_traverse_args &a, const float o[3], const float d[3], const float inv[3],
+                                           int32_t level, float this_tmin, float this_tmax, RayState &st, SpanState &sp)
+{
+    const float eps = 1e-6f;  // grid.cu:95
+    if (!st.continuous) st.t_last = fast_forward(st.t_last, this_tmin, a.step_size, a.cone_angle);
+
+    const float *bmin = a.aabbs + 6 * level, *bmax = bmin + 3;
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
         const float resf = (float)a.res[ax];
@@ -131,18 +142,43 @@ __device__ __forceinline__ void traverse_span(const nfa_traverse_args &a, int64_
         const int32_t start_index = c + (d[ax] > 0.0f ? 1 : 0);
         const float tmax_ax = ((bmin[ax] + (((float)start_index * voxel) - ray_start)) * inv[ax]) + this_tmin;
         const float step_f = (d[ax] == 0.0f) ? 0.0f : (d[ax] > 0.0f ? 1.0f : -1.0f);
-        tdist[ax] = (d[ax] == 0.0f) ? this_tmax : tmax_ax;
-        step[ax] = (int32_t)step_f;
+        sp.tdist[ax] = (d[ax] == 0.0f) ? this_tmax : tmax_ax;
+        sp.step[ax] = (int32_t)step_f;
         const float delta_tmp = voxel * inv[ax] * step_f;
-        delta[ax] = (d[ax] == 0.0f) ? this_tmax : delta_tmp;
-        cur[ax] = c;
-        overflow[ax] = f + step[ax];
+        sp.delta[ax] = (d[ax] == 0.0f) ? this_tmax : delta_tmp;
+        sp.cur[ax] = c;
+        sp.overflow[ax] = f + sp.step[ax];
     }
-    const int64_t level_base = (int64_t)level * a.res[0] * a.res[1] * a.res[2];
-    int32_t cells_left = a.res[0] + a.res[1] + a.res[2] + 3;  // safety cap, never binding for a valid DDA
-    // 4x4x4 bricks: bit ((x&3)<<4 | (y&3)<<2 | (z&3)) of word ((x>>2)*by + (y>>2))*bz + (z>>2)
-    const int32_t by = (a.res[1] + 3) >> 2, bz = (a.res[2] + 3) >> 2, bx = (a.res[0] + 3) >> 2;
-    const int32_t brick_base = level * bx * by * bz;
+    sp.this_tmax = this_tmax;
+    sp.level = level;
+    sp.cells_left = a.res[0] + a.res[1] + a.res[2] + 3;
+    if (a.bricks != nullptr) {
+        const int32_t bid = brick_index(a, sp);
+        if (bid != st.brick_id) {
+            st.brick_id = bid;
+            const unsigned long long w = a.bricks[bid];  // (the 1-bit mask would be a second, dependent access)
+            st.brick_lo = (uint32_t)w; st.brick_hi = (uint32_t)(w >> 32);
+        }
+    }
+}
+
+// One cell of the span; true when the span is over (its last cell, or the sample budget spent).
+//
+// The body is written for the scalar unit as much as for the vector ALUs: with unrelated rays every `if`, `break` and bool
+// that lives across a branch becomes a handful of 64-bit mask operations on the CU's single scalar pipe, and the first
+// version of this loop issued more scalar than vector instructions (8.1 G vs 6.1 G per launch on cfg 5: the scalar pipe was
+// the bottleneck).  Hence: one exit, flags in integer registers, selects instead of branches, and the brick word of the NEXT
+// cell requested before the current cell is marched (the DDA does not depend on the march), so that the load's latency
+// overlaps the march.
+template <int EMIT, bool HAS_IV, bool HAS_SM>
+__device__ __forceinline__ bool span_cell(const nfa_traverse_args &a, int64_t tid, int64_t iv_base, int64_t sm_base,
+                                          SpanState &sp, RayState &st, const RunOut &ro)
+{
+    const float step_size = a.step_size, cone = a.cone_angle;
+    const int32_t limit = a.traverse_steps_limit;
+    float (&tdist)[3] = sp.tdist;
+    int32_t (&cur)[3] = sp.cur;
+    const float this_tmax = sp.this_tmax;
 
     // one sample [t_last, t_next) (grid.cu:219-258)
     auto emit = [&](float t_next) {
@@ -191,80 +227,76 @@ __device__ __forceinline__ void traverse_span(const nfa_traverse_args &a, int64_
         st.t_last = t_next;
     };
 
-    // The hot loop is written for the scalar unit as much as for the vector ALUs: with unrelated rays every `if`, `break`
-    // and bool that lives across a branch becomes a handful of 64-bit mask operations on the CU's single scalar pipe, and
-    // the first version of this loop issued more scalar than vector instructions (8.1 G vs 6.1 G per launch on cfg 5:
-    // the scalar pipe was the bottleneck).  Hence: one exit per loop, flags in integer registers, selects instead of
-    // branches, and the brick word of the NEXT cell requested before the current cell is marched (the DDA does not
-    // depend on the march), so that the load's latency overlaps the march.
-    auto brick_of = [&](void) {
-        return brick_base + (int32_t)mad_u24(mad_u24((uint32_t)cur[0] >> 2, (uint32_t)by, (uint32_t)cur[1] >> 2), (uint32_t)bz, (uint32_t)cur[2] >> 2);
-    };
     const bool use_bricks = a.bricks != nullptr;
+    const float t_traverse = fminf(fminf(tdist[0], fminf(tdist[1], tdist[2])), this_tmax);
+    bool occupied;
     if (use_bricks) {
-        const int32_t bid = brick_of();
-        if (bid != st.brick_id) {
-            st.brick_id = bid;
-            const unsigned long long w = a.bricks[bid];  // (the 1-bit mask would be a second, dependent access)
-            st.brick_lo = (uint32_t)w; st.brick_hi = (uint32_t)(w >> 32);
-        }
+        const uint32_t half_w = (cur[0] & 2) ? st.brick_hi : st.brick_lo;
+        occupied = (half_w >> (((cur[0] & 1) << 4) | ((cur[1] & 3) << 2) | (cur[2] & 3))) & 1u;
+    } else {
+        const int64_t level_base = (int64_t)sp.level * a.res[0] * a.res[1] * a.res[2];
+        occupied = a.binaries[level_base + (int64_t)(cur[0] * a.res[1] * a.res[2] + cur[1] * a.res[2] + cur[2])] != 0;
     }
-    if (limit > 0 && st.n_samples >= limit) return;
-    for (;;) {
-        const float t_traverse = fminf(fminf(tdist[0], fminf(tdist[1], tdist[2])), this_tmax);
-        bool occupied;
-        if (use_bricks) {
-            const uint32_t half_w = (cur[0] & 2) ? st.brick_hi : st.brick_lo;
-            occupied = (half_w >> (((cur[0] & 1) << 4) | ((cur[1] & 3) << 2) | (cur[2] & 3))) & 1u;
-        } else {
-            occupied = a.binaries[level_base + (int64_t)(cur[0] * a.res[1] * a.res[2] + cur[1] * a.res[2] + cur[2])] != 0;
-        }
-        // single_traversal, utils_grid.cuh:116-142 (branch-free)
-        const bool s0 = (tdist[0] < tdist[1]) && (tdist[0] < tdist[2]);
-        const bool s1 = !s0 && (tdist[1] < tdist[2]);
-        const bool s2 = !s0 && !s1;
-        cur[0] += s0 ? step[0] : 0; tdist[0] += s0 ? delta[0] : 0.0f;
-        cur[1] += s1 ? step[1] : 0; tdist[1] += s1 ? delta[1] : 0.0f;
-        cur[2] += s2 ? step[2] : 0; tdist[2] += s2 ? delta[2] : 0.0f;
-        const bool done = (s0 && cur[0] == overflow[0]) || (s1 && cur[1] == overflow[1]) || (s2 && cur[2] == overflow[2]);
-        unsigned long long w_next = 0ull;
-        const int32_t bid_next = use_bricks ? brick_of() : st.brick_id;
-        const bool fetch = use_bricks && !done && bid_next != st.brick_id;
-        if (fetch) w_next = a.bricks[bid_next];
+    // single_traversal, utils_grid.cuh:116-142 (branch-free)
+    const bool s0 = (tdist[0] < tdist[1]) && (tdist[0] < tdist[2]);
+    const bool s1 = !s0 && (tdist[1] < tdist[2]);
+    const bool s2 = !s0 && !s1;
+    cur[0] += s0 ? sp.step[0] : 0; tdist[0] += s0 ? sp.delta[0] : 0.0f;
+    cur[1] += s1 ? sp.step[1] : 0; tdist[1] += s1 ? sp.delta[1] : 0.0f;
+    cur[2] += s2 ? sp.step[2] : 0; tdist[2] += s2 ? sp.delta[2] : 0.0f;
+    // (the stepped axis reached its overflow index; as one select chain: `||` of `&&`s compiles to nested branches)
+    const int32_t off_end = s0 ? (cur[0] ^ sp.overflow[0]) : (s1 ? (cur[1] ^ sp.overflow[1]) : (cur[2] ^ sp.overflow[2]));
+    const bool done = off_end == 0;
+    unsigned long long w_next = 0ull;
+    const int32_t bid_next = use_bricks ? brick_index(a, sp) : st.brick_id;
+    const bool fetch = use_bricks && !done && bid_next != st.brick_id;
+    if (fetch) w_next = a.bricks[bid_next];
 
-        if (step_size <= 0.0f) {  // one interval per occupied cell (grid.cu:155,198,212)
-            if (occupied) emit(t_traverse);
-            else { st.t_last = t_traverse; st.continuous = 0; }
-        } else {
-            // March to t_traverse.  An empty cell skips with the dt of its first step (grid.cu:193-206), an occupied
-            // one emits with dt recomputed per sample (grid.cu:207-262): one loop, so that a wave whose lanes sit in
-            // cells of both kinds runs it once.
-            float dt = calc_dt(st.t_last, cone, step_size);
-            // a skip of many steps (cell much larger than the step): closed form (march.h), same result as the loop
-            if (!occupied && t_traverse - st.t_last > 8.0f * dt) st.t_last = fast_forward_exact(st.t_last, t_traverse, dt);
-            for (;;) {
-                const float t_next = st.t_last + dt;
-                const bool budget = !(occupied && limit > 0 && st.n_samples >= limit);
-                if (!((st.t_last + dt * 0.5f < t_traverse) && (t_next != st.t_last) && budget)) break;
-                if (occupied) {
-                    emit(t_next);
-                    dt = calc_dt(t_next, cone, step_size);
-                } else {
-                    st.t_last = t_next;
-                }
-            }
-            if (!occupied) {
-                // left the loop before the target without progress (ours: the reference would spin): jump there
-                if (st.t_last + dt * 0.5f < t_traverse) st.t_last = t_traverse;
-                st.continuous = 0;
+    if (step_size <= 0.0f) {  // one interval per occupied cell (grid.cu:155,198,212)
+        if (occupied) emit(t_traverse);
+        else { st.t_last = t_traverse; st.continuous = 0; }
+    } else {
+        // March to t_traverse.  An empty cell skips with the dt of its first step (grid.cu:193-206), an occupied
+        // one emits with dt recomputed per sample (grid.cu:207-262): one loop, so that a wave whose lanes sit in
+        // cells of both kinds runs it once.  (Measured: two loops, and empty cells walked ahead with the occupied
+        // ones sampled in batches, are both slower -- 14.0 and 22-24 ms against 12.8 ms on cfg 5.)
+        float dt = calc_dt(st.t_last, cone, step_size);
+        // a skip of many steps (cell much larger than the step): closed form (march.h), same result as the loop
+        if (!occupied && t_traverse - st.t_last > 8.0f * dt) st.t_last = fast_forward_exact(st.t_last, t_traverse, dt);
+        for (;;) {
+            const float t_next = st.t_last + dt;
+            const bool budget = !(occupied && limit > 0 && st.n_samples >= limit);
+            if (!((st.t_last + dt * 0.5f < t_traverse) && (t_next != st.t_last) && budget)) break;
+            if (occupied) {
+                emit(t_next);
+                dt = calc_dt(t_next, cone, step_size);
+            } else {
+                st.t_last = t_next;
             }
         }
-        st.brick_id = fetch ? bid_next : st.brick_id;
-        st.brick_lo = fetch ? (uint32_t)w_next : st.brick_lo;
-        st.brick_hi = fetch ? (uint32_t)(w_next >> 32) : st.brick_hi;
-        --cells_left;
-        if (done || cells_left <= 0 || (limit > 0 && st.n_samples >= limit)) break;
+        if (!occupied) {
+            // left the loop before the target without progress (ours: the reference would spin): jump there
+            if (st.t_last + dt * 0.5f < t_traverse) st.t_last = t_traverse;
+            st.continuous = 0;
+        }
     }
+    st.brick_id = fetch ? bid_next : st.brick_id;
+    st.brick_lo = fetch ? (uint32_t)w_next : st.brick_lo;
+    st.brick_hi = fetch ? (uint32_t)(w_next >> 32) : st.brick_hi;
+    --sp.cells_left;
+    return done || sp.cells_left <= 0 || (limit > 0 && st.n_samples >= limit);
+}
+
+template <int EMIT, bool HAS_IV, bool HAS_SM>
+__device__ __forceinline__ void traverse_span(const nfa_traverse_args &a, int64_t tid, const float o[3],
+                                              const float d[3], const float inv[3], int32_t level,
+                                              float this_tmin, float this_tmax, int64_t iv_base,
+                                              int64_t sm_base, RayState &st, const RunOut &ro)
+{
+    SpanState sp;
+    span_begin(a, o, d, inv, level, this_tmin, this_tmax, st, sp);
+    if (a.traverse_steps_limit > 0 && st.n_samples >= a.traverse_steps_limit) return;
+    while (!span_cell<EMIT, HAS_IV, HAS_SM>(a, tid, iv_base, sm_base, sp, st, ro)) {}
 }
 
 // EMIT_NONE  : count pass (mode 0)
@@ -349,6 +381,9 @@ __global__ __launch_bounds__(256) void traverse_kernel(const nfa_traverse_args a
                 if (this_tmin >= this_tmax) continue;
                 traverse_span<EMIT, HAS_IV, HAS_SM>(a, tid, o, d, inv, level, this_tmin, this_tmax, iv_base,
                                                     sm_base, st, ro);
+                // The budget is spent: the last thing that happened was a sample (continuous), so the spans still to
+                // come would change nothing (grid.cu:151,185: no fast-forward, no cell visited) -- skip their set-up.
+                if (a.traverse_steps_limit > 0 && st.n_samples >= a.traverse_steps_limit) break;
             }
         }
         if (a.terminate_planes) a.terminate_planes[tid] = st.t_last;
@@ -371,6 +406,133 @@ static void launch_traverse(const nfa_traverse_args &a, bool fused, hipStream_t 
     const unsigned grid = grid_1d((EMIT == EMIT_RUNS && ro.order) ? ro.n_order : a.n_rays, 256, 1 << 20);
     if (fused) hipLaunchKernelGGL((traverse_kernel<EMIT, HAS_IV, HAS_SM, true>), dim3(grid), dim3(256), 0, s, a, ro);
     else       hipLaunchKernelGGL((traverse_kernel<EMIT, HAS_IV, HAS_SM, false>), dim3(grid), dim3(256), 0, s, a, ro);
+}
+
+// ------------------------------------------------------------------------------------------
+// Limited walks (traverse_steps_limit > 0: one iteration of the test-mode loop, examples/utils.py:252-425) stop after a
+// handful of samples, i.e. after a number of cells that is geometric in the local occupancy.  With one ray per lane from
+// start to end a wave lasts as long as its unluckiest ray: on cfg 5 (2 % scattered occupancy) the mean is 50 cells to the
+// first sample, the maximum over 64 lanes about 240, and the lanes are busy a fifth of the time (2.5 ms per call for
+// 2 M rays where the cells themselves are worth 0.3 ms).  Here a wave owns `chunk` consecutive slots of the ray list and
+// a lane that has finished its ray is given the next one: the wave leaves its cell loop when fewer than `min_busy` lanes
+// are still walking, sets up new rays (and the next spans of rays that crossed into another level) on the free lanes, and
+// re-enters.  Per ray the arithmetic is span_begin / span_cell, the same code as traverse_kernel: results are identical.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void traverse_refill_kernel(const nfa_traverse_args a, const RunOut ro, const int32_t chunk,
+                                                              const int32_t min_busy)
+{
+    enum { IDLE = 0, SPAN = 1, WALK = 2, FINISH = 3 };
+    const int lane = lane_id();
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    const int64_t n_walk = ro.order ? ro.n_order : a.n_rays;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int64_t next = wave * chunk;  // (wave-uniform) first slot not handed out yet
+    const int64_t end = next + chunk < n_walk ? next + chunk : n_walk;
+    const int32_t limit = a.traverse_steps_limit;
+    const int32_t G = a.n_grids;
+
+    int32_t phase = IDLE, ev = 0;
+    int64_t tid = 0;
+    float near_plane = 0.0f, far_plane = 0.0f;
+    float o[3] = {0.0f, 0.0f, 0.0f}, d[3] = {0.0f, 0.0f, 0.0f}, inv[3] = {0.0f, 0.0f, 0.0f};
+    RayState st;
+    SpanState sp;
+    st.t_last = 0.0f; st.continuous = 0; st.n_intervals = 0; st.n_samples = 0;
+    st.brick_id = -1; st.brick_lo = st.brick_hi = 0u; st.n_runs = 0; st.run_len = 0;
+
+    for (;;) {
+        // Two passes: rays that left a span in the cell loop (their next span, or their end), then the rays handed to
+        // the lanes that are free after that.
+#pragma nounroll
+        for (int pass = 0; pass < 2; ++pass) {
+            // ---- lanes between spans: the ray's next span, or its end
+            if (phase == SPAN) {
+                bool found = false;
+                if (FUSED) {
+                    if (ev == 0) {
+                        float tmin, tmax;
+                        if (slab_test(o, inv, a.aabbs, a.aabbs + 3, -INFINITY, INFINITY, tmin, tmax)) {
+                            const float this_tmin = fmaxf(tmin, near_plane);
+                            const float this_tmax = fminf(tmax, far_plane);
+                            if (this_tmin < this_tmax) { span_begin(a, o, d, inv, 0, this_tmin, this_tmax, st, sp); found = true; }
+                        }
+                    }
+                    ev = 1;
+                } else {
+                    const uint8_t *hits = a.hits + tid * G;
+                    const float *ts = a.t_sorted + tid * 2 * G;
+                    const int64_t *ti = a.t_indices + tid * 2 * G;
+                    while (ev < 2 * G - 1 && !found) {  // grid.cu:125-150
+                        const int32_t i = ev++;
+                        const int64_t idx = ti[i];
+                        int32_t level = (int32_t)(idx % G);
+                        bool ok = hits[level] != 0;
+                        if (ok && idx >= G) {  // leaving: inside the next grid?
+                            const int64_t nidx = ti[i + 1];
+                            level = (int32_t)(nidx % G);
+                            ok = nidx >= G && hits[level] != 0;
+                        }
+                        const float this_tmin = fmaxf(ts[i], near_plane);
+                        const float this_tmax = fminf(ts[i + 1], far_plane);
+                        if (ok && this_tmin < this_tmax) { span_begin(a, o, d, inv, level, this_tmin, this_tmax, st, sp); found = true; }
+                    }
+                }
+                phase = found ? WALK : FINISH;
+            }
+            if (phase == FINISH) {
+                if (a.terminate_planes) a.terminate_planes[tid] = st.t_last;
+                a.sm_cnts[tid] = st.n_samples;
+                if (st.n_samples > (1 << 21) && st.n_runs <= ro.max_runs) st.n_runs = ro.max_runs + 1;
+                ro.run_cnts[tid] = st.n_runs;
+                if (st.n_runs > ro.max_runs) atomicAdd(ro.overflow, 1);
+                phase = IDLE;
+            }
+            if (pass == 1) break;
+            // ---- free lanes take the next rays of the wave's chunk
+            const unsigned long long idle = __ballot(phase == IDLE);
+            if (idle != 0ull && next < end) {
+                if (phase == IDLE) {
+                    const int64_t slot = next + __popcll(idle & lanes_below);
+                    if (slot < end) {
+                        tid = ro.order ? (int64_t)ro.order[slot] : slot;
+                        if (a.mode == 2 && a.rays_mask != nullptr && !a.rays_mask[tid]) {  // grid.cu:100 (outputs defined, as in traverse_kernel)
+                            if (a.terminate_planes) a.terminate_planes[tid] = a.near_planes[tid];
+                            a.sm_cnts[tid] = 0;
+                            ro.run_cnts[tid] = 0;
+                        } else if (!(a.ray_filter != nullptr && a.ray_filter[tid] <= a.ray_filter_min)) {
+                            near_plane = a.near_planes[tid]; far_plane = a.far_planes[tid];
+    #pragma unroll
+                            for (int ax = 0; ax < 3; ++ax) {
+                                o[ax] = a.rays_o[3 * tid + ax];
+                                d[ax] = a.rays_d[3 * tid + ax];
+                                inv[ax] = 1.0f / d[ax];
+                            }
+                            st.t_last = near_plane; st.continuous = 0; st.n_samples = 0;
+                            st.brick_id = -1; st.n_runs = 0; st.run_len = 0;
+                            const bool ray_ok = isfinite(o[0]) && isfinite(o[1]) && isfinite(o[2]) && isfinite(d[0]) && isfinite(d[1]) && isfinite(d[2]);
+                            ev = ray_ok ? 0 : 2 * G;  // (no geometry: no spans, see traverse_kernel)
+                            phase = SPAN;
+                        }
+                    }
+                }
+                next += __popcll(idle);
+            }
+        }
+        const unsigned long long walking = __ballot(phase == WALK);
+        if (walking == 0ull) {
+            if (next >= end) break;  // (every lane is IDLE here: SPAN and FINISH were resolved above)
+            continue;
+        }
+        // ---- cells, for as long as enough lanes have one to visit
+        const int32_t n_walking = __popcll(walking);
+        const int32_t need = next < end ? min_busy : (n_walking * 3 >> 2) > 1 ? (n_walking * 3 >> 2) : 1;
+        do {
+            if (phase == WALK) {
+                if (span_cell<EMIT_RUNS, false, true>(a, tid, 0, 0, sp, st, ro))
+                    phase = (limit > 0 && st.n_samples >= limit) ? FINISH : SPAN;  // budget spent: nothing after it changes the ray (see traverse_kernel)
+            }
+        } while (__popcll(__ballot(phase == WALK)) >= need);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -709,7 +871,22 @@ int nfa_traverse_cone_runs(const nfa_traverse_args *pa, int32_t *run_cnts, uint6
     ro.n_order = ray_order ? n_order : a.n_rays;
     NFA_REQUIRE(!ray_order || (n_order >= 0 && n_order <= a.n_rays), "traverse_cone_runs: n_order out of range");
     if (ray_order && n_order == 0) return NFA_OK;
-    launch_traverse<EMIT_RUNS, false, true>(a, fused, s, ro);
+    const char *refill_env = getenv("NFA_REFILL");  // "0": one ray per lane; "chunk,min_busy": tuning
+    const char *refill_all = getenv("NFA_REFILL_ALL");
+    if ((a.traverse_steps_limit > 0 || (refill_all && refill_all[0] == '1')) && !(refill_env && refill_env[0] == '0')) {
+        // slots per wave: enough of them that a lane is refilled several times, as long as the launch still fills the chip
+        const int64_t n_walk = ro.n_order;
+        int64_t chunk = ((n_walk + 4095) / 4096 + 63) / 64 * 64;
+        chunk = chunk < 64 ? 64 : (chunk > 1024 ? 1024 : chunk);
+        int min_busy = 48;
+        if (refill_env) { long c = 0; int m = 0; if (sscanf(refill_env, "%ld,%d", &c, &m) == 2 && c >= 64 && m >= 1 && m <= 64) { chunk = c / 64 * 64; min_busy = m; } }
+        const int64_t n_waves = (n_walk + chunk - 1) / chunk;
+        const unsigned grid = (unsigned)((n_waves + 3) / 4);
+        if (fused) hipLaunchKernelGGL((traverse_refill_kernel<true>), dim3(grid), dim3(256), 0, s, a, ro, (int32_t)chunk, (int32_t)min_busy);
+        else       hipLaunchKernelGGL((traverse_refill_kernel<false>), dim3(grid), dim3(256), 0, s, a, ro, (int32_t)chunk, (int32_t)min_busy);
+    } else {
+        launch_traverse<EMIT_RUNS, false, true>(a, fused, s, ro);
+    }
     NFA_CHECK_LAUNCH("traverse_cone_runs");
     return NFA_OK;
 }

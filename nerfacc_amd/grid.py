@@ -504,11 +504,13 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
             run_cnts = (torch.zeros if alive is not None else torch.empty)(n_rays, dtype=torch.int32, device=dev)
             runs = torch.empty((MAX_RUNS, n_rays), dtype=torch.int64, device=dev)
             order = alive
-            if binned or (bin_rays is None and n_rays >= 65536 and alive is None):
+            if binned or (bin_rays is None and n_rays >= 65536 and alive is None and limit <= 0):
                 # Unrelated rays: a wave runs as long as its longest ray, so its lanes get rays that cross about as many cells
                 # (results do not depend on it).  bin_rays None: the key is computed anyway (0.06 ms per 2 M rays beside a walk
                 # of milliseconds) for its coherence measure, and the assignment is used when the PREVIOUS batch's measure
                 # said that neighbouring rays differ (image-ordered rays lose 8 % when binned, unrelated ones gain 10-17 %).
+                # (Not for limited walks: their length is decided by the next occupied cells, and the kernel hands rays to
+                # lanes as they become free.)
                 order = torch.empty(n_rays, dtype=torch.int32, device=dev)
                 scratch = torch.empty(1024 + n_rays, dtype=torch.uint8, device=dev)
                 res3 = (C.c_int32 * 3)(*binaries.shape[1:])
