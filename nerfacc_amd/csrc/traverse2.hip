@@ -23,6 +23,11 @@ constexpr int EXP_RPW = 32;        // rays per wave batch in the expansion
 #define NFA_EXP_QMAX 1024
 #endif
 constexpr int EXP_QMAX = NFA_EXP_QMAX;  // runs staged per batch (EXP_RPW * max_runs)
+#ifndef NFA_EXP_IV_QMAX
+#define NFA_EXP_IV_QMAX 256
+#endif
+constexpr int EXP_IV_QMAX = NFA_EXP_IV_QMAX;  // expand_intervals stages a batch's records this many at a time (>= 32: one ray's)
+static_assert(EXP_IV_QMAX >= 32 && EXP_IV_QMAX <= EXP_QMAX, "expand_intervals: a ray's records must fit the staging area");
 #ifndef NFA_EXP_WPB
 #define NFA_EXP_WPB 2  /* measured on cfg 2: 1 wave 176 us, 2 waves 160 us, 4 waves 175 us */
 #endif
@@ -398,9 +403,9 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_intervals_kernel(int64_t 
                                                                float *__restrict__ vals, int64_t *__restrict__ ray_indices,
                                                                uint8_t *__restrict__ is_left, uint8_t *__restrict__ is_right, int vec)
 {
-    __shared__ uint32_t s_pos[EXP_WPB][EXP_QMAX];
-    __shared__ float s_t0[EXP_WPB][EXP_QMAX];
-    __shared__ uint8_t s_cont[EXP_WPB][EXP_QMAX];
+    __shared__ uint32_t s_pos[EXP_WPB][EXP_IV_QMAX];
+    __shared__ float s_t0[EXP_WPB][EXP_IV_QMAX];
+    __shared__ uint8_t s_cont[EXP_WPB][EXP_IV_QMAX];
     __shared__ __attribute__((aligned(16))) int32_t s_own[EXP_WPB][256 + 4];  // + look-ahead slot for the chunk's last edge
     __shared__ __attribute__((aligned(16))) uint32_t s_mask[EXP_WPB][128];   // the chunk's is_left / is_right bytes, 4 per lane
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -413,26 +418,36 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_intervals_kernel(int64_t 
     for (int64_t batch = (int64_t)blockIdx.x * EXP_WPB + wave; batch < n_batches; batch += (int64_t)gridDim.x * EXP_WPB) {
         const int64_t r0 = batch * EXP_RPW;
         const int64_t ray = r0 + lane;
-        const bool mine = lane < EXP_RPW && ray < n_rays;
-        int32_t c = 0, c_real = 0;
+        const int n_loc = (int)min((int64_t)EXP_RPW, n_rays - r0);
+        int32_t c_all = 0, c_real = 0;
         int64_t s = 0, n = 0;
-        if (mine) {
+        if (lane < n_loc) {
             c_real = run_cnts[ray];
             const longlong2 row = iv_packed_info[ray];
             s = row.x;
             n = row.y;
-            c = (c_real > max_runs) ? 1 : c_real;  // overflowed ray: one sentinel entry
+            c_all = (c_real > max_runs) ? 1 : c_real;  // overflowed ray: one sentinel entry
         }
-        const int64_t W0 = __shfl(s, 0, 64);
-        const int last = (int)min((int64_t)EXP_RPW, n_rays - r0) - 1;
-        const int64_t W1 = __shfl(s + n, last, 64);
-        int32_t incl = c;
+        int32_t incl_all = c_all;
 #pragma unroll
         for (int off = 1; off < EXP_RPW; off <<= 1) {
-            const int32_t u = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += u;
+            const int32_t u = __shfl_up(incl_all, off, 64);
+            if (lane >= off) incl_all += u;
         }
-        const int32_t Q = __shfl(incl, EXP_RPW - 1, 64);
+        // The batch's records are staged EXP_IV_QMAX at a time: the rays [a, b) whose records fit (a typical batch has a
+        // hundred and is one group; 32 rays with 32 records each would be four).  The staging area decides how many waves a
+        // CU holds: sized for the worst case (1024 entries, 10.8 KB per wave) the kernel ran at 2.4 TB/s, with 256 entries
+        // (3.8 KB) at 3.3 TB/s.
+        for (int a = 0; a < n_loc;) {
+        const int32_t before = __shfl(incl_all - c_all, a, 64);
+        const int b = a + __popcll(__ballot(lane >= a && lane < n_loc && incl_all - before <= EXP_IV_QMAX));
+        const bool mine = lane >= a && lane < b;
+        const int32_t c = mine ? c_all : 0;
+        const int32_t incl = incl_all - before;   // (lanes a .. b-1)
+        const int64_t W0 = __shfl(s, a, 64);
+        const int64_t W1 = __shfl(s + n, b - 1, 64);
+        const int32_t Q = __shfl(incl, b - 1, 64);
+        a = b;
         __builtin_amdgcn_wave_barrier();
         if (mine && c > 0) {  // staging, one lane per ray
             const int32_t base = incl - c;
@@ -572,6 +587,7 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_intervals_kernel(int64_t 
             }
         }
         __builtin_amdgcn_wave_barrier();
+        }  // groups of rays
     }
 }
 
@@ -717,7 +733,7 @@ int nfa_expand_intervals(int64_t n_rays, float step_size, const int32_t *run_cnt
     if (n_rays == 0) return NFA_OK;
     NFA_REQUIRE(run_cnts && runs && iv_packed_info && vals && ray_indices && is_left && is_right,
                 "expand_intervals: null pointer");
-    NFA_REQUIRE(max_runs >= 1 && max_runs * EXP_RPW <= EXP_QMAX, "expand_intervals: max_runs must be in [1, 32]");
+    NFA_REQUIRE(max_runs >= 1 && max_runs <= EXP_IV_QMAX && max_runs * EXP_RPW <= EXP_QMAX, "expand_intervals: max_runs must be in [1, 32]");
     NFA_REQUIRE(step_size > 0.0f, "expand_intervals: step_size must be > 0");
     const int vec = ((reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(ray_indices) | reinterpret_cast<uintptr_t>(is_left) |
                       reinterpret_cast<uintptr_t>(is_right)) & 15) == 0;
