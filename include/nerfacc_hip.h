@@ -220,7 +220,11 @@ int nfa_fill_ray_indices(int64_t n_rays, const int64_t *packed_info /*[n_rays,2]
  *                           run records {t_first:f32 | k_start:31, continues_previous:1} in runs[max_runs][n_rays]
  *                           (slot-major), one per chain of continuous samples and at least one per 64 samples; rays
  *                           with more records are counted in *overflow_count and must be filled with
- *                           nfa_traverse_grids(mode 1, ray_filter = run_cnts, ray_filter_min = max_runs);
+ *                           nfa_traverse_grids(mode 1, ray_filter = run_cnts, ray_filter_min = max_runs).
+ *                           With traverse_steps_limit > 0 the lanes of a wave are not bound to one ray each: a wave owns a
+ *                           chunk of consecutive entries of the ray list and hands the next one to a lane whose ray is
+ *                           finished (limited walks end after a geometric number of cells; results are the same).
+ *                           Environment, for measurements: NFA_REFILL=0 (one ray per lane), NFA_REFILL=<chunk>,<min_busy>;
  *   nfa_expand_cone_runs    records + exclusive cumsum of the counts -> (t_starts, t_ends, ray_indices): every output
  *                           re-runs the serial recurrence t <- t + max(step, t * cone) from its record's t_first (at
  *                           most 63 steps), so the values are bit-identical to the marching loop's, and the second DDA
