@@ -232,6 +232,13 @@ int nfa_fill_ray_indices(int64_t n_rays, const int64_t *packed_info /*[n_rays,2]
 int nfa_traverse_cone_runs(const nfa_traverse_args *args, int32_t *run_cnts, uint64_t *runs, int32_t max_runs,
                            int32_t *overflow_count, const int32_t *ray_order /* as for nfa_traverse_runs, or NULL */,
                            int64_t n_order, nfa_stream_t stream);
+/* nfa_traverse_cone_runs over the 1-bit grid copy of nfa_pack_walk_bits (grids of at most 512 cells per axis, as for
+ * nfa_traverse_runs): the same outputs, bit for bit, with the constant-step walk's DDA (packed step counters, interleaved
+ * bit index, one 4-byte load per cell) -- about half the instructions per cell.  args->bricks is not read.
+ * (csrc/walk.hip: cone_walk_kernel, cone_refill_kernel; ref grid.cu:68-282.) */
+int nfa_traverse_cone_walk(const nfa_traverse_args *args, const uint32_t *bits, int32_t *run_cnts, uint64_t *runs,
+                           int32_t max_runs, int32_t *overflow_count, const int32_t *ray_order, int64_t n_order,
+                           nfa_stream_t stream);
 int nfa_expand_cone_runs(int64_t n_rays, float step_size, float cone_angle, const int32_t *run_cnts,
                          const uint64_t *runs, int32_t max_runs, const int64_t *packed_info, float *t_starts,
                          float *t_ends, int64_t *ray_indices, nfa_stream_t stream);

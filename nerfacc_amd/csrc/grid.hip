@@ -82,6 +82,12 @@ enum { EMIT_NONE = 0, EMIT_API = 1, EMIT_DIRECT = 2, EMIT_RUNS = 3 };
 // t * cone) from its first distance, so {t_first, k_start} determines every sample of it; chains are cut every
 // CONE_RUN_CAP samples so that the expansion (expand_runs_kernel<EXP_CONE>) iterates the recurrence at most that often
 // per output.  The second walk of the fill pass becomes a coalesced expansion.
+#ifndef NFA_REFILL_SPLIT
+#define NFA_REFILL_SPLIT 1
+#endif
+#ifndef NFA_TRAVERSE_SPLIT
+#define NFA_TRAVERSE_SPLIT 0
+#endif
 constexpr int CONE_RUN_CAP = 64;
 struct RunOut {
     int32_t *run_cnts;          // [n_rays]
@@ -170,7 +176,7 @@ __device__ __forceinline__ void span_begin(const nfa_traverse_args &a, const flo
 // the bottleneck).  Hence: one exit, flags in integer registers, selects instead of branches, and the brick word of the NEXT
 // cell requested before the current cell is marched (the DDA does not depend on the march), so that the load's latency
 // overlaps the march.
-template <int EMIT, bool HAS_IV, bool HAS_SM>
+template <int EMIT, bool HAS_IV, bool HAS_SM, bool SPLIT = false>
 __device__ __forceinline__ bool span_cell(const nfa_traverse_args &a, int64_t tid, int64_t iv_base, int64_t sm_base,
                                           SpanState &sp, RayState &st, const RunOut &ro)
 {
@@ -255,6 +261,36 @@ __device__ __forceinline__ bool span_cell(const nfa_traverse_args &a, int64_t ti
     if (step_size <= 0.0f) {  // one interval per occupied cell (grid.cu:155,198,212)
         if (occupied) emit(t_traverse);
         else { st.t_last = t_traverse; st.continuous = 0; }
+    } else if (SPLIT) {
+        // The same two marches for walks that spend their time in empty cells (limited walks): the empty cell's is
+        // straight-line code -- eight select steps cover a cell of the finest level at the smallest step, the loop behind
+        // them runs only for what is left (a step that makes no progress leaves t_last unchanged, the loop then sees it and
+        // the jump below applies, as in the merged loop) -- and the sampling loop runs only when some lane has an occupied cell.
+        float dt = calc_dt(st.t_last, cone, step_size);
+        if (!occupied) {
+            if (t_traverse - st.t_last > 8.0f * dt) st.t_last = fast_forward_exact(st.t_last, t_traverse, dt);
+            const float half = dt * 0.5f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float t_next = st.t_last + dt;
+                st.t_last = (st.t_last + half < t_traverse) ? t_next : st.t_last;
+            }
+            for (;;) {
+                const float t_next = st.t_last + dt;
+                if (!((st.t_last + half < t_traverse) && (t_next != st.t_last))) break;
+                st.t_last = t_next;
+            }
+            if (st.t_last + half < t_traverse) st.t_last = t_traverse;
+            st.continuous = 0;
+        } else {
+            for (;;) {
+                const float t_next = st.t_last + dt;
+                const bool budget = !(limit > 0 && st.n_samples >= limit);
+                if (!((st.t_last + dt * 0.5f < t_traverse) && (t_next != st.t_last) && budget)) break;
+                emit(t_next);
+                dt = calc_dt(t_next, cone, step_size);
+            }
+        }
     } else {
         // March to t_traverse.  An empty cell skips with the dt of its first step (grid.cu:193-206), an occupied
         // one emits with dt recomputed per sample (grid.cu:207-262): one loop, so that a wave whose lanes sit in
@@ -296,7 +332,7 @@ __device__ __forceinline__ void traverse_span(const nfa_traverse_args &a, int64_
     SpanState sp;
     span_begin(a, o, d, inv, level, this_tmin, this_tmax, st, sp);
     if (a.traverse_steps_limit > 0 && st.n_samples >= a.traverse_steps_limit) return;
-    while (!span_cell<EMIT, HAS_IV, HAS_SM>(a, tid, iv_base, sm_base, sp, st, ro)) {}
+    while (!span_cell<EMIT, HAS_IV, HAS_SM, EMIT == EMIT_RUNS && NFA_TRAVERSE_SPLIT != 0>(a, tid, iv_base, sm_base, sp, st, ro)) {}
 }
 
 // EMIT_NONE  : count pass (mode 0)
@@ -528,7 +564,7 @@ __global__ __launch_bounds__(256) void traverse_refill_kernel(const nfa_traverse
         const int32_t need = next < end ? min_busy : (n_walking * 3 >> 2) > 1 ? (n_walking * 3 >> 2) : 1;
         do {
             if (phase == WALK) {
-                if (span_cell<EMIT_RUNS, false, true>(a, tid, 0, 0, sp, st, ro))
+                if (span_cell<EMIT_RUNS, false, true, NFA_REFILL_SPLIT != 0>(a, tid, 0, 0, sp, st, ro))
                     phase = (limit > 0 && st.n_samples >= limit) ? FINISH : SPAN;  // budget spent: nothing after it changes the ray (see traverse_kernel)
             }
         } while (__popcll(__ballot(phase == WALK)) >= need);

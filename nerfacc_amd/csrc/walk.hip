@@ -371,7 +371,7 @@ struct WalkSpan {
 };
 
 // setup_traversal (include/utils_grid.cuh:58-114) in the reference's operation order
-__device__ __forceinline__ void walk_span_setup(const nfa_traverse_args &a, const WalkParams &p, const float o[3], const float d[3],
+__device__ __forceinline__ void walk_span_setup(const nfa_traverse_args &a, const WalkLayout &lay, const float o[3], const float d[3],
                                                 int32_t level, float this_tmin, float this_tmax, WalkSpan &sp)
 {
     const float eps = 1e-6f;
@@ -412,10 +412,10 @@ __device__ __forceinline__ void walk_span_setup(const nfa_traverse_args &a, cons
     sp.dx = delta[0]; sp.dy = delta[1]; sp.dz = delta[2];
     sp.rem = (uint32_t)(nst[0] - 1) | ((uint32_t)(nst[1] - 1) << 10) | ((uint32_t)(nst[2] - 1) << 20) | WK_GUARD;
     // an axis walked downwards counts its reflected coordinate (2^nb - 1 - c = c ^ (2^nb - 1)) upwards: every step is "+1"
-    uint32_t widx = 0u, flip = (uint32_t)level << p.lay.bits, mk[3];
+    uint32_t widx = 0u, flip = (uint32_t)level << lay.bits, mk[3];
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
-        const uint32_t M = p.lay.mask[ax];
+        const uint32_t M = lay.mask[ax];
         const uint32_t dep = bit_deposit((uint32_t)cur[ax], M);
         widx |= stepi[ax] < 0 ? (dep ^ M) : dep;
         flip |= stepi[ax] < 0 ? M : 0u;
@@ -582,7 +582,7 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
                 *reinterpret_cast<float *>(col + (kk << WK_LG)) = this_tmin;
                 *reinterpret_cast<float *>(col + ((kk + 1u) << WK_LG)) = this_tmax;
                 ev_span |= 1u << kk;
-                walk_span_setup(a, p, o, d, level, this_tmin, this_tmax, sp);
+                walk_span_setup(a, p.lay, o, d, level, this_tmin, this_tmax, sp);
                 const uint32_t idx0 = sp.widx ^ sp.flip;
                 w_cur = bits[idx0 >> 5]; i_cur = idx0;
                 open_type = (int32_t)((w_cur >> (idx0 & 31u)) & 1u);
@@ -652,6 +652,345 @@ NFA_WALK_OCC __global__ __launch_bounds__(WK_THREADS) void walk_kernel(const nfa
         if (s.n_samples > (1 << 21) && n_runs <= p.max_runs) n_runs = p.max_runs + 1;
         p.run_cnts[tid] = n_runs;
         if (n_runs > p.max_runs) atomicAdd(p.overflow, 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The cone-angle walk (step_size > 0 and cone_angle > 0; ref grid.cu:207-262 recomputes dt = max(step, t * cone) at every
+// sample and at every empty cell, so samples are no arithmetic runs and phase 2 above does not apply: the march is the
+// reference's loop).  The DDA is phase 1's -- boundary distances, the packed step counter, the interleaved bit index, one
+// 4-byte load per cell from the 1-bit grid copy requested a cell ahead -- instead of grid.hip's (brick index from three
+// coordinates, end test on three overflow indices, a brick word cached in registers): 104 -> ~45 vector instructions per
+// cell outside the march.  Output: the counts and run records of grid.hip's EMIT_RUNS pass (nfa_expand_cone_runs).
+struct ConeParams {
+    const uint32_t *bits;
+    WalkLayout lay;
+    int32_t *run_cnts;           // [n_rays]
+    unsigned long long *runs;    // [max_runs, n_rays] slot-major
+    int32_t max_runs;
+    int32_t *overflow;           // [1]
+    const int32_t *order;        // lane -> ray assignment or NULL
+    int64_t n_order;
+    int32_t chunk, min_busy;     // cone_refill_kernel: entries of the ray list per wave; lanes that keep the cell loop going
+};
+#ifndef NFA_CONE_WALK_SPLIT
+#define NFA_CONE_WALK_SPLIT 0
+#endif
+#ifndef NFA_CONE_REFILL_SPLIT
+#define NFA_CONE_REFILL_SPLIT 1
+#endif
+constexpr int CONE_WALK_RUN_CAP = 64;   // = grid.hip's CONE_RUN_CAP: the expansion iterates the recurrence at most this often
+struct ConeRay {
+    float t_last;
+    int32_t continuous, n_samples, n_runs, run_len;
+};
+
+// the span's first cell
+__device__ __forceinline__ void cone_span_begin(const nfa_traverse_args &a, const ConeParams &p, const float o[3], const float d[3],
+                                                int32_t level, float this_tmin, float this_tmax, ConeRay &st, WalkSpan &sp,
+                                                unsigned long long &w_cur, uint32_t &i_cur)
+{
+    if (!st.continuous) st.t_last = fast_forward(st.t_last, this_tmin, a.step_size, a.cone_angle);  // grid.cu:151-163
+    walk_span_setup(a, p.lay, o, d, level, this_tmin, this_tmax, sp);
+    i_cur = sp.widx ^ sp.flip;
+    w_cur = reinterpret_cast<const unsigned long long *>(p.bits)[i_cur >> 6];
+}
+
+// One cell (grid.cu:184-272); true when the span is over (the step left its last cell, or the sample budget is spent).
+template <bool SPLIT>
+__device__ __forceinline__ bool cone_cell(const nfa_traverse_args &a, const ConeParams &p, int64_t tid, float this_tmax, WalkSpan &sp,
+                                          unsigned long long &w_cur, uint32_t &i_cur, ConeRay &st)
+{
+    const float step_size = a.step_size, cone = a.cone_angle;
+    const int32_t limit = a.traverse_steps_limit;
+    const float n = vmin_f32(sp.ty, sp.tz);
+    const float m = vmin_f32(sp.tx, n);
+    const float t_traverse = vmin_f32(m, this_tmax);
+    const uint32_t w_half = (i_cur & 32u) ? (uint32_t)(w_cur >> 32) : (uint32_t)w_cur;
+    const bool occupied = __builtin_amdgcn_ubfe(w_half, i_cur, 1u) != 0u;   // bit (i_cur & 31) of the half
+    // single_traversal (include/utils_grid.cuh:116-142), as in walk_cell
+    const bool s0 = sp.tx < n;
+    const bool s1 = sp.ty < sp.tz;
+    const float dsel = s0 ? sp.dx : (s1 ? sp.dy : sp.dz);
+    const float nm = m + dsel;
+    const float ty1 = s1 ? nm : sp.ty, tz1 = s1 ? sp.tz : nm;
+    sp.tx = s0 ? nm : sp.tx;
+    sp.ty = s0 ? sp.ty : ty1;
+    sp.tz = s0 ? sp.tz : tz1;
+    sp.rem -= s0 ? 1u : (s1 ? (1u << 10) : (1u << 20));
+    const uint32_t M = s0 ? sp.mx : (s1 ? sp.my : sp.mz);
+    uint32_t filled;
+    asm("v_bfi_b32 %0, %1, %2, -1" : "=v"(filled) : "v"(M), "v"(sp.widx));
+    filled += M & 7u;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(sp.widx) : "v"(M), "v"(filled), "v"(sp.widx));
+    const bool done = (sp.rem & WK_GUARD) != WK_GUARD;
+    // The next cell's bit: the low six index bits are two of each coordinate, so an aligned 64-bit word of the copy is a
+    // 4 x 4 x 4 brick; it stays in registers while the ray is inside it (with unrelated rays every load of a wave is 64
+    // cache lines: one load per cell instead of one per brick cost the unlimited walk of cfg 5 2 ms of 12) and the load,
+    // when there is one, is taken in after the march, whose instructions hide its latency.
+    const uint32_t i_next = sp.widx ^ sp.flip;
+    const bool fetch = !done && ((i_next ^ i_cur) >> 6) != 0u;
+    unsigned long long w_next = 0ull;
+    if (fetch) w_next = reinterpret_cast<const unsigned long long *>(p.bits)[i_next >> 6];
+
+    // one sample [t_last, t_next) (grid.cu:219-258): counted, and a run record at the head of a chain and every 64 samples
+    auto emit = [&](float t_next) {
+        const bool cut = !st.continuous || st.run_len == CONE_WALK_RUN_CAP;
+        if (cut) {
+            if (st.n_runs < p.max_runs)
+                p.runs[(int64_t)st.n_runs * a.n_rays + tid] =
+                    (unsigned long long)f32_bits(st.t_last) |
+                    ((unsigned long long)((uint32_t)st.n_samples | (st.continuous ? 0x80000000u : 0u)) << 32);
+            st.n_runs++;
+        }
+        st.run_len = cut ? 1 : st.run_len + 1;
+        st.n_samples++;
+        st.continuous = 1;
+        st.t_last = t_next;
+    };
+    // March to t_traverse.  An empty cell skips with the dt of its first step (grid.cu:193-206), an occupied one emits with
+    // dt recomputed per sample (grid.cu:207-262): one loop, so that a wave whose lanes sit in cells of both kinds runs it once.
+    float dt = calc_dt(st.t_last, cone, step_size);
+    if (SPLIT) {
+        // The same two marches for walks that spend their time in empty cells (limited walks).  The empty cell's is
+        // straight-line code: eight select steps cover a cell of the finest level at the smallest step, the loop behind them
+        // runs only for what is left (a step without progress leaves t_last unchanged; the loop then sees it and the jump
+        // applies, as in the merged loop); the sampling loop runs only when some lane of the wave has an occupied cell.
+        if (!occupied) {
+            if (t_traverse - st.t_last > 8.0f * dt) st.t_last = fast_forward_exact(st.t_last, t_traverse, dt);
+            const float half = dt * 0.5f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float t_next = st.t_last + dt;
+                st.t_last = (st.t_last + half < t_traverse) ? t_next : st.t_last;
+            }
+            for (;;) {
+                const float t_next = st.t_last + dt;
+                if (!((st.t_last + half < t_traverse) && (t_next != st.t_last))) break;
+                st.t_last = t_next;
+            }
+            if (st.t_last + half < t_traverse) st.t_last = t_traverse;
+            st.continuous = 0;
+        } else {
+            for (;;) {
+                const float t_next = st.t_last + dt;
+                const bool budget = !(limit > 0 && st.n_samples >= limit);
+                if (!((st.t_last + dt * 0.5f < t_traverse) && (t_next != st.t_last) && budget)) break;
+                emit(t_next);
+                dt = calc_dt(t_next, cone, step_size);
+            }
+        }
+    } else {
+        // a skip of many steps (cell much larger than the step): closed form (march.h), same result as the loop
+        if (!occupied && t_traverse - st.t_last > 8.0f * dt) st.t_last = fast_forward_exact(st.t_last, t_traverse, dt);
+        for (;;) {
+            const float t_next = st.t_last + dt;
+            const bool budget = !(occupied && limit > 0 && st.n_samples >= limit);
+            if (!((st.t_last + dt * 0.5f < t_traverse) && (t_next != st.t_last) && budget)) break;
+            if (occupied) {
+                emit(t_next);
+                dt = calc_dt(t_next, cone, step_size);
+            } else {
+                st.t_last = t_next;
+            }
+        }
+        if (!occupied) {
+            // left the loop before the target without progress (ours: the reference would spin): jump there
+            if (st.t_last + dt * 0.5f < t_traverse) st.t_last = t_traverse;
+            st.continuous = 0;
+        }
+    }
+    i_cur = i_next;
+    w_cur = fetch ? w_next : w_cur;
+    return done || (limit > 0 && st.n_samples >= limit);
+}
+
+// The ray's next span from its event list (grid.cu:125-150), or from the in-kernel slab test (FUSED: one grid).  `ev`: the
+// next event to look at (FUSED: 0 = the span not taken yet).
+template <bool FUSED>
+__device__ __forceinline__ bool cone_next_span(const nfa_traverse_args &a, const ConeParams &p, int64_t tid, const float o[3],
+                                               const float d[3], float near_plane, float far_plane, int32_t &ev, ConeRay &st,
+                                               WalkSpan &sp, float &span_tmax, unsigned long long &w_cur, uint32_t &i_cur)
+{
+    const int32_t G = a.n_grids;
+    if (FUSED) {
+        if (ev != 0) return false;
+        ev = 1;
+        const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
+        float tmin, tmax, lo, hi;
+        bool hit = true;
+        const float *bmin = a.aabbs, *bmax = a.aabbs + 3;
+        if (inv[0] >= 0) { tmin = (bmin[0] - o[0]) * inv[0]; tmax = (bmax[0] - o[0]) * inv[0]; }
+        else             { tmin = (bmax[0] - o[0]) * inv[0]; tmax = (bmin[0] - o[0]) * inv[0]; }
+#pragma unroll
+        for (int ax = 1; ax < 3; ++ax) {
+            if (inv[ax] >= 0) { lo = (bmin[ax] - o[ax]) * inv[ax]; hi = (bmax[ax] - o[ax]) * inv[ax]; }
+            else              { lo = (bmax[ax] - o[ax]) * inv[ax]; hi = (bmin[ax] - o[ax]) * inv[ax]; }
+            if (tmin > hi || lo > tmax) hit = false;
+            if (lo > tmin) tmin = lo;
+            if (hi < tmax) tmax = hi;
+        }
+        if (tmax <= 0) hit = false;
+        const float this_tmin = fmaxf(tmin, near_plane), this_tmax = fminf(tmax, far_plane);
+        if (!(hit && this_tmin < this_tmax)) return false;
+        span_tmax = this_tmax;
+        cone_span_begin(a, p, o, d, 0, this_tmin, this_tmax, st, sp, w_cur, i_cur);
+        return true;
+    } else {
+        const uint8_t *hits = a.hits + tid * G;
+        const float *ts = a.t_sorted + tid * 2 * G;
+        const int64_t *ti = a.t_indices + tid * 2 * G;
+        while (ev < 2 * G - 1) {
+            const int32_t i = ev++;
+            const int64_t idx = ti[i];
+            int32_t level = (int32_t)(idx % G);
+            bool ok = hits[level] != 0;
+            if (ok && idx >= G) {  // leaving: inside the next grid?
+                const int64_t nidx = ti[i + 1];
+                level = (int32_t)(nidx % G);
+                ok = nidx >= G && hits[level] != 0;
+            }
+            const float this_tmin = fmaxf(ts[i], near_plane);
+            const float this_tmax = fminf(ts[i + 1], far_plane);
+            if (ok && this_tmin < this_tmax) {
+                span_tmax = this_tmax;
+                cone_span_begin(a, p, o, d, level, this_tmin, this_tmax, st, sp, w_cur, i_cur);
+                return true;
+            }
+        }
+        return false;
+    }
+}
+
+__device__ __forceinline__ void cone_ray_out(const nfa_traverse_args &a, const ConeParams &p, int64_t tid, const ConeRay &st)
+{
+    if (a.terminate_planes) a.terminate_planes[tid] = st.t_last;
+    a.sm_cnts[tid] = st.n_samples;
+    // rays with > 2^21 samples go to the serial fill (the expansion packs a 27-bit batch offset)
+    int32_t n_runs = st.n_runs;
+    if (st.n_samples > (1 << 21) && n_runs <= p.max_runs) n_runs = p.max_runs + 1;
+    p.run_cnts[tid] = n_runs;
+    if (n_runs > p.max_runs) atomicAdd(p.overflow, 1);
+}
+
+// a ray masked out by rays_mask (grid.cu:100; the reference leaves its outputs uninitialised, we define them)
+__device__ __forceinline__ bool cone_ray_masked(const nfa_traverse_args &a, const ConeParams &p, int64_t tid)
+{
+    if (!(a.mode == 2 && a.rays_mask != nullptr && !a.rays_mask[tid])) return false;
+    if (a.terminate_planes) a.terminate_planes[tid] = a.near_planes[tid];
+    a.sm_cnts[tid] = 0;
+    p.run_cnts[tid] = 0;
+    return true;
+}
+
+// one ray per lane, from its first span to its last
+template <bool FUSED>
+__global__ __launch_bounds__(256) void cone_walk_kernel(const nfa_traverse_args a, const ConeParams p)
+{
+    const int64_t n_walk = p.order ? p.n_order : a.n_rays;
+    const int32_t limit = a.traverse_steps_limit;
+    for (int64_t slot_i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; slot_i < n_walk;
+         slot_i += (int64_t)blockDim.x * gridDim.x) {
+        const int64_t tid = p.order ? (int64_t)p.order[slot_i] : slot_i;
+        if (cone_ray_masked(a, p, tid)) continue;
+        const float near_plane = a.near_planes[tid], far_plane = a.far_planes[tid];
+        const float o[3] = {a.rays_o[3 * tid], a.rays_o[3 * tid + 1], a.rays_o[3 * tid + 2]};
+        const float d[3] = {a.rays_d[3 * tid], a.rays_d[3 * tid + 1], a.rays_d[3 * tid + 2]};
+        ConeRay st;
+        st.t_last = near_plane; st.continuous = 0; st.n_samples = 0; st.n_runs = 0; st.run_len = 0;
+        // (a ray with a non-finite origin or direction has no geometry: no samples, see grid.hip's traverse_kernel)
+        const bool ray_ok = isfinite(o[0]) && isfinite(o[1]) && isfinite(o[2]) && isfinite(d[0]) && isfinite(d[1]) && isfinite(d[2]);
+        int32_t ev = ray_ok ? 0 : 2 * a.n_grids;
+        WalkSpan sp;
+        float span_tmax = 0.f;
+        unsigned long long w_cur = 0ull;
+        uint32_t i_cur = 0u;
+        while (cone_next_span<FUSED>(a, p, tid, o, d, near_plane, far_plane, ev, st, sp, span_tmax, w_cur, i_cur)) {
+            while (!cone_cell<NFA_CONE_WALK_SPLIT != 0>(a, p, tid, span_tmax, sp, w_cur, i_cur, st)) {}
+            // The budget is spent: the last thing that happened was a sample (continuous), so the spans still to come would
+            // change nothing (grid.cu:151,185: no fast-forward, no cell visited).
+            if (limit > 0 && st.n_samples >= limit) break;
+        }
+        cone_ray_out(a, p, tid, st);
+    }
+}
+
+// Limited walks (traverse_steps_limit > 0: one iteration of the test-mode loop, examples/utils.py:252-425) stop after a
+// handful of samples, i.e. after a number of cells that is geometric in the local occupancy; with one ray per lane a wave
+// lasts as long as its unluckiest ray (cfg 5, 2 % scattered occupancy: 50 cells to the first sample on average, ~240 for
+// the worst of 64 lanes, lanes busy a fifth of the time).  Here a wave owns `chunk` consecutive entries of the ray list
+// and a lane that has finished its ray is given the next one: the wave leaves its cell loop when fewer than `min_busy`
+// lanes are still walking, sets up new rays (and the next spans of rays that crossed into another level) on the free
+// lanes, and re-enters.  Per ray the same functions as cone_walk_kernel: identical results.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void cone_refill_kernel(const nfa_traverse_args a, const ConeParams p)
+{
+    enum { IDLE = 0, SPAN = 1, WALK = 2, FINISH = 3 };
+    const int lane = lane_id();
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    const int64_t n_walk = p.order ? p.n_order : a.n_rays;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int64_t next = wave * p.chunk;  // (wave-uniform) first entry not handed out yet
+    const int64_t end = next + p.chunk < n_walk ? next + p.chunk : n_walk;
+    const int32_t limit = a.traverse_steps_limit;
+
+    int32_t phase = IDLE, ev = 0;
+    int64_t tid = 0;
+    float near_plane = 0.0f, far_plane = 0.0f, span_tmax = 0.0f;
+    float o[3] = {0.0f, 0.0f, 0.0f}, d[3] = {0.0f, 0.0f, 0.0f};
+    ConeRay st;
+    st.t_last = 0.0f; st.continuous = 0; st.n_samples = 0; st.n_runs = 0; st.run_len = 0;
+    WalkSpan sp;
+    sp.tx = sp.ty = sp.tz = sp.dx = sp.dy = sp.dz = 0.f; sp.mx = sp.my = sp.mz = 0u; sp.rem = 0u; sp.widx = 0u; sp.flip = 0u;
+    unsigned long long w_cur = 0ull;
+    uint32_t i_cur = 0u;
+
+    for (;;) {
+        // Two passes: rays that left a span in the cell loop (their next span, or their end), then the rays handed to the
+        // lanes that are free after that.
+#pragma nounroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (phase == SPAN)
+                phase = cone_next_span<FUSED>(a, p, tid, o, d, near_plane, far_plane, ev, st, sp, span_tmax, w_cur, i_cur) ? WALK : FINISH;
+            if (phase == FINISH) {
+                cone_ray_out(a, p, tid, st);
+                phase = IDLE;
+            }
+            if (pass == 1) break;
+            const unsigned long long idle = __ballot(phase == IDLE);
+            if (idle != 0ull && next < end) {
+                if (phase == IDLE) {
+                    const int64_t slot = next + __popcll(idle & lanes_below);
+                    if (slot < end) {
+                        tid = p.order ? (int64_t)p.order[slot] : slot;
+                        if (!cone_ray_masked(a, p, tid)) {
+                            near_plane = a.near_planes[tid]; far_plane = a.far_planes[tid];
+#pragma unroll
+                            for (int ax = 0; ax < 3; ++ax) { o[ax] = a.rays_o[3 * tid + ax]; d[ax] = a.rays_d[3 * tid + ax]; }
+                            st.t_last = near_plane; st.continuous = 0; st.n_samples = 0; st.n_runs = 0; st.run_len = 0;
+                            const bool ray_ok = isfinite(o[0]) && isfinite(o[1]) && isfinite(o[2]) && isfinite(d[0]) && isfinite(d[1]) && isfinite(d[2]);
+                            ev = ray_ok ? 0 : 2 * a.n_grids;
+                            phase = SPAN;
+                        }
+                    }
+                }
+                next += __popcll(idle);
+            }
+        }
+        const unsigned long long walking = __ballot(phase == WALK);
+        if (walking == 0ull) {
+            if (next >= end) break;  // (every lane is IDLE here: SPAN and FINISH were resolved above)
+            continue;
+        }
+        // ---- cells, for as long as enough lanes have one to visit
+        const int32_t n_walking = __popcll(walking);
+        const int32_t need = next < end ? p.min_busy : (n_walking * 3 >> 2) > 1 ? (n_walking * 3 >> 2) : 1;
+        do {
+            if (phase == WALK) {
+                if (cone_cell<NFA_CONE_REFILL_SPLIT != 0>(a, p, tid, span_tmax, sp, w_cur, i_cur, st))
+                    phase = (limit > 0 && st.n_samples >= limit) ? FINISH : SPAN;  // budget spent: nothing after it changes the ray
+            }
+        } while (__popcll(__ballot(phase == WALK)) >= need);
     }
 }
 
@@ -1133,6 +1472,63 @@ int nfa_traverse_runs(const nfa_traverse_args *pa, const uint32_t *bits, int32_t
     else if (!lim)          hipLaunchKernelGGL((walk_kernel<false, false>), dim3(grid), dim3(WK_THREADS), shmem, s, a, p);
     else                    hipLaunchKernelGGL((walk_kernel<false, true>), dim3(grid), dim3(WK_THREADS), shmem, s, a, p);
     NFA_CHECK_LAUNCH("traverse_runs");
+    return NFA_OK;
+}
+
+int nfa_traverse_cone_walk(const nfa_traverse_args *pa, const uint32_t *bits, int32_t *run_cnts, uint64_t *runs, int32_t max_runs,
+                           int32_t *overflow_count, const int32_t *ray_order, int64_t n_order, nfa_stream_t stream)
+{
+    NFA_REQUIRE(pa != nullptr, "traverse_cone_walk: null args");
+    const nfa_traverse_args &a = *pa;
+    NFA_REQUIRE(a.n_rays >= 0 && a.n_rays < (int64_t)1 << 31, "traverse_cone_walk: n_rays out of range");
+    NFA_REQUIRE(overflow_count, "traverse_cone_walk: overflow_count is null");
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(overflow_count, 0, sizeof(int32_t), s) != hipSuccess) { set_error("traverse_cone_walk: memset failed"); return NFA_EHIP; }
+    if (a.n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(a.step_size > 0.0f && a.cone_angle > 0.0f, "traverse_cone_walk: needs step_size > 0 and cone_angle > 0");
+    NFA_REQUIRE(a.mode == 0 || a.mode == 2, "traverse_cone_walk: mode must be 0 (all rays) or 2 (rays_mask + traverse_steps_limit)");
+    NFA_REQUIRE(a.mode != 2 || a.traverse_steps_limit > 0, "traverse_steps_limit must be > 0 when over_allocate is true");
+    NFA_REQUIRE(a.rays_o && a.rays_d && a.aabbs && a.near_planes && a.far_planes && a.sm_cnts && !a.iv_cnts && bits && run_cnts && runs,
+                "traverse_cone_walk: null pointer (or interval outputs requested)");
+    NFA_REQUIRE(max_runs >= 1 && max_runs <= 32, "traverse_cone_walk: max_runs must be in [1, 32]");
+    NFA_REQUIRE(a.n_grids >= 1 && a.res[0] > 0 && a.res[1] > 0 && a.res[2] > 0, "traverse_cone_walk: bad grid shape");
+    NFA_REQUIRE(a.res[0] <= WK_MAX_RES && a.res[1] <= WK_MAX_RES && a.res[2] <= WK_MAX_RES,
+                "traverse_cone_walk: at most 512 cells per axis (use nfa_traverse_cone_runs beyond)");
+    const bool fused = !a.t_sorted && !a.t_indices && !a.hits;
+    NFA_REQUIRE(fused || (a.t_sorted && a.t_indices && a.hits), "traverse_cone_walk: t_sorted, t_indices and hits must be given together");
+    NFA_REQUIRE(!fused || a.n_grids == 1, "traverse_cone_walk: in-kernel intersection supports one grid");
+    ConeParams p;
+    p.bits = bits;
+    p.lay = walk_layout(a.res);
+    NFA_REQUIRE(p.lay.bits >= 6 && ((int64_t)a.n_grids << p.lay.bits) < ((int64_t)1 << 31),
+                "traverse_cone_walk: a level of the grid copy must be a whole number of 64-bit words (at least 4 cells per axis) and the copy below 2^31 bits");
+    p.run_cnts = run_cnts;
+    p.runs = reinterpret_cast<unsigned long long *>(runs);
+    p.max_runs = max_runs;
+    p.overflow = overflow_count;
+    p.order = ray_order;
+    p.n_order = ray_order ? n_order : a.n_rays;
+    NFA_REQUIRE(!ray_order || (n_order >= 0 && n_order <= a.n_rays), "traverse_cone_walk: n_order out of range");
+    if (ray_order && n_order == 0) return NFA_OK;
+    const char *refill_env = getenv("NFA_REFILL");  // "0": one ray per lane also for limited walks; "chunk,min_busy": tuning
+    if (a.traverse_steps_limit > 0 && !(refill_env && refill_env[0] == '0')) {
+        // entries per wave: enough of them that a lane is refilled several times, as long as the launch still fills the chip
+        int64_t chunk = ((p.n_order + 4095) / 4096 + 63) / 64 * 64;
+        chunk = chunk < 64 ? 64 : (chunk > 1024 ? 1024 : chunk);
+        int min_busy = 48;
+        if (refill_env) { long c = 0; int m = 0; if (sscanf(refill_env, "%ld,%d", &c, &m) == 2 && c >= 64 && m >= 1 && m <= 64) { chunk = c / 64 * 64; min_busy = m; } }
+        p.chunk = (int32_t)chunk; p.min_busy = min_busy;
+        const int64_t n_waves = (p.n_order + chunk - 1) / chunk;
+        const unsigned grid = (unsigned)((n_waves + 3) / 4);
+        if (fused) hipLaunchKernelGGL((cone_refill_kernel<true>), dim3(grid), dim3(256), 0, s, a, p);
+        else       hipLaunchKernelGGL((cone_refill_kernel<false>), dim3(grid), dim3(256), 0, s, a, p);
+    } else {
+        p.chunk = 64; p.min_busy = 64;
+        const unsigned grid = grid_1d(p.n_order, 256, 1 << 20);
+        if (fused) hipLaunchKernelGGL((cone_walk_kernel<true>), dim3(grid), dim3(256), 0, s, a, p);
+        else       hipLaunchKernelGGL((cone_walk_kernel<false>), dim3(grid), dim3(256), 0, s, a, p);
+    }
+    NFA_CHECK_LAUNCH("traverse_cone_walk");
     return NFA_OK;
 }
 

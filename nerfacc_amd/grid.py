@@ -419,6 +419,7 @@ def _traverse_onepass(dev, rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted,
 
 
 CONE_RUNS = os.environ.get("NERFACC_AMD_CONE_RUNS", "1") != "0"   # 0: the serial count + fill passes (A/B testing)
+CONE_WALK = os.environ.get("NERFACC_AMD_CONE_WALK", "1") != "0"   # 0: the count pass over the brick-packed grid (grid.hip) instead of walk.hip's DDA (A/B testing)
 CONE_BIN_THRESHOLD = 1.25   # cone-angle walk: bin the rays when a wave of 64 neighbours crosses this many times its mean ray's cells
 
 
@@ -518,8 +519,13 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
                        float(near_hint) if near_hint is not None else 0.0, B.ptr(order), B.ptr(scratch), B.ptr(meta[4:6]), B.stream())
                 if not binned and not (stats_sink is not None and stats_sink.get("cells_max_over_mean", 1.0) > CONE_BIN_THRESHOLD):
                     order = None
-            B.call("nfa_traverse_cone_runs", C.byref(a), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS, B.ptr(meta[3:4]), B.ptr(order),
-                   0 if order is None else order.numel(), B.stream())
+            if CONE_WALK and _walk_supported(binaries) and min(binaries.shape[1:]) >= 4:
+                # the constant-step walk's DDA over the 1-bit grid copy (csrc/walk.hip: cone_walk_kernel / cone_refill_kernel)
+                B.call("nfa_traverse_cone_walk", C.byref(a), B.ptr(_get_walk_bits(binaries)), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
+                       B.ptr(meta[3:4]), B.ptr(order), 0 if order is None else order.numel(), B.stream())
+            else:
+                B.call("nfa_traverse_cone_runs", C.byref(a), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS, B.ptr(meta[3:4]), B.ptr(order),
+                       0 if order is None else order.numel(), B.stream())
         else:
             _launch(a)
         packed_info = _cumsum_packed(sm_cnts, meta[0:3], stats=True)
