@@ -33,6 +33,70 @@ def test_native_library_is_loaded(dev):
     assert "libnerfacc_hip.so" in maps
 
 
+# ----------------------------------------------------------------------------- cone-angle walk: its three kernels agree
+def test_cone_walk_forms_agree_and_match_oracle(dev, oracle):
+    """Distance-dependent steps: the count pass exists over the brick-packed grid (grid.hip: traverse_kernel<EMIT_RUNS>, one ray
+    per lane; traverse_refill_kernel for limited walks) and over the 1-bit grid copy (walk.hip: cone_walk_kernel,
+    cone_refill_kernel).  Every form must produce the same samples, counts and termination planes, bit for bit -- and the
+    oracle's: nested levels, one level with the in-kernel slab test, masks, step limits from 1 to 40, a wide and a narrow cone,
+    resolutions that are not multiples of 4, rays with zero direction components and rays that miss."""
+    rng = np.random.default_rng(77)
+    cases = [  # (levels, res, occupancy, n_rays, step, cone, limit, masked, inside)
+        (3, (32, 32, 32), 0.15, 20_000, 6e-3, 0.01, None, False, True),
+        (3, (32, 32, 32), 0.03, 20_000, 6e-3, 0.004, 4, True, True),
+        (1, (48, 40, 30), 0.05, 9_000, 4e-3, 0.02, 1, True, False),
+        (1, (64, 64, 64), 0.5, 5_000, 3e-3, 0.003, None, False, False),
+        (4, (16, 16, 16), 0.02, 30_000, 1e-2, 0.004, 7, True, True),
+        (2, (50, 24, 30), 0.3, 3_000, 5e-3, 0.05, 40, False, True),
+    ]
+    saved = (na.grid.CONE_WALK, os.environ.get("NFA_REFILL"))
+    try:
+        for levels, res, occ, R, step, cone, limit, masked, inside in cases:
+            est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=list(res), levels=levels).to(dev)
+            b = rng.random((levels, *res)) < occ
+            o = (rng.random((R, 3)).astype(np.float32) - 0.5) * (1.0 if inside else 4.0)
+            d = rng.standard_normal((R, 3)).astype(np.float32)
+            d[rng.random(R) < 0.05, int(rng.integers(0, 3))] = 0.0
+            d /= np.maximum(np.linalg.norm(d, axis=-1, keepdims=True), 1e-6)
+            near = np.full(R, 0.05, np.float32); far = np.full(R, 1e10, np.float32)
+            mask = (rng.random(R) < 0.6) if masked else None
+            kw = dict(rays_mask=None if mask is None else T(mask, dev), traverse_steps_limit=limit, return_terminate=True,
+                      near_hint=0.05)
+            args = (T(o, dev), T(d, dev), T(b, dev), est.aabbs, T(near, dev), T(far, dev), step, cone)
+            outs = {}
+            for form, (walk, refill) in {"walk": (True, None), "walk, one ray per lane": (True, "0"), "bricks": (False, None),
+                                         "bricks, one ray per lane": (False, "0"), "walk, small chunks": (True, "64,40")}.items():
+                na.grid.CONE_WALK = walk
+                if refill is None:
+                    os.environ.pop("NFA_REFILL", None)
+                else:
+                    os.environ["NFA_REFILL"] = refill
+                outs[form] = na.grid._traverse_samples(*args, **kw)
+            ref = outs["walk"]
+            assert ref[0].numel() > 500, (levels, res, ref[0].numel())
+            for form, got in outs.items():
+                assert all(torch.equal(x, y) for x, y in zip(ref, got)), (form, levels, res, limit)
+            # ... and the oracle's samples
+            ab = est.aabbs.cpu().numpy()
+            if limit is None:
+                riv, rsm, _ = oracle.traverse_grids(o, d, b, ab, near_planes=near, far_planes=far, step_size=step, cone_angle=cone)
+                keep = np.ones(rsm["ray_indices"].shape[0], bool)
+            else:
+                riv, rsm, _ = oracle.traverse_grids(o, d, b, ab, near_planes=near, far_planes=far, step_size=step, cone_angle=cone,
+                                                    traverse_steps_limit=limit, over_allocate=True,
+                                                    rays_mask=mask if mask is not None else np.ones(R, bool))
+                keep = rsm["is_valid"]
+            L, Rr = riv["vals"][riv["is_left"]], riv["vals"][riv["is_right"]]
+            assert (ref[0].cpu().numpy() == rsm["ray_indices"][keep]).all()
+            assert (ref[1].cpu().numpy() == L).all() and (ref[2].cpu().numpy() == Rr).all()
+    finally:
+        na.grid.CONE_WALK = saved[0]
+        if saved[1] is None:
+            os.environ.pop("NFA_REFILL", None)
+        else:
+            os.environ["NFA_REFILL"] = saved[1]
+
+
 # ----------------------------------------------------------------------------- pack / scans
 def test_binned_ray_assignment_same_results(dev):
     """estimator.bin_rays: the lane -> ray assignment of the walk is a permutation sorted by path length; every output
