@@ -503,6 +503,52 @@ def _cfg3_cpu_baseline(R=1 << 17, min_seconds=4.0):
                        f"numpy (one thread) for the elementwise s -> t map, densities and transmittance")
 
 
+def extra_cfg2_testmode(dev, args, n_img=3, parity=True):
+    """The a12 test-mode loop (render_rays_test_mode; ref examples/utils.py:252-425) on the headline scene: one 1024 x 1024
+    image through the 128^3 grid, constant step (cone_angle 0: one sample per alive ray and iteration to begin with), max_samples
+    1024, early_stop_eps 1e-4 -- the synthetic-scene regime; cfg 5 carries the unbounded-scene one.  Parity: a 2048-ray
+    subset (its own image: the schedule depends on the ray count) against oracle.test_mode_loop."""
+    from nerfacc_amd.marching import render_rays_test_mode
+    w = make_workload(dev, args.rays, args.res, args.grid, "image", 0, args.field)
+    est, step = w["estimator"], w["step"]
+    kw = dict(render_step_size=step, early_stop_eps=1e-4)
+    with torch.no_grad():
+        render_rays_test_mode(1024, w["rgb_sigma_fn"], est, w["rays_o"], w["rays_d"], **kw)            # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_img):
+            rgb, opa, dep, total = render_rays_test_mode(1024, w["rgb_sigma_fn"], est, w["rays_o"], w["rays_d"], **kw)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n_img
+    R = w["n_rays"]
+    out = {"workload": f"render_rays_test_mode, cfg 2's scene: {R} image rays, {args.res}^3 {args.grid}, step {step:.6f}, cone 0, "
+                       f"max_samples 1024, early_stop_eps 1e-4",
+           "ms_per_image": dt * 1e3, "rays_per_s": R / dt, "total_samples": int(total)}
+    if parity:
+        try:
+            from oracle import oracle as O
+            O.build()
+            o, d = w["rays_np"]
+            sub = np.arange(0, R, R // 2048)[:2048]
+            o2, d2 = np.ascontiguousarray(o[sub]), np.ascontiguousarray(d[sub])
+            with torch.no_grad():
+                g_rgb, g_opa, g_dep, g_total = render_rays_test_mode(1024, w["rgb_sigma_fn"], est, torch.from_numpy(o2).to(dev),
+                                                                     torch.from_numpy(d2).to(dev), **kw)
+            ss = np.float32(w["sigma_scale"])
+            field_np = lambda ts, te, ri: (np.repeat(ts[:, None], 3, 1).astype(np.float32),
+                                           (ss * (4.0 * (0.5 + 0.5 * np.sin(20.0 * (ts + te))))).astype(np.float32))
+            orgb, oopa, odep, ototal, tinfo = O.test_mode_loop(1024, field_np, o2, d2, w["binaries_np"], est.aabbs.cpu().numpy(), **kw)
+            e_rgb = float(np.abs(g_rgb.cpu().numpy() - orgb).max()); e_opa = float(np.abs(g_opa.cpu().numpy() - oopa).max())
+            guarded = int(tinfo["guard_rays"].sum())
+            ok = (g_total == ototal or guarded > 0) and e_rgb <= 2e-5 * max(1.0, float(np.abs(orgb).max())) and e_opa <= 2e-5
+            out["parity"] = {"checked": bool(ok), "rays": int(sub.size), "total_samples": int(g_total), "oracle_total_samples": int(ototal),
+                             "rays_on_the_termination_threshold": guarded, "rgb_max_abs_err": e_rgb, "opacity_max_abs_err": e_opa,
+                             "iterations": int(tinfo["iterations"])}
+        except Exception as e:  # the check must never cost the timing
+            out["parity_error"] = repr(e)
+    return out
+
+
 def extra_cfg3(dev, R, steps, field="native", cpu_base=True):
     """BASELINE cfg 3: PropNetEstimator, 2 proposal levels 64 -> 64 -> 16, uniform, fwd + proposal-loss backward."""
     import nerfacc_amd as na
@@ -792,7 +838,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the second (software-pipelined) timed loop")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary configurations (cfg2 variants, cfg3, cfg5)")
-    ap.add_argument("--only", default="", choices=["", "cfg2_compacting", "cfg2_random", "cfg3", "cfg5", "cfg5_testmode"],
+    ap.add_argument("--only", default="", choices=["", "cfg2_compacting", "cfg2_random", "cfg2_testmode", "cfg3", "cfg5", "cfg5_testmode"],
                     help="run ONE secondary configuration alone and print its object (for rocprofv3 passes: profiles/<round>_<cfg>_*)")
     args = ap.parse_args()
 
@@ -816,6 +862,7 @@ def main():
         fn = {"cfg2_compacting": lambda: extra_cfg2_variant(dev, args, sigma_scale=16.0),
               "cfg2_random": lambda: extra_cfg2_variant(dev, args, rays="random"),
               "cfg3": lambda: extra_cfg3(dev, 1 << 20, max(3, args.steps // 4), args.field),
+              "cfg2_testmode": lambda: extra_cfg2_testmode(dev, args, n_img=max(2, args.steps // 4)),
               "cfg5": lambda: extra_cfg5(dev, 1 << 21, max(2, args.steps // 6)),
               "cfg5_testmode": lambda: extra_cfg5(dev, 1 << 21, max(2, args.steps // 6), train=False)}[args.only]
         print(json.dumps({args.only: fn()}))
@@ -1020,6 +1067,7 @@ def main():
             w.pop("last", None)
             for key, fn in (("cfg2_compacting", lambda: extra_cfg2_variant(dev, args, sigma_scale=16.0)),
                             ("cfg2_random", lambda: extra_cfg2_variant(dev, args, rays="random")),
+                            ("cfg2_testmode", lambda: extra_cfg2_testmode(dev, args)),
                             ("cfg3", lambda: extra_cfg3(dev, 1 << 20, 5, args.field)),
                             ("cfg5", lambda: extra_cfg5(dev, 1 << 21, 3))):
                 try:
