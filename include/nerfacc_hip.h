@@ -402,7 +402,10 @@ int nfa_render_fused_bwd(const float *t_starts, const float *t_ends, const float
  * densities with prefix_trans = 1 - opacities[ray], samples with alpha < alpha_thre dropped (alpha_thre <= 0:
  * none), and colors[r,3] / opacities[r] / depths[r] accumulated in place (+=).  Deterministic (a ray is owned by
  * one wave); replaces render_weight_from_density + boolean masks + 3 accumulate_along_rays_ launches.
- * *n_visible (may be NULL) += number of samples that passed the threshold (the loop's running sample count). */
+ * n_visible (may be NULL): NFA_VISIBLE_SLOTS counters, zeroed by the caller before the first iteration; their sum is the number
+ * of samples that passed the threshold so far (the loop's running sample count; one counter would serialise the launch on
+ * its address). */
+#define NFA_VISIBLE_SLOTS 1024
 int nfa_render_step_accumulate(const float *t_starts, const float *t_ends, const float *sigmas, const float *rgbs,
                                const int64_t *packed_info, const int64_t *tiles, int64_t n_tiles, int64_t n_rays,
                                int64_t n_elems, float alpha_thre, float *colors, float *opacities, float *depths,

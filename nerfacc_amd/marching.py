@@ -31,6 +31,9 @@ from .grid import _traverse_samples, ray_aabb_intersect
 from .volrend import accumulate_along_rays_, render_weight_from_density
 
 
+_VISIBLE_SLOTS = 1024  # include/nerfacc_hip.h: NFA_VISIBLE_SLOTS
+
+
 def _render_step_native(seg, t_starts, t_ends, sigmas, rgbs, alpha_thre, rgb, opacity, depth, n_visible) -> None:
     dev = B.require_device(t_starts, t_ends, sigmas, rgbs, rgb, opacity, depth)
     assert rgb.is_contiguous() and opacity.is_contiguous() and depth.is_contiguous()
@@ -100,7 +103,7 @@ def render_rays_test_mode(
                 # weights with prefix_trans = 1 - opacity[ray], alpha_thre masking and the three in-place
                 # accumulations (:370-405) as one pass of the segmented engine
                 if alpha_thre > 0 and n_visible is None:
-                    n_visible = torch.zeros(1, dtype=torch.int64, device=device)
+                    n_visible = torch.zeros(_VISIBLE_SLOTS, dtype=torch.int64, device=device)
                 counter = n_visible if alpha_thre > 0 else None
                 if 2 * n_alive < num_rays:
                     # Most rays are finished: the pass runs on the rows that have samples (element offsets are
@@ -138,7 +141,7 @@ def render_rays_test_mode(
         total_samples += n_counted  # samples that entered the accumulation (:416)
 
     if n_visible is not None:
-        total_samples += int(n_visible.item())
+        total_samples += int(n_visible.sum().item())
     if render_bkgd is not None:
         rgb = rgb + render_bkgd * (1.0 - opacity)
     eps = torch.finfo(rgb.dtype).eps
