@@ -94,6 +94,17 @@ __device__ __forceinline__ float dpp_prev_lane(float old, float src)
 }
 // a * b + c on 24-bit unsigned operands as ONE full-rate instruction (hipcc turns __umul24(a, b) + c into the
 // quarter-rate 64-bit v_mad_u64_u32)
+// Level of an event of a ray's sorted intersection list.  t_indices holds argsort indices in [0, 2G) (grid.py:158-162: entries
+// below G enter level idx, the others leave level idx - G), so the reference's `idx % G` (grid.cu:127,137) is a conditional
+// subtraction; as a 64-bit modulo by a run-time divisor it was ~200 instructions, twice per event -- a fifth of a limited
+// walk's launch (the test-mode loop reads its list from the start in every iteration).  Out-of-range input: level >= G,
+// which callers treat as "not hit".
+__device__ __forceinline__ int32_t event_level(int64_t idx, int32_t G)
+{
+    const int32_t i = (int32_t)idx;
+    return i >= G ? i - G : i;
+}
+
 __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
 {
     uint32_t r;

@@ -404,13 +404,13 @@ __global__ __launch_bounds__(256) void traverse_kernel(const nfa_traverse_args a
             for (int32_t i = 0; i < (ray_ok ? 2 * G - 1 : 0); ++i) {  // grid.cu:125-150
                 const int64_t idx = ti[i];
                 const bool is_entering = idx < G;
-                int32_t level = (int32_t)(idx % G);
-                if (!hits[level]) continue;
+                int32_t level = event_level(idx, G);
+                if ((uint32_t)level >= (uint32_t)G || !hits[level]) continue;
                 if (!is_entering) {
                     const int64_t nidx = ti[i + 1];
                     if (nidx < G) continue;
-                    level = (int32_t)(nidx % G);
-                    if (!hits[level]) continue;
+                    level = event_level(nidx, G);
+                    if ((uint32_t)level >= (uint32_t)G || !hits[level]) continue;
                 }
                 const float this_tmin = fmaxf(ts[i], near_plane);
                 const float this_tmax = fminf(ts[i + 1], far_plane);
@@ -501,12 +501,12 @@ __global__ __launch_bounds__(256) void traverse_refill_kernel(const nfa_traverse
                     while (ev < 2 * G - 1 && !found) {  // grid.cu:125-150
                         const int32_t i = ev++;
                         const int64_t idx = ti[i];
-                        int32_t level = (int32_t)(idx % G);
-                        bool ok = hits[level] != 0;
+                        int32_t level = event_level(idx, G);
+                        bool ok = (uint32_t)level < (uint32_t)G && hits[level] != 0;
                         if (ok && idx >= G) {  // leaving: inside the next grid?
                             const int64_t nidx = ti[i + 1];
-                            level = (int32_t)(nidx % G);
-                            ok = nidx >= G && hits[level] != 0;
+                            level = event_level(nidx, G);
+                            ok = nidx >= G && (uint32_t)level < (uint32_t)G && hits[level] != 0;
                         }
                         const float this_tmin = fmaxf(ts[i], near_plane);
                         const float this_tmax = fminf(ts[i + 1], far_plane);

@@ -563,13 +563,13 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
                     while (!found && next_i < 2 * G - 1) {
                         const int32_t i = next_i++;
                         const int64_t idx = ti[i];
-                        level = (int32_t)(idx % G);
-                        if (!hits[level]) continue;
+                        level = event_level(idx, G);
+                        if ((uint32_t)level >= (uint32_t)G || !hits[level]) continue;
                         if (!(idx < G)) {
                             const int64_t nidx = ti[i + 1];
                             if (nidx < G) continue;
-                            level = (int32_t)(nidx % G);
-                            if (!hits[level]) continue;
+                            level = event_level(nidx, G);
+                            if ((uint32_t)level >= (uint32_t)G || !hits[level]) continue;
                         }
                         this_tmin = fmaxf(ts[i], near_plane); this_tmax = fminf(ts[i + 1], far_plane);
                         if (this_tmin >= this_tmax) continue;
@@ -672,6 +672,9 @@ struct ConeParams {
     const int32_t *order;        // lane -> ray assignment or NULL
     int64_t n_order;
     int32_t chunk, min_busy;     // cone_refill_kernel: entries of the ray list per wave; lanes that keep the cell loop going
+#ifdef NFA_CONE_PROFILE
+    unsigned long long *profile; // [8] debugging aid: cycles outside / inside the cell loop, trips, lane-trips, rounds
+#endif
 };
 #ifndef NFA_CONE_WALK_SPLIT
 #define NFA_CONE_WALK_SPLIT 0
@@ -843,12 +846,12 @@ __device__ __forceinline__ bool cone_next_span(const nfa_traverse_args &a, const
         while (ev < 2 * G - 1) {
             const int32_t i = ev++;
             const int64_t idx = ti[i];
-            int32_t level = (int32_t)(idx % G);
-            bool ok = hits[level] != 0;
+            int32_t level = event_level(idx, G);
+            bool ok = (uint32_t)level < (uint32_t)G && hits[level] != 0;
             if (ok && idx >= G) {  // leaving: inside the next grid?
                 const int64_t nidx = ti[i + 1];
-                level = (int32_t)(nidx % G);
-                ok = nidx >= G && hits[level] != 0;
+                level = event_level(nidx, G);
+                ok = nidx >= G && (uint32_t)level < (uint32_t)G && hits[level] != 0;
             }
             const float this_tmin = fmaxf(ts[i], near_plane);
             const float this_tmax = fminf(ts[i + 1], far_plane);
@@ -860,6 +863,58 @@ __device__ __forceinline__ bool cone_next_span(const nfa_traverse_args &a, const
         }
         return false;
     }
+}
+
+// The same walk over a ray's event list held by the lane: the (at most eight) argsort indices packed four bits each, the hit
+// flags as a bit mask, the sorted distances in the lane's LDS column -- loaded in one go when the lane takes the ray.  Read from
+// memory event by event (an index, then the flag it points at, then two distances: a chain of dependent loads per event,
+// three to six events before a fresh ray's first span) the list was most of a refill round's 19 k cycles.
+constexpr int CONE_EV_MAX = 8;   // 2 * n_grids entries: up to four levels
+__device__ __forceinline__ void cone_stage_events(const nfa_traverse_args &a, int64_t tid, uint32_t &ti_pack, uint32_t &hit_mask, float *ts_col)
+{
+    const int32_t G = a.n_grids;
+    const int64_t *ti = a.t_indices + tid * 2 * G;
+    const float *ts = a.t_sorted + tid * 2 * G;
+    const uint8_t *hits = a.hits + tid * G;
+    uint32_t pk = 0u, hm = 0u;
+#pragma unroll
+    for (int i = 0; i < CONE_EV_MAX; ++i)
+        if (i < 2 * G) {
+            const int64_t v = ti[i];
+            pk |= ((uint64_t)v < (uint64_t)(2 * G) ? (uint32_t)v : 15u) << (4 * i);   // (out of range: 15, a level nobody hits)
+            ts_col[i * 256] = ts[i];
+        }
+#pragma unroll
+    for (int g = 0; g < CONE_EV_MAX / 2; ++g)
+        if (g < G) hm |= (hits[g] != 0 ? 1u : 0u) << g;
+    ti_pack = pk; hit_mask = hm;
+}
+
+__device__ __forceinline__ bool cone_next_span_staged(const nfa_traverse_args &a, const ConeParams &p, const float o[3], const float d[3],
+                                                      float near_plane, float far_plane, int32_t &ev, uint32_t ti_pack, uint32_t hit_mask,
+                                                      const float *ts_col, ConeRay &st, WalkSpan &sp, float &span_tmax,
+                                                      unsigned long long &w_cur, uint32_t &i_cur)
+{
+    const int32_t G = a.n_grids;
+    while (ev < 2 * G - 1) {  // grid.cu:125-150
+        const int32_t i = ev++;
+        const int32_t idx = (int32_t)((ti_pack >> (4 * i)) & 15u);
+        int32_t level = idx >= G ? idx - G : idx;
+        bool ok = level < G && ((hit_mask >> level) & 1u) != 0u;
+        if (ok && idx >= G) {  // leaving: inside the next grid?
+            const int32_t nidx = (int32_t)((ti_pack >> (4 * (i + 1))) & 15u);
+            level = nidx >= G ? nidx - G : nidx;
+            ok = nidx >= G && level < G && ((hit_mask >> level) & 1u) != 0u;
+        }
+        const float this_tmin = fmaxf(ts_col[i * 256], near_plane);
+        const float this_tmax = fminf(ts_col[(i + 1) * 256], far_plane);
+        if (ok && this_tmin < this_tmax) {
+            span_tmax = this_tmax;
+            cone_span_begin(a, p, o, d, level, this_tmin, this_tmax, st, sp, w_cur, i_cur);
+            return true;
+        }
+    }
+    return false;
 }
 
 __device__ __forceinline__ void cone_ray_out(const nfa_traverse_args &a, const ConeParams &p, int64_t tid, const ConeRay &st)
@@ -922,9 +977,13 @@ __global__ __launch_bounds__(256) void cone_walk_kernel(const nfa_traverse_args 
 // and a lane that has finished its ray is given the next one: the wave leaves its cell loop when fewer than `min_busy`
 // lanes are still walking, sets up new rays (and the next spans of rays that crossed into another level) on the free
 // lanes, and re-enters.  Per ray the same functions as cone_walk_kernel: identical results.
-template <bool FUSED>
+template <bool FUSED, bool STAGED /* the event list travels with the lane (n_grids <= 4) */>
 __global__ __launch_bounds__(256) void cone_refill_kernel(const nfa_traverse_args a, const ConeParams p)
 {
+    static_assert(!(FUSED && STAGED), "a fused walk has no event list");
+    __shared__ float ts_lds[STAGED ? CONE_EV_MAX * 256 : 1];
+    float *const ts_col = ts_lds + (STAGED ? threadIdx.x : 0);
+    uint32_t ti_pack = 0u, hit_mask = 0u;
     enum { IDLE = 0, SPAN = 1, WALK = 2, FINISH = 3 };
     const int lane = lane_id();
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
@@ -945,13 +1004,20 @@ __global__ __launch_bounds__(256) void cone_refill_kernel(const nfa_traverse_arg
     unsigned long long w_cur = 0ull;
     uint32_t i_cur = 0u;
 
+#ifdef NFA_CONE_PROFILE
+    unsigned long long pf_setup = 0, pf_cells = 0, pf_trips = 0, pf_lanes = 0, pf_rounds = 0, pf_t = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
         // Two passes: rays that left a span in the cell loop (their next span, or their end), then the rays handed to the
         // lanes that are free after that.
 #pragma nounroll
         for (int pass = 0; pass < 2; ++pass) {
-            if (phase == SPAN)
-                phase = cone_next_span<FUSED>(a, p, tid, o, d, near_plane, far_plane, ev, st, sp, span_tmax, w_cur, i_cur) ? WALK : FINISH;
+            if (phase == SPAN) {
+                bool found;
+                if (STAGED) found = cone_next_span_staged(a, p, o, d, near_plane, far_plane, ev, ti_pack, hit_mask, ts_col, st, sp, span_tmax, w_cur, i_cur);
+                else found = cone_next_span<FUSED>(a, p, tid, o, d, near_plane, far_plane, ev, st, sp, span_tmax, w_cur, i_cur);
+                phase = found ? WALK : FINISH;
+            }
             if (phase == FINISH) {
                 cone_ray_out(a, p, tid, st);
                 phase = IDLE;
@@ -967,6 +1033,7 @@ __global__ __launch_bounds__(256) void cone_refill_kernel(const nfa_traverse_arg
                             near_plane = a.near_planes[tid]; far_plane = a.far_planes[tid];
 #pragma unroll
                             for (int ax = 0; ax < 3; ++ax) { o[ax] = a.rays_o[3 * tid + ax]; d[ax] = a.rays_d[3 * tid + ax]; }
+                            if (STAGED) cone_stage_events(a, tid, ti_pack, hit_mask, ts_col);
                             st.t_last = near_plane; st.continuous = 0; st.n_samples = 0; st.n_runs = 0; st.run_len = 0;
                             const bool ray_ok = isfinite(o[0]) && isfinite(o[1]) && isfinite(o[2]) && isfinite(d[0]) && isfinite(d[1]) && isfinite(d[2]);
                             ev = ray_ok ? 0 : 2 * a.n_grids;
@@ -978,6 +1045,9 @@ __global__ __launch_bounds__(256) void cone_refill_kernel(const nfa_traverse_arg
             }
         }
         const unsigned long long walking = __ballot(phase == WALK);
+#ifdef NFA_CONE_PROFILE
+        { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); pf_setup += t1 - pf_t; pf_t = t1; pf_rounds++; }
+#endif
         if (walking == 0ull) {
             if (next >= end) break;  // (every lane is IDLE here: SPAN and FINISH were resolved above)
             continue;
@@ -986,12 +1056,25 @@ __global__ __launch_bounds__(256) void cone_refill_kernel(const nfa_traverse_arg
         const int32_t n_walking = __popcll(walking);
         const int32_t need = next < end ? p.min_busy : (n_walking * 3 >> 2) > 1 ? (n_walking * 3 >> 2) : 1;
         do {
+#ifdef NFA_CONE_PROFILE
+            pf_trips++; pf_lanes += __popcll(__ballot(phase == WALK));
+#endif
             if (phase == WALK) {
                 if (cone_cell<NFA_CONE_REFILL_SPLIT != 0>(a, p, tid, span_tmax, sp, w_cur, i_cur, st))
                     phase = (limit > 0 && st.n_samples >= limit) ? FINISH : SPAN;  // budget spent: nothing after it changes the ray
             }
         } while (__popcll(__ballot(phase == WALK)) >= need);
+#ifdef NFA_CONE_PROFILE
+        { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); pf_cells += t1 - pf_t; pf_t = t1; }
+#endif
     }
+#ifdef NFA_CONE_PROFILE
+    if (p.profile && lane == 0) {
+        unsigned long long *pr = p.profile + 8 * (wave & 127);
+        atomicAdd(pr + 0, pf_setup); atomicAdd(pr + 1, pf_cells); atomicAdd(pr + 2, pf_trips); atomicAdd(pr + 3, pf_lanes);
+        atomicAdd(pr + 4, pf_rounds); atomicAdd(pr + 5, 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1510,6 +1593,12 @@ int nfa_traverse_cone_walk(const nfa_traverse_args *pa, const uint32_t *bits, in
     p.n_order = ray_order ? n_order : a.n_rays;
     NFA_REQUIRE(!ray_order || (n_order >= 0 && n_order <= a.n_rays), "traverse_cone_walk: n_order out of range");
     if (ray_order && n_order == 0) return NFA_OK;
+#ifdef NFA_CONE_PROFILE
+    {   // debugging aid: env NFA_CONE_PROFILE_PTR = address of a zeroed device buffer of 128 x 8 uint64
+        const char *e = getenv("NFA_CONE_PROFILE_PTR");
+        p.profile = e ? reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 0)) : nullptr;
+    }
+#endif
     const char *refill_env = getenv("NFA_REFILL");  // "0": one ray per lane also for limited walks; "chunk,min_busy": tuning
     if (a.traverse_steps_limit > 0 && !(refill_env && refill_env[0] == '0')) {
         // entries per wave: enough of them that a lane is refilled several times, as long as the launch still fills the chip
@@ -1520,8 +1609,11 @@ int nfa_traverse_cone_walk(const nfa_traverse_args *pa, const uint32_t *bits, in
         p.chunk = (int32_t)chunk; p.min_busy = min_busy;
         const int64_t n_waves = (p.n_order + chunk - 1) / chunk;
         const unsigned grid = (unsigned)((n_waves + 3) / 4);
-        if (fused) hipLaunchKernelGGL((cone_refill_kernel<true>), dim3(grid), dim3(256), 0, s, a, p);
-        else       hipLaunchKernelGGL((cone_refill_kernel<false>), dim3(grid), dim3(256), 0, s, a, p);
+        const char *staged_env = getenv("NFA_CONE_STAGED");   // "0": event lists read from memory (A/B)
+        const bool staged = !fused && 2 * a.n_grids <= CONE_EV_MAX && !(staged_env && staged_env[0] == '0');
+        if (fused)       hipLaunchKernelGGL((cone_refill_kernel<true, false>), dim3(grid), dim3(256), 0, s, a, p);
+        else if (staged) hipLaunchKernelGGL((cone_refill_kernel<false, true>), dim3(grid), dim3(256), 0, s, a, p);
+        else             hipLaunchKernelGGL((cone_refill_kernel<false, false>), dim3(grid), dim3(256), 0, s, a, p);
     } else {
         p.chunk = 64; p.min_busy = 64;
         const unsigned grid = grid_1d(p.n_order, 256, 1 << 20);

@@ -48,6 +48,7 @@ def test_cone_walk_forms_agree_and_match_oracle(dev, oracle):
         (1, (64, 64, 64), 0.5, 5_000, 3e-3, 0.003, None, False, False),
         (4, (16, 16, 16), 0.02, 30_000, 1e-2, 0.004, 7, True, True),
         (2, (50, 24, 30), 0.3, 3_000, 5e-3, 0.05, 40, False, True),
+        (5, (16, 16, 16), 0.05, 6_000, 1e-2, 0.004, 5, True, True),    # ten events per ray: the refill kernel reads them from memory
     ]
     saved = (na.grid.CONE_WALK, os.environ.get("NFA_REFILL"))
     try:
