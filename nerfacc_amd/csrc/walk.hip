@@ -1600,7 +1600,8 @@ int nfa_traverse_cone_walk(const nfa_traverse_args *pa, const uint32_t *bits, in
     }
 #endif
     const char *refill_env = getenv("NFA_REFILL");  // "0": one ray per lane also for limited walks; "chunk,min_busy": tuning
-    if (a.traverse_steps_limit > 0 && !(refill_env && refill_env[0] == '0')) {
+    const char *refill_all = getenv("NFA_REFILL_ALL");   // "1": the refilling kernel for unlimited walks too (measurements)
+    if ((a.traverse_steps_limit > 0 || (refill_all && refill_all[0] == '1')) && !(refill_env && refill_env[0] == '0')) {
         // entries per wave: enough of them that a lane is refilled several times, as long as the launch still fills the chip
         int64_t chunk = ((p.n_order + 4095) / 4096 + 63) / 64 * 64;
         chunk = chunk < 64 ? 64 : (chunk > 1024 ? 1024 : chunk);

@@ -22,12 +22,14 @@ d = rng.standard_normal((R, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=
 d = torch.from_numpy(d).to(dev)
 near = torch.full((R,), 0.2, device=dev); far = torch.full((R,), 1e10, device=dev)
 mask = torch.ones(R, dtype=torch.bool, device=dev)
+sink = {}
 LIMITS = tuple(int(v) for v in sys.argv[1:]) or (1, 4, 16, 64, 256, 0)
 for limit in LIMITS:
     for rep in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         out = GR._traverse_samples(o, d, est.binaries, est.aabbs, near, far, 1e-3, 0.004, rays_mask=mask if limit else None,
-                                   traverse_steps_limit=limit, n_alive=R if limit else None)
+                                   traverse_steps_limit=limit, n_alive=R if limit else None,
+                                   bin_rays={"": None, "0": False, "1": True}[os.environ.get("NFA_LS_BIN", "")], stats_sink=sink)
         e1.record(); torch.cuda.synchronize()
     print(f"limit {limit:4d}: samples {out[0].numel():10d}  {e0.elapsed_time(e1):8.3f} ms")
