@@ -482,6 +482,18 @@ def extra_cfg2_variant(dev, args, **kw):
     return out
 
 
+def extra_cfg4_per_rank(dev, args, res=256):
+    """What ONE rank of `bench.py --gpus N` (N > 1: BASELINE cfg 4) does per step, on this GPU: the same 1024 x 1024 rays through
+    cfg 4's shared 256^3 grid.  The N = 1 line itself is cfg 2 (128^3, the metric's configuration), whose walk crosses half as
+    many cells: the scaling efficiency of cfg 4 is value(N) / (N x this rate), not value(N) / (N x value(1))."""
+    binaries = shared_grid(dev, res, args.grid, 0, 1)
+    w = make_workload(dev, args.rays, res, args.grid, "image", 0, args.field, binaries=binaries)
+    dt, ks, _ = timed_steps(lambda: run_step(w, 1)[0], max(3, args.steps // 2), 3)
+    return {"workload": f"cfg 4's per-rank step on one GPU: {args.rays} image rays, shared {res}^3 {args.grid} grid, sampling + rendering fwd + bwd",
+            "ms_per_step": dt * 1e3, "rays_per_s": args.rays / dt, "samples": int(w["last"][0].numel()),
+            "native_ms_per_step": sum(v["ms_per_step"] for v in ks.values())}
+
+
 def _cfg3_cpu_baseline(R=1 << 17, min_seconds=4.0):
     """cfg 3 on the host: the oracle's restatement of PropNetEstimator.sampling's level loop (2 -> 64 -> 64 -> 16, uniform;
     ref estimators/prop_net.py:38-129, resampling = pdf.cu's kernels in C/OpenMP, the batched transmittance and the s -> t
@@ -838,7 +850,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the second (software-pipelined) timed loop")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary configurations (cfg2 variants, cfg3, cfg5)")
-    ap.add_argument("--only", default="", choices=["", "cfg2_compacting", "cfg2_random", "cfg2_testmode", "cfg3", "cfg5", "cfg5_testmode"],
+    ap.add_argument("--only", default="", choices=["", "cfg2_compacting", "cfg2_random", "cfg2_testmode", "cfg4_per_rank", "cfg3", "cfg5", "cfg5_testmode"],
                     help="run ONE secondary configuration alone and print its object (for rocprofv3 passes: profiles/<round>_<cfg>_*)")
     args = ap.parse_args()
 
@@ -863,6 +875,7 @@ def main():
               "cfg2_random": lambda: extra_cfg2_variant(dev, args, rays="random"),
               "cfg3": lambda: extra_cfg3(dev, 1 << 20, max(3, args.steps // 4), args.field),
               "cfg2_testmode": lambda: extra_cfg2_testmode(dev, args, n_img=max(2, args.steps // 4)),
+              "cfg4_per_rank": lambda: extra_cfg4_per_rank(dev, args),
               "cfg5": lambda: extra_cfg5(dev, 1 << 21, max(2, args.steps // 6)),
               "cfg5_testmode": lambda: extra_cfg5(dev, 1 << 21, max(2, args.steps // 6), train=False)}[args.only]
         print(json.dumps({args.only: fn()}))
@@ -1068,6 +1081,7 @@ def main():
             for key, fn in (("cfg2_compacting", lambda: extra_cfg2_variant(dev, args, sigma_scale=16.0)),
                             ("cfg2_random", lambda: extra_cfg2_variant(dev, args, rays="random")),
                             ("cfg2_testmode", lambda: extra_cfg2_testmode(dev, args)),
+                            ("cfg4_per_rank", lambda: extra_cfg4_per_rank(dev, args)),
                             ("cfg3", lambda: extra_cfg3(dev, 1 << 20, 5, args.field)),
                             ("cfg5", lambda: extra_cfg5(dev, 1 << 21, 3))):
                 try:
