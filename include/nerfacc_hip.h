@@ -458,6 +458,18 @@ int nfa_pdf_loss_fwd(const float *q_vals, const float *q_cdfs, const float *k_va
 int nfa_pdf_loss_bwd(const float *q_cdfs, const float *k_cdfs, const uint32_t *key_ids, int64_t n_rays,
                      int32_t n_query_edges, int32_t n_key_edges, float eps, const float *g_loss, float *g_k_cdfs,
                      float *g_q_cdfs, nfa_stream_t stream);
+/* The same loss as its MEAN over all (ray, interval) pairs, which is what PropNetEstimator.compute_loss uses (ref:
+ * estimators/prop_net.py:151 `.mean()`): the forward writes nfa_pdf_loss_partials(...) per-wave partial sums instead of the
+ * loss array (mean = sum of partials / (n_rays * (n_query_edges - 1)); the wave -> rows assignment is fixed, so the sum is
+ * deterministic), the backward takes the gradient of the mean (one device float).  Saves the loss array's write + read and
+ * its expanded gradient's write + read. */
+int64_t nfa_pdf_loss_partials(int64_t n_rays, int32_t n_query_edges, int32_t n_key_edges);
+int nfa_pdf_loss_sum_fwd(const float *q_vals, const float *q_cdfs, const float *k_vals, const float *k_cdfs,
+                         int64_t n_rays, int32_t n_query_edges, int32_t n_key_edges, float eps, float *partials,
+                         uint32_t *key_ids, nfa_stream_t stream);
+int nfa_pdf_loss_mean_bwd(const float *q_cdfs, const float *k_cdfs, const uint32_t *key_ids, int64_t n_rays,
+                          int32_t n_query_edges, int32_t n_key_edges, float eps, const float *g_mean, float *g_k_cdfs,
+                          float *g_q_cdfs, nfa_stream_t stream);
 
 #ifdef __cplusplus
 }

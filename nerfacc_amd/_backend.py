@@ -49,6 +49,9 @@ _SIGS = {
     "nfa_pack_info": [_vp, _i64, _i64, _vp, _vp, _vp, _vp],
     "nfa_pdf_loss_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _vp],
     "nfa_pdf_loss_bwd": [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _vp, _vp],
+    "nfa_pdf_loss_partials": [_i64, _i32, _i32],
+    "nfa_pdf_loss_sum_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _vp],
+    "nfa_pdf_loss_mean_bwd": [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _vp, _vp],
     "nfa_pack_bits": [_vp, _i64, _vp, _vp],
     "nfa_ray_aabb_intersect": [_vp, _vp, _i64, _vp, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
     "nfa_traverse_grids": [C.POINTER(TraverseArgs), _vp],
@@ -104,7 +107,7 @@ _SIGS = {
     "nfa_version": [],
     "nfa_device_arch": [C.c_char_p, _int],
 }
-_RESTYPES = {"nfa_traverse_onepass_scratch_words": _i64, "nfa_grid_rebinarize_scratch_bytes": _i64, "nfa_bricks_words": _i64, "nfa_walk_bits_words": _i64, "nfa_cumsum_scratch_bytes": _i64, "nfa_seg_table_rows": _i64, "nfa_seg_plan": None, "nfa_last_error": C.c_char_p}
+_RESTYPES = {"nfa_traverse_onepass_scratch_words": _i64, "nfa_grid_rebinarize_scratch_bytes": _i64, "nfa_bricks_words": _i64, "nfa_walk_bits_words": _i64, "nfa_pdf_loss_partials": _i64, "nfa_cumsum_scratch_bytes": _i64, "nfa_seg_table_rows": _i64, "nfa_seg_plan": None, "nfa_last_error": C.c_char_p}
 
 EXPORTED_SYMBOLS = tuple(_SIGS)
 

@@ -487,11 +487,23 @@ __global__ __launch_bounds__(256) void searchsorted_kernel(
 // in LDS (only the ray's own lane group touches it) and writes it once.
 constexpr int PL_STAGE_MAX = 1024;  // key entries (vals + cdfs [+ grad row]) a wave may stage
 
+// The mean form (PropNetEstimator.compute_loss takes `.mean()` of the loss, ref prop_net.py:151): the forward leaves one partial
+// sum per wave instead of the loss array (the caller adds them up: deterministic, the wave -> rows assignment is fixed), the
+// backward takes the scalar gradient of the mean.  Saves writing and re-reading the loss array and its expanded gradient.
+__device__ __forceinline__ float pl_wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
 __global__ __launch_bounds__(256) void pdf_loss_fwd_kernel(const float *__restrict__ q_vals, const float *__restrict__ q_cdfs,
                                                            const float *__restrict__ k_vals, const float *__restrict__ k_cdfs,
                                                            int64_t n_rays, int Q1, int K1, int L, float eps,
-                                                           float *__restrict__ loss, uint32_t *__restrict__ ids /* left | right << 16, or null */)
+                                                           float *__restrict__ loss /* or null */, uint32_t *__restrict__ ids /* left | right << 16, or null */,
+                                                           float *__restrict__ partials /* [waves] or null */)
 {
+    float acc = 0.0f;
     __shared__ float s_kv[4][PL_STAGE_MAX];
     __shared__ float s_kc[4][PL_STAGE_MAX];
     const int lane = lane_id(), gl = lane & (L - 1), rpw = 64 / L, Q = Q1 - 1;
@@ -515,10 +527,16 @@ __global__ __launch_bounds__(256) void pdf_loss_fwd_kernel(const float *__restri
                 const float w = qc[j + 1] - qc[j];
                 const float wo = kc[right] - kc[left];
                 const float d = fmaxf(w - wo, 0.0f);
-                loss[ray * Q + j] = (d * d) / (w + eps);
+                const float l = (d * d) / (w + eps);
+                if (loss) loss[ray * Q + j] = l;
+                acc += l;
                 if (ids) ids[ray * Q + j] = (uint32_t)(left - kb) | ((uint32_t)(right - kb) << 16);
             }
         }
+    }
+    if (partials) {
+        const float tot = pl_wave_sum(acc);
+        if (lane == 0) partials[wave] = tot;
     }
 }
 
@@ -529,8 +547,10 @@ template <int LL>
 __global__ __launch_bounds__(256) void pdf_loss_fwd_rows_kernel(const float *__restrict__ q_vals, const float *__restrict__ q_cdfs,
                                                                 const float *__restrict__ k_vals, const float *__restrict__ k_cdfs,
                                                                 int64_t n_rays, int Q1, int K1, int n_rounds, float eps,
-                                                                float *__restrict__ loss, uint32_t *__restrict__ ids)
+                                                                float *__restrict__ loss /* or null */, uint32_t *__restrict__ ids,
+                                                                float *__restrict__ partials /* [waves] or null */)
 {
+    float acc = 0.0f;
     constexpr int RPW = 64 / LL;
     constexpr int STAGE = PL_STAGE_MAX / 2, SLOTS = STAGE / 64;
     __shared__ float s_kv[4][STAGE];
@@ -585,10 +605,16 @@ __global__ __launch_bounds__(256) void pdf_loss_fwd_rows_kernel(const float *__r
         const float d = fmaxf(w - wo, 0.0f);
         const int o = grp * Q + gl;
         if (ok) {
-            (loss + r0 * Q)[o] = (d * d) / (w + eps);
+            const float l = (d * d) / (w + eps);
+            if (loss) (loss + r0 * Q)[o] = l;
+            acc += l;
             if (ids) (ids + r0 * Q)[o] = (uint32_t)(left - kb) | ((uint32_t)(right - kb) << 16);
         }
         r0 = r_next;
+    }
+    if (partials) {
+        const float tot = pl_wave_sum(acc);
+        if (lane == 0) partials[wave] = tot;
     }
 }
 
@@ -596,9 +622,11 @@ __global__ __launch_bounds__(256) void pdf_loss_fwd_rows_kernel(const float *__r
 // accumulated in LDS by the ray's own lane group and written once.
 __global__ __launch_bounds__(256) void pdf_loss_bwd_kernel(const float *__restrict__ q_cdfs, const float *__restrict__ k_cdfs,
                                                            const uint32_t *__restrict__ ids, int64_t n_rays, int Q1, int K1,
-                                                           int L, float eps, const float *__restrict__ g_loss,
-                                                           float *__restrict__ g_k_cdfs, float *__restrict__ g_q_cdfs)
+                                                           int L, float eps, const float *__restrict__ g_loss /* or null: the mean form */,
+                                                           float *__restrict__ g_k_cdfs, float *__restrict__ g_q_cdfs,
+                                                           const float *__restrict__ g_mean, float count)
 {
+    const float g_all = g_loss ? 0.0f : g_mean[0] / count;   // d mean / d loss_i (torch: grad / numel)
     __shared__ float s_g[4][PL_STAGE_MAX];
     __shared__ float s_gq[4][PL_STAGE_MAX];
     const int lane = lane_id(), gl = lane & (L - 1), rpw = 64 / L, Q = Q1 - 1;
@@ -623,7 +651,7 @@ __global__ __launch_bounds__(256) void pdf_loss_bwd_kernel(const float *__restri
                 const float d = fmaxf(w - (kc[right] - kc[left]), 0.0f);
                 if (d > 0.0f) {
                     // d l / d wo = -2 d / (w + eps);  d l / d w = 2 d / (w + eps) - d^2 / (w + eps)^2
-                    const float g = g_loss[ray * Q + j], inv = 1.0f / (w + eps);
+                    const float g = g_loss ? g_loss[ray * Q + j] : g_all, inv = 1.0f / (w + eps);
                     const float gwo = -2.0f * d * inv * g;
                     atomicAdd(&gk[kb + right], gwo);
                     atomicAdd(&gk[kb + left], -gwo);
@@ -647,9 +675,11 @@ __global__ __launch_bounds__(256) void pdf_loss_bwd_kernel(const float *__restri
 template <int LL>
 __global__ __launch_bounds__(256) void pdf_loss_bwd_rows_kernel(const float *__restrict__ q_cdfs, const float *__restrict__ k_cdfs,
                                                                 const uint32_t *__restrict__ ids, int64_t n_rays, int Q1, int K1,
-                                                                float eps, const float *__restrict__ g_loss,
-                                                                float *__restrict__ g_k_cdfs, float *__restrict__ g_q_cdfs)
+                                                                float eps, const float *__restrict__ g_loss /* or null: the mean form */,
+                                                                float *__restrict__ g_k_cdfs, float *__restrict__ g_q_cdfs,
+                                                                const float *__restrict__ g_mean, float count)
 {
+    const float g_all = g_loss ? 0.0f : g_mean[0] / count;   // d mean / d loss_i (torch: grad / numel)
     constexpr int RPW = 64 / LL;
     constexpr int STAGE = PL_STAGE_MAX / 2, SLOTS = STAGE / 64;
     __shared__ float s_kc[4][STAGE];
@@ -676,7 +706,7 @@ __global__ __launch_bounds__(256) void pdf_loss_bwd_rows_kernel(const float *__r
         const float *qc = q_cdfs + r0 * Q1;
         pq0 = qc[qo]; pq1 = qc[qo + 1];
         pid = (ids + r0 * Q)[lo];
-        pg = (g_loss + r0 * Q)[lo];
+        pg = g_loss ? (g_loss + r0 * Q)[lo] : g_all;
     };
     int64_t r0 = uniform64_pdf(wave * RPW);
     if (r0 < n_rays) prefetch(r0);
@@ -857,21 +887,28 @@ static int pdf_loss_lanes(int Q, int K1, int Q1)
     return L;
 }
 
-int nfa_pdf_loss_fwd(const float *q_vals, const float *q_cdfs, const float *k_vals, const float *k_cdfs, int64_t n_rays,
-                     int32_t n_query_edges, int32_t n_key_edges, float eps, float *loss, uint32_t *key_ids, nfa_stream_t stream)
+static unsigned pdf_loss_grid(int64_t n_rays, int32_t n_query_edges, int32_t n_key_edges)
+{
+    const int L = pdf_loss_lanes(n_query_edges - 1, n_key_edges, n_query_edges);
+    return grid_1d(ceil_div64(n_rays, 64 / L) * 64, 256, 1 << 16);
+}
+
+static int pdf_loss_fwd_impl(const float *q_vals, const float *q_cdfs, const float *k_vals, const float *k_cdfs, int64_t n_rays,
+                             int32_t n_query_edges, int32_t n_key_edges, float eps, float *loss, uint32_t *key_ids,
+                             float *partials, nfa_stream_t stream)
 {
     NFA_REQUIRE(n_rays >= 0 && n_query_edges >= 2 && n_key_edges >= 1, "pdf_loss_fwd: bad sizes");
     NFA_REQUIRE(n_key_edges <= PL_STAGE_MAX && n_query_edges <= PL_STAGE_MAX, "pdf_loss_fwd: rows longer than 1024 edges are not supported");
     if (n_rays == 0) return NFA_OK;
-    NFA_REQUIRE(q_vals && q_cdfs && k_vals && k_cdfs && loss, "pdf_loss_fwd: null pointer");
+    NFA_REQUIRE(q_vals && q_cdfs && k_vals && k_cdfs && (loss || partials), "pdf_loss_fwd: null pointer");
     const int L = pdf_loss_lanes(n_query_edges - 1, n_key_edges, n_query_edges);
-    const unsigned grid = grid_1d(ceil_div64(n_rays, 64 / L) * 64, 256, 1 << 16);
+    const unsigned grid = pdf_loss_grid(n_rays, n_query_edges, n_key_edges);
     if (n_query_edges - 1 <= L && (64 / L) * n_key_edges <= PL_STAGE_MAX / 2) {
         int n_rounds = 0;
         while ((1 << n_rounds) <= (int)n_key_edges - 1) ++n_rounds;
 #define NFA_PL_ROWS(LL)                                                                                                   \
     hipLaunchKernelGGL(pdf_loss_fwd_rows_kernel<LL>, dim3(grid), dim3(256), 0, as_stream(stream), q_vals, q_cdfs, k_vals, k_cdfs, \
-                       n_rays, (int)n_query_edges, (int)n_key_edges, n_rounds, eps, loss, key_ids)
+                       n_rays, (int)n_query_edges, (int)n_key_edges, n_rounds, eps, loss, key_ids, partials)
         switch (L) {
             case 2: NFA_PL_ROWS(2); break;
             case 4: NFA_PL_ROWS(4); break;
@@ -885,25 +922,46 @@ int nfa_pdf_loss_fwd(const float *q_vals, const float *q_cdfs, const float *k_va
         return NFA_OK;
     }
     hipLaunchKernelGGL(pdf_loss_fwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), q_vals, q_cdfs, k_vals, k_cdfs,
-                       n_rays, (int)n_query_edges, (int)n_key_edges, L, eps, loss, key_ids);
+                       n_rays, (int)n_query_edges, (int)n_key_edges, L, eps, loss, key_ids, partials);
     NFA_CHECK_LAUNCH("pdf_loss_fwd");
     return NFA_OK;
 }
 
-int nfa_pdf_loss_bwd(const float *q_cdfs, const float *k_cdfs, const uint32_t *key_ids, int64_t n_rays,
-                     int32_t n_query_edges, int32_t n_key_edges, float eps, const float *g_loss, float *g_k_cdfs,
-                     float *g_q_cdfs, nfa_stream_t stream)
+int nfa_pdf_loss_fwd(const float *q_vals, const float *q_cdfs, const float *k_vals, const float *k_cdfs, int64_t n_rays,
+                     int32_t n_query_edges, int32_t n_key_edges, float eps, float *loss, uint32_t *key_ids, nfa_stream_t stream)
+{
+    NFA_REQUIRE(loss || n_rays == 0, "pdf_loss_fwd: loss is null");
+    return pdf_loss_fwd_impl(q_vals, q_cdfs, k_vals, k_cdfs, n_rays, n_query_edges, n_key_edges, eps, loss, key_ids, nullptr, stream);
+}
+
+int64_t nfa_pdf_loss_partials(int64_t n_rays, int32_t n_query_edges, int32_t n_key_edges)
+{
+    if (n_rays <= 0 || n_query_edges < 2 || n_key_edges < 1) return 0;
+    return (int64_t)pdf_loss_grid(n_rays, n_query_edges, n_key_edges) * 4;   // waves of the launch
+}
+
+int nfa_pdf_loss_sum_fwd(const float *q_vals, const float *q_cdfs, const float *k_vals, const float *k_cdfs, int64_t n_rays,
+                         int32_t n_query_edges, int32_t n_key_edges, float eps, float *partials, uint32_t *key_ids, nfa_stream_t stream)
+{
+    NFA_REQUIRE(partials || n_rays == 0, "pdf_loss_sum_fwd: partials is null");
+    return pdf_loss_fwd_impl(q_vals, q_cdfs, k_vals, k_cdfs, n_rays, n_query_edges, n_key_edges, eps, nullptr, key_ids, partials, stream);
+}
+
+static int pdf_loss_bwd_impl(const float *q_cdfs, const float *k_cdfs, const uint32_t *key_ids, int64_t n_rays,
+                             int32_t n_query_edges, int32_t n_key_edges, float eps, const float *g_loss, const float *g_mean,
+                             float *g_k_cdfs, float *g_q_cdfs, nfa_stream_t stream)
 {
     NFA_REQUIRE(n_rays >= 0 && n_query_edges >= 2 && n_key_edges >= 1, "pdf_loss_bwd: bad sizes");
     NFA_REQUIRE(n_key_edges <= PL_STAGE_MAX && n_query_edges <= PL_STAGE_MAX, "pdf_loss_bwd: rows longer than 1024 edges are not supported");
     if (n_rays == 0) return NFA_OK;
-    NFA_REQUIRE(q_cdfs && k_cdfs && key_ids && g_loss && g_k_cdfs, "pdf_loss_bwd: null pointer");
+    NFA_REQUIRE(q_cdfs && k_cdfs && key_ids && (g_loss || g_mean) && g_k_cdfs, "pdf_loss_bwd: null pointer");
     const int L = pdf_loss_lanes(n_query_edges - 1, n_key_edges, n_query_edges);
-    const unsigned grid = grid_1d(ceil_div64(n_rays, 64 / L) * 64, 256, 1 << 16);
+    const unsigned grid = pdf_loss_grid(n_rays, n_query_edges, n_key_edges);
+    const float count = (float)((double)n_rays * (double)(n_query_edges - 1));
     if (n_query_edges - 1 <= L && (64 / L) * n_key_edges <= PL_STAGE_MAX / 2) {
 #define NFA_PLB_ROWS(LL)                                                                                                  \
     hipLaunchKernelGGL(pdf_loss_bwd_rows_kernel<LL>, dim3(grid), dim3(256), 0, as_stream(stream), q_cdfs, k_cdfs, key_ids, n_rays, \
-                       (int)n_query_edges, (int)n_key_edges, eps, g_loss, g_k_cdfs, g_q_cdfs)
+                       (int)n_query_edges, (int)n_key_edges, eps, g_loss, g_k_cdfs, g_q_cdfs, g_mean, count)
         switch (L) {
             case 2: NFA_PLB_ROWS(2); break;
             case 4: NFA_PLB_ROWS(4); break;
@@ -917,9 +975,25 @@ int nfa_pdf_loss_bwd(const float *q_cdfs, const float *k_cdfs, const uint32_t *k
         return NFA_OK;
     }
     hipLaunchKernelGGL(pdf_loss_bwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), q_cdfs, k_cdfs, key_ids, n_rays,
-                       (int)n_query_edges, (int)n_key_edges, L, eps, g_loss, g_k_cdfs, g_q_cdfs);
+                       (int)n_query_edges, (int)n_key_edges, L, eps, g_loss, g_k_cdfs, g_q_cdfs, g_mean, count);
     NFA_CHECK_LAUNCH("pdf_loss_bwd");
     return NFA_OK;
+}
+
+int nfa_pdf_loss_bwd(const float *q_cdfs, const float *k_cdfs, const uint32_t *key_ids, int64_t n_rays,
+                     int32_t n_query_edges, int32_t n_key_edges, float eps, const float *g_loss, float *g_k_cdfs,
+                     float *g_q_cdfs, nfa_stream_t stream)
+{
+    NFA_REQUIRE(g_loss || n_rays == 0, "pdf_loss_bwd: g_loss is null");
+    return pdf_loss_bwd_impl(q_cdfs, k_cdfs, key_ids, n_rays, n_query_edges, n_key_edges, eps, g_loss, nullptr, g_k_cdfs, g_q_cdfs, stream);
+}
+
+int nfa_pdf_loss_mean_bwd(const float *q_cdfs, const float *k_cdfs, const uint32_t *key_ids, int64_t n_rays,
+                          int32_t n_query_edges, int32_t n_key_edges, float eps, const float *g_mean, float *g_k_cdfs,
+                          float *g_q_cdfs, nfa_stream_t stream)
+{
+    NFA_REQUIRE(g_mean || n_rays == 0, "pdf_loss_mean_bwd: g_mean is null");
+    return pdf_loss_bwd_impl(q_cdfs, k_cdfs, key_ids, n_rays, n_query_edges, n_key_edges, eps, nullptr, g_mean, g_k_cdfs, g_q_cdfs, stream);
 }
 
 }  // extern "C"

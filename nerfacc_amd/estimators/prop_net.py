@@ -25,6 +25,7 @@ from ..volrend import render_transmittance_from_density
 from .base import AbstractEstimator
 
 FUSE_CDFS = os.environ.get("NERFACC_AMD_FUSE_CDFS", "1") != "0"   # A/B switch (the tests compare both forms)
+FUSE_LOSS_MEAN = os.environ.get("NERFACC_AMD_FUSE_LOSS_MEAN", "1") != "0"   # A/B switch: 0 = _pdf_loss(...).mean() through the loss array
 
 
 class PropNetEstimator(AbstractEstimator):
@@ -98,7 +99,7 @@ class PropNetEstimator(AbstractEstimator):
         loss = 0.0
         while self.prop_cache:
             prop_intervals, prop_cdfs = self.prop_cache.pop()
-            loss += _pdf_loss(intervals, cdfs, prop_intervals, prop_cdfs).mean()
+            loss += _pdf_loss_mean(intervals, cdfs, prop_intervals, prop_cdfs)
         return loss * loss_scaler
 
     @torch.enable_grad()
@@ -277,6 +278,62 @@ class _PdfLossBatched(torch.autograd.Function):
             B.call("nfa_pdf_loss_bwd", B.ptr(qc), B.ptr(kc), B.ptr(ids), n_rays, Q1, K1, ctx.eps,
                    B.ptr(g_loss.contiguous()), B.ptr(g_kc), B.ptr(g_qc), B.stream())
         return None, g_qc, None, (g_kc if ctx.needs_input_grad[3] else None), None
+
+
+class _PdfLossBatchedMean(torch.autograd.Function):
+    """``_pdf_loss(...).mean()`` of the batched branch without the loss array: the forward pass leaves one partial sum per wave
+    (added up here: a few thousand floats), the backward pass takes the mean's scalar gradient -- the (R, S) loss, its
+    reduction and the expanded (R, S) gradient never touch memory (ref: prop_net.py:151, :232-256)."""
+
+    @staticmethod
+    def forward(ctx, q_vals, q_cdfs, k_vals, k_cdfs, eps: float):
+        ctx.set_materialize_grads(False)
+        qv, qc, kv, kc = (t.contiguous() for t in (q_vals, q_cdfs, k_vals, k_cdfs))
+        dev = B.require_device(qv, qc, kv, kc)
+        Q1, K1 = qv.shape[-1], kv.shape[-1]
+        n_rays = qv.numel() // Q1
+        need_bwd = any(ctx.needs_input_grad)
+        with torch.cuda.device(dev):
+            n_part = int(B.load().nfa_pdf_loss_partials(n_rays, Q1, K1))
+            partials = torch.empty(max(n_part, 1), dtype=torch.float32, device=dev)
+            ids = torch.empty(qv.shape[:-1] + (Q1 - 1,), dtype=torch.int32, device=dev) if need_bwd else None
+            if n_part == 0:
+                partials.zero_()
+            B.call("nfa_pdf_loss_sum_fwd", B.ptr(qv), B.ptr(qc), B.ptr(kv), B.ptr(kc), n_rays, Q1, K1, float(eps), B.ptr(partials),
+                   B.ptr(ids), B.stream())
+        if need_bwd:
+            ctx.save_for_backward(qc, kc, ids)
+        ctx.eps = float(eps)
+        return partials.sum() / float(max(n_rays * (Q1 - 1), 1))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_mean):
+        if g_mean is None or not (ctx.needs_input_grad[1] or ctx.needs_input_grad[3]):
+            return None, None, None, None, None
+        qc, kc, ids = ctx.saved_tensors
+        Q1, K1 = qc.shape[-1], kc.shape[-1]
+        n_rays = qc.numel() // Q1
+        g_kc = torch.empty_like(kc)
+        g_qc = torch.empty_like(qc) if ctx.needs_input_grad[1] else None
+        g = g_mean.to(torch.float32).reshape(1).contiguous()
+        with torch.cuda.device(qc.device):
+            B.call("nfa_pdf_loss_mean_bwd", B.ptr(qc), B.ptr(kc), B.ptr(ids), n_rays, Q1, K1, ctx.eps, B.ptr(g), B.ptr(g_kc), B.ptr(g_qc),
+                   B.stream())
+        return None, g_qc, None, (g_kc if ctx.needs_input_grad[3] else None), None
+
+
+def _pdf_loss_mean(segments_query: RayIntervals, cdfs_query: Tensor, segments_key: RayIntervals, cdfs_key: Tensor,
+                   eps: float = 1e-7) -> Tensor:
+    """``_pdf_loss(...).mean()`` (what ``compute_loss`` adds up, ref :151); batched float32 CUDA rows take the form that
+    never materialises the per-interval loss."""
+    qv, kv = segments_query.vals, segments_key.vals
+    if (FUSE_LOSS_MEAN and qv.dim() > 1 and kv.dim() > 1 and qv.is_cuda
+            and all(t.dtype == torch.float32 for t in (qv, kv, cdfs_query, cdfs_key))
+            and qv.shape[:-1] == kv.shape[:-1] and cdfs_query.shape == qv.shape and cdfs_key.shape == kv.shape
+            and 2 <= qv.shape[-1] <= 1024 and kv.shape[-1] <= 1024 and qv.numel() > 0):
+        return _PdfLossBatchedMean.apply(qv, cdfs_query, kv, cdfs_key, eps)
+    return _pdf_loss(segments_query, cdfs_query, segments_key, cdfs_key, eps).mean()
 
 
 def _pdf_loss(segments_query: RayIntervals, cdfs_query: Tensor, segments_key: RayIntervals, cdfs_key: Tensor,

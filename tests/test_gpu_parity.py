@@ -1315,6 +1315,37 @@ def test_pdf_loss_fused_matches_composition(dev):
     assert kc.grad is not None and torch.isfinite(kc.grad).all()
 
 
+def test_pdf_loss_mean_form_matches_the_loss_array(dev):
+    """compute_loss takes the MEAN of the interlevel loss (ref prop_net.py:151): the form that leaves per-wave partial sums and
+    takes the mean's scalar gradient equals `_pdf_loss(...).mean()` in value (fp32 summation order aside) and in both gradients,
+    for the short-row kernel, the general kernel, a scaled loss (loss_scaler) and the key-gradient-only case of the estimator."""
+    from nerfacc_amd.data_specs import RayIntervals
+    from nerfacc_amd.estimators.prop_net import _pdf_loss, _pdf_loss_mean
+    rng = np.random.default_rng(15)
+    for R, Q1, K1 in ((100_003, 17, 65), (513, 17, 65), (40, 65, 65), (7, 3, 2), (300, 129, 33), (1, 2, 1)):
+        def mk(n):
+            v = np.sort(rng.uniform(0, 1, (R, n)).astype(np.float32), -1)
+            c = np.sort(rng.uniform(0, 1, (R, n)).astype(np.float32), -1)
+            return torch.from_numpy(v).to(dev), torch.from_numpy(c).to(dev)
+        qv, qc0 = mk(Q1); kv, kc0 = mk(K1)
+        qc, kc = qc0.clone().requires_grad_(True), kc0.clone().requires_grad_(True)
+        m = _pdf_loss_mean(RayIntervals(vals=qv), qc, RayIntervals(vals=kv), kc)
+        assert m.dim() == 0
+        (m * 3.0).backward()
+        qc2, kc2 = qc0.clone().requires_grad_(True), kc0.clone().requires_grad_(True)
+        ref = _pdf_loss(RayIntervals(vals=qv), qc2, RayIntervals(vals=kv), kc2).mean()
+        (ref * 3.0).backward()
+        assert_close(m, ref, atol=1e-7, rtol=2e-5)
+        assert_close(kc.grad, kc2.grad, atol=1e-9, rtol=1e-5)
+        assert_close(qc.grad, qc2.grad, atol=1e-8, rtol=1e-5)
+        # twice the same launch: the same bits (per-wave partial sums, no atomics)
+        m2 = _pdf_loss_mean(RayIntervals(vals=qv), qc0, RayIntervals(vals=kv), kc0)
+        assert torch.equal(m2, m.detach())
+    kc = kc0.clone().requires_grad_(True)
+    _pdf_loss_mean(RayIntervals(vals=qv), qc0, RayIntervals(vals=kv), kc).backward()
+    assert kc.grad is not None and torch.isfinite(kc.grad).all()
+
+
 # ----------------------------------------------------------------------------- full-size properties (BASELINE cfg 2)
 def test_full_size_properties(dev):
     """1024x1024 rays through a 128^3 grid at ~10% occupancy: size-independent invariants."""
