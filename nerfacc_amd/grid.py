@@ -419,6 +419,7 @@ def _traverse_onepass(dev, rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted,
 
 
 CONE_RUNS = os.environ.get("NERFACC_AMD_CONE_RUNS", "1") != "0"   # 0: the serial count + fill passes (A/B testing)
+ALIVE_LIST_FRACTION = float(os.environ.get("NERFACC_AMD_ALIVE_FRACTION", "0.75"))   # test-mode loop: below this share of alive rays only they are walked
 CONE_WALK = os.environ.get("NERFACC_AMD_CONE_WALK", "1") != "0"   # 0: the count pass over the brick-packed grid (grid.hip) instead of walk.hip's DDA (A/B testing)
 CONE_BIN_THRESHOLD = 1.25   # cone-angle walk: bin the rays when a wave of 64 neighbours crosses this many times its mean ray's cells
 
@@ -472,7 +473,7 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
                 return out
         alive = None   # ids of the alive rays, when only they are walked
         if (rays_mask is not None and n_alive is not None and (use_runs or use_cone_runs) and not binned
-                and 0 <= n_alive and 4 * n_alive < 3 * n_rays):
+                and 0 <= n_alive and n_alive < ALIVE_LIST_FRACTION * n_rays):
             alive = torch.nonzero_static(rays_mask, size=int(n_alive)).view(-1).to(torch.int32)
             sm_cnts = torch.zeros(n_rays, dtype=torch.int64, device=dev)          # (the rays not listed keep these)
             terminate = near_planes.clone() if return_terminate else None
