@@ -835,8 +835,11 @@ def parity_check(w, oracle_out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # (defaults: 100 steps = a 150 ms timed region.  The loop is driven by the host -- two size reads per step -- and the hosts of
+    #  the pool occasionally stall a process for 3-30 ms: in a 30 ms region one such stall doubled `ms_per_step` of a run whose
+    #  kernels all had their usual durations, profiles/README.md)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rays", type=int, default=1024 * 1024)
     ap.add_argument("--res", type=int, default=0,
                     help="grid resolution; default: 128 on one GPU (BASELINE cfg 2), 256 (the shared grid of cfg 4) on several")
