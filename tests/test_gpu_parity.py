@@ -90,6 +90,17 @@ def test_cone_walk_forms_agree_and_match_oracle(dev, oracle):
             L, Rr = riv["vals"][riv["is_left"]], riv["vals"][riv["is_right"]]
             assert (ref[0].cpu().numpy() == rsm["ray_indices"][keep]).all()
             assert (ref[1].cpu().numpy() == L).all() and (ref[2].cpu().numpy() == Rr).all()
+            # rays without geometry (NaN / inf origin or direction): no samples in any form (DESIGN: divergences), nobody hangs
+            o2, d2 = o.copy(), d.copy()
+            o2[0, 0] = np.nan; o2[1, 2] = np.inf; d2[2, 1] = np.nan; d2[3, 0] = -np.inf; d2[4] = np.nan
+            args2 = (T(o2, dev), T(d2, dev)) + args[2:]
+            outs2 = []
+            for walk, refill in ((True, None), (False, None), (True, "0")):
+                na.grid.CONE_WALK = walk
+                os.environ.pop("NFA_REFILL", None) if refill is None else os.environ.__setitem__("NFA_REFILL", refill)
+                outs2.append(na.grid._traverse_samples(*args2, **kw))
+            assert all(torch.equal(x, y) for got in outs2[1:] for x, y in zip(outs2[0], got))
+            assert (outs2[0][3][:5, 1] == 0).all()
     finally:
         na.grid.CONE_WALK = saved[0]
         if saved[1] is None:
