@@ -194,6 +194,12 @@ int nfa_traverse_onepass_walk(const nfa_traverse_args *args, const uint32_t *bit
  * the order.  scratch: 1024 + n_rays bytes. */
 int nfa_bin_rays(const float *rays_o, const float *rays_d, int64_t n_rays, const float *box, int32_t *order,
                  void *scratch, nfa_stream_t stream);
+/* Between two iterations of the test-mode loop (ref: examples/utils.py:409-414): mask[r] = opacity[r] <= opacity_max &&
+ * packed_info[r].count == n_samples (the ray is not opaque yet and used its whole budget), alive[0 .. *count) = the ids of
+ * the rays with mask 1 (ascending inside stretches of 8192 rays, the stretches in arbitrary order: a ray_order for
+ * nfa_traverse_runs / nfa_traverse_cone_walk with n_order = *count), *count = their number.  One launch. */
+int nfa_alive_rays(const float *opacity, const int64_t *packed_info /*[n_rays,2]*/, int64_t n_samples, float opacity_max,
+                   int64_t n_rays, uint8_t *mask, int32_t *alive, int64_t *count, nfa_stream_t stream);
 /* The same for nested levels (aabbs[n_grids][6], finest first; e.g. rays that start inside the finest box): the key is the
  * number of cell boundaries the ray crosses from near_plane on, summed over the levels (the length inside level l but
  * outside level l - 1, times sum_k |d_k| res_k / extent_k).  ray_order of nfa_traverse_cone_runs / nfa_traverse_runs. */

@@ -591,6 +591,57 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_intervals_kernel(int64_t 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The test-mode loop's bookkeeping between two iterations (ref examples/utils.py:409-414:
+// ray_mask = (opacity <= 1 - early_stop_eps) & (samples taken == n_samples)) as ONE launch: the mask, the list of the alive
+// rays (what the next traversal walks) and their number.  The torch composition was ten launches (<=, ==, &, sum, the four of
+// nonzero_static, a cast, a copy) -- on a small scene more than the iteration's kernels.  A workgroup owns ALIVE_PER_WG
+// consecutive rays and appends its alive ones, in ascending order, at an offset taken from one atomic counter: the list is
+// ascending inside a workgroup's stretch and the stretches come in the order the workgroups finish (the walk's results do not
+// depend on the list's order).
+constexpr int ALIVE_THREADS = 1024, ALIVE_PER_THREAD = 8, ALIVE_PER_WG = ALIVE_THREADS * ALIVE_PER_THREAD;
+__global__ __launch_bounds__(ALIVE_THREADS) void alive_rays_kernel(const float *__restrict__ opacity, const longlong2 *__restrict__ packed_info,
+                                                                  int64_t n_samples, float thre, int64_t n_rays, uint8_t *__restrict__ mask,
+                                                                  int32_t *__restrict__ alive, unsigned long long *__restrict__ count)
+{
+    __shared__ int32_t s_wave[ALIVE_THREADS / 64];
+    __shared__ unsigned long long s_base;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * ALIVE_PER_WG + (int64_t)threadIdx.x * ALIVE_PER_THREAD;
+    uint32_t bits = 0u;
+#pragma unroll
+    for (int k = 0; k < ALIVE_PER_THREAD; ++k) {
+        const int64_t r = r0 + k;
+        if (r < n_rays) {
+            const bool a = (opacity[r] <= thre) && (packed_info[r].y == n_samples);
+            mask[r] = a ? 1 : 0;
+            bits |= (a ? 1u : 0u) << k;
+        }
+    }
+    const int32_t c = __builtin_popcount(bits);
+    int32_t incl = c;   // inclusive scan over the wave, then over the workgroup's waves
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t u = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += u;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < ALIVE_THREADS / 64; ++w) {
+        const int32_t x = s_wave[w];
+        before += w < wave ? x : 0;
+        total += x;
+    }
+    if (threadIdx.x == 0) s_base = total > 0 ? atomicAdd(count, (unsigned long long)total) : 0ull;
+    __syncthreads();
+    int64_t o = (int64_t)s_base + before + incl - c;
+#pragma unroll
+    for (int k = 0; k < ALIVE_PER_THREAD; ++k)
+        if ((bits >> k) & 1u) alive[o++] = (int32_t)(r0 + k);
+}
+
 }  // namespace nfa
 
 using namespace nfa;
@@ -637,6 +688,21 @@ int nfa_bin_rays(const float *rays_o, const float *rays_d, int64_t n_rays, const
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, s, hist);
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(grid), dim3(256), 0, s, bins, n_rays, per_block, hist, order);
     NFA_CHECK_LAUNCH("bin_rays");
+    return NFA_OK;
+}
+
+int nfa_alive_rays(const float *opacity, const int64_t *packed_info, int64_t n_samples, float opacity_max, int64_t n_rays,
+                   uint8_t *mask, int32_t *alive, int64_t *count, nfa_stream_t stream)
+{
+    NFA_REQUIRE(n_rays >= 0 && n_rays < ((int64_t)1 << 31) && count, "alive_rays: bad arguments");
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(count, 0, sizeof(int64_t), s) != hipSuccess) { set_error("alive_rays: memset failed"); return NFA_EHIP; }
+    if (n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(opacity && packed_info && mask && alive, "alive_rays: null pointer");
+    const unsigned grid = (unsigned)((n_rays + ALIVE_PER_WG - 1) / ALIVE_PER_WG);
+    hipLaunchKernelGGL(alive_rays_kernel, dim3(grid), dim3(ALIVE_THREADS), 0, s, opacity, reinterpret_cast<const longlong2 *>(packed_info),
+                       n_samples, opacity_max, n_rays, mask, alive, reinterpret_cast<unsigned long long *>(count));
+    NFA_CHECK_LAUNCH("alive_rays");
     return NFA_OK;
 }
 

@@ -427,7 +427,8 @@ CONE_BIN_THRESHOLD = 1.25   # cone-angle walk: bin the rays when a wave of 64 ne
 @torch.no_grad()
 def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size, cone_angle,
                       rays_mask=None, traverse_steps_limit=None, t_sorted=None, t_indices=None, hits=None,
-                      return_terminate=False, near_hint=None, bin_rays=False, stats_sink=None, speculate=True, n_alive=None):
+                      return_terminate=False, near_hint=None, bin_rays=False, stats_sink=None, speculate=True, n_alive=None,
+                      alive_list=None):
     """Sampler fast path: (ray_indices, t_starts, t_ends, packed_info) straight from the traversal.
 
     Same values as ``intervals.vals[is_left]``, ``intervals.vals[is_right]``,
@@ -443,7 +444,8 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
     rays get no samples, every other ray at most ``traverse_steps_limit``.  ``n_alive``: the number of True entries of
     ``rays_mask`` when the caller knows it (the test-mode loop reads it anyway): with fewer than three quarters of the rays
     alive only those are walked, packed into dense waves -- a dead ray then costs no lane (it used to cost its wave the
-    lane's slot for as long as the wave's longest alive ray walked).
+    lane's slot for as long as the wave's longest alive ray walked).  ``alive_list``: the ids of those rays when the caller has
+    them already (int32, at least ``n_alive`` entries: ``nfa_alive_rays``); used whatever the share.
     """
     limit = -1 if traverse_steps_limit is None else int(traverse_steps_limit)
     use_runs = float(step_size) > 0.0 and float(cone_angle) == 0.0 and _walk_supported(binaries)
@@ -472,7 +474,12 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
             if out is not None:
                 return out
         alive = None   # ids of the alive rays, when only they are walked
-        if (rays_mask is not None and n_alive is not None and (use_runs or use_cone_runs) and not binned
+        if (alive_list is not None and n_alive is not None and rays_mask is not None and (use_runs or use_cone_runs) and not binned
+                and 0 <= n_alive <= alive_list.numel() and alive_list.dtype == torch.int32 and alive_list.device == dev):
+            alive = alive_list[:int(n_alive)]
+            sm_cnts = torch.zeros(n_rays, dtype=torch.int64, device=dev)          # (the rays not listed keep these)
+            terminate = near_planes.clone() if return_terminate else None
+        elif (rays_mask is not None and n_alive is not None and (use_runs or use_cone_runs) and not binned
                 and 0 <= n_alive and n_alive < ALIVE_LIST_FRACTION * n_rays):
             alive = torch.nonzero_static(rays_mask, size=int(n_alive)).view(-1).to(torch.int32)
             sm_cnts = torch.zeros(n_rays, dtype=torch.int64, device=dev)          # (the rays not listed keep these)

@@ -81,8 +81,11 @@ def render_rays_test_mode(
     opc_thre = 1 - early_stop_eps
     n_visible = None  # device counter of the samples that pass alpha_thre on the fused path
 
+    alive = alive_count = None    # the alive rays' ids and their number, written by nfa_alive_rays at the end of an iteration
+    n_alive = num_rays
     while iter_samples < max_samples:
-        n_alive = int(ray_mask.sum().item())
+        if alive_count is not None:
+            n_alive = int(alive_count.item())
         if n_alive == 0:
             break
         n_samples = max(min(num_rays // n_alive, 64), min_samples)
@@ -91,7 +94,8 @@ def render_rays_test_mode(
         ray_indices, t_starts, t_ends, packed_info, termination_planes = _traverse_samples(
             rays_o, rays_d, estimator.binaries, estimator.aabbs, near_planes, far_planes, render_step_size,
             cone_angle, rays_mask=ray_mask, traverse_steps_limit=n_samples, t_sorted=t_sorted, t_indices=t_indices,
-            hits=hits, return_terminate=True, near_hint=near_plane if iter_samples == n_samples else None, n_alive=n_alive)
+            hits=hits, return_terminate=True, near_hint=near_plane if iter_samples == n_samples else None, n_alive=n_alive,
+            alive_list=alive)
 
         n_counted = 0
         if ray_indices.numel() > 0:
@@ -126,7 +130,18 @@ def render_rays_test_mode(
                 accumulate_along_rays_(weights, values=(ts_v + te_v)[..., None] / 2.0, ray_indices=ri_v, outputs=depth)
                 n_counted = ri_v.shape[0]
         near_planes = termination_planes
-        ray_mask = torch.logical_and(opacity.view(-1) <= opc_thre, packed_info[:, 1] == n_samples)
+        if packed_info.is_contiguous() and packed_info.dtype == torch.int64 and opacity.dtype == torch.float32:
+            # alive = not opaque yet and the whole budget used (:409-414): mask, list and count in one launch
+            if alive is None:
+                alive = torch.empty(num_rays, dtype=torch.int32, device=device)
+                alive_count = torch.zeros(1, dtype=torch.int64, device=device)
+            ray_mask = torch.empty(num_rays, dtype=torch.bool, device=device)
+            with torch.cuda.device(device):
+                B.call("nfa_alive_rays", B.ptr(opacity), B.ptr(packed_info), int(n_samples), float(opc_thre), num_rays,
+                       B.ptr(ray_mask), B.ptr(alive), B.ptr(alive_count), B.stream())
+        else:
+            ray_mask = torch.logical_and(opacity.view(-1) <= opc_thre, packed_info[:, 1] == n_samples)
+            alive, alive_count, n_alive = None, None, int(ray_mask.sum().item())
         total_samples += n_counted  # samples that entered the accumulation (:416)
 
     if n_visible is not None:
