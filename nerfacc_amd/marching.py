@@ -95,7 +95,7 @@ def render_rays_test_mode(
             rays_o, rays_d, estimator.binaries, estimator.aabbs, near_planes, far_planes, render_step_size,
             cone_angle, rays_mask=ray_mask, traverse_steps_limit=n_samples, t_sorted=t_sorted, t_indices=t_indices,
             hits=hits, return_terminate=True, near_hint=near_plane if iter_samples == n_samples else None, n_alive=n_alive,
-            alive_list=alive)
+            alive_list=alive, speculate=False)   # (an iteration is host-bound: the plain size read is cheaper than the side-stream one)
 
         n_counted = 0
         if ray_indices.numel() > 0:
