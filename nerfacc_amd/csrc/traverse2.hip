@@ -397,6 +397,9 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_runs_kernel(int64_t n_ray
 // then the end t_first + m * inc of each of its samples.  is_right is false exactly at chain starts, is_left
 // is false exactly before a chain start (or the end of the ray's edges).  Same batch / chunk structure as
 // expand_runs_kernel; one lane per ray stages that ray's records (it needs the running count of chain starts).
+#ifdef NFA_EXP_IV_WAVES
+__attribute__((amdgpu_waves_per_eu(NFA_EXP_IV_WAVES, NFA_EXP_IV_WAVES)))
+#endif
 __global__ __launch_bounds__(64 * EXP_WPB) void expand_intervals_kernel(int64_t n_rays, float dt, const int32_t *__restrict__ run_cnts,
                                                                const unsigned long long *__restrict__ runs, int32_t max_runs,
                                                                const longlong2 *__restrict__ iv_packed_info,
