@@ -939,7 +939,11 @@ __device__ __forceinline__ bool cone_ray_masked(const nfa_traverse_args &a, cons
 }
 
 // one ray per lane, from its first span to its last
+#ifndef NFA_CONE_WALK_WAVES
+#define NFA_CONE_WALK_WAVES 6   /* 89 -> 80 registers: 6 waves per SIMD instead of 5; cfg 5's traversal 10.6 -> 10.1 ms (4 waves 11.4, 8 spill: 10.8) */
+#endif
 template <bool FUSED>
+__attribute__((amdgpu_waves_per_eu(NFA_CONE_WALK_WAVES, NFA_CONE_WALK_WAVES)))
 __global__ __launch_bounds__(256) void cone_walk_kernel(const nfa_traverse_args a, const ConeParams p)
 {
     const int64_t n_walk = p.order ? p.n_order : a.n_rays;
@@ -978,6 +982,9 @@ __global__ __launch_bounds__(256) void cone_walk_kernel(const nfa_traverse_args 
 // lanes are still walking, sets up new rays (and the next spans of rays that crossed into another level) on the free
 // lanes, and re-enters.  Per ray the same functions as cone_walk_kernel: identical results.
 template <bool FUSED, bool STAGED /* the event list travels with the lane (n_grids <= 4) */>
+#ifdef NFA_CONE_REFILL_WAVES
+__attribute__((amdgpu_waves_per_eu(NFA_CONE_REFILL_WAVES, NFA_CONE_REFILL_WAVES)))
+#endif
 __global__ __launch_bounds__(256) void cone_refill_kernel(const nfa_traverse_args a, const ConeParams p)
 {
     static_assert(!(FUSED && STAGED), "a fused walk has no event list");
