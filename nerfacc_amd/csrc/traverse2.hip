@@ -26,6 +26,11 @@ constexpr int EXP_QMAX = NFA_EXP_QMAX;  // runs staged per batch (EXP_RPW * max_
 #ifndef NFA_EXP_IV_QMAX
 #define NFA_EXP_IV_QMAX 256
 #endif
+#ifndef NFA_EXP_RUNS_QMAX
+#define NFA_EXP_RUNS_QMAX 1024  /* one group; 256 (2 more waves per SIMD) measured 2 % slower here (156 vs 152.5 us), where it made expand_intervals 26 % faster */
+#endif
+constexpr int EXP_RUNS_QMAX = NFA_EXP_RUNS_QMAX;  // expand_runs stages a batch's records this many at a time (>= 32: one ray's)
+static_assert(EXP_RUNS_QMAX >= 32 && EXP_RUNS_QMAX <= EXP_QMAX, "expand_runs: a ray's records must fit the staging area");
 constexpr int EXP_IV_QMAX = NFA_EXP_IV_QMAX;  // expand_intervals stages a batch's records this many at a time (>= 32: one ray's)
 static_assert(EXP_IV_QMAX >= 32 && EXP_IV_QMAX <= EXP_QMAX, "expand_intervals: a ray's records must fit the staging area");
 #ifndef NFA_EXP_WPB
@@ -207,8 +212,8 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_runs_kernel(int64_t n_ray
                                                           float *__restrict__ t_mids, int64_t *__restrict__ ray_indices, int vec, float cone,
                                                           int64_t capacity)
 {
-    __shared__ uint32_t s_pos[EXP_WPB][EXP_QMAX];
-    __shared__ float s_t0[EXP_WPB][EXP_QMAX];
+    __shared__ uint32_t s_pos[EXP_WPB][EXP_RUNS_QMAX];
+    __shared__ float s_t0[EXP_WPB][EXP_RUNS_QMAX];
     __shared__ __attribute__((aligned(16))) int32_t s_own[EXP_WPB][256];  // entry that starts at each output of the current chunk
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     uint32_t *pos = s_pos[wave];
@@ -218,39 +223,54 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_runs_kernel(int64_t n_ray
     for (int64_t batch = (int64_t)blockIdx.x * EXP_WPB + wave; batch < n_batches; batch += (int64_t)gridDim.x * EXP_WPB) {
         const int64_t r0 = batch * EXP_RPW;
         const int64_t ray = r0 + lane;
-        const bool own = lane < EXP_RPW && ray < n_rays;
-        int32_t c = 0, c_real = 0;
+        const int n_loc = (int)min((int64_t)EXP_RPW, n_rays - r0);
+        const bool own_all = lane < n_loc;
+        int32_t c_all = 0, c_real = 0;
         int64_t s = 0, n = 0;
-        if (own) {
+        if (own_all) {
             const longlong2 row = packed_info[ray];
             s = row.x;
             n = row.y;
             c_real = MODE == EXP_RAY_INDICES ? (n > 0 ? 1 : 0) : run_cnts[ray];  // (ray indices: the ray is one "run")
-            c = (c_real > max_runs) ? 1 : c_real;  // overflowed ray: one sentinel entry
+            c_all = (c_real > max_runs) ? 1 : c_real;  // overflowed ray: one sentinel entry
         }
-        const int64_t W0 = __shfl(s, 0, 64);
-        const int last_lane = (int)min((int64_t)EXP_RPW, n_rays - r0) - 1;
+        int32_t incl_all = c_all;
+#pragma unroll
+        for (int off = 1; off < EXP_RPW; off <<= 1) {
+            const int32_t u = __shfl_up(incl_all, off, 64);
+            if (lane >= off) incl_all += u;
+        }
+        if (MODE == EXP_RAY_INDICES) {
+            const int64_t W0b = __shfl(s, 0, 64);
+            const int64_t W1b = min((int64_t)__shfl(s + n, n_loc - 1, 64), capacity);
+            if (W1b - W0b >= ((int64_t)1 << 27)) {
+                // the packed 27-bit positions below cannot address this window (rays of millions of samples): plain
+                // cooperative fill, still coalesced
+                for (int rl = 0; rl < n_loc; ++rl) {
+                    const int64_t s_r = __shfl(s, rl, 64), n_r = __shfl(n, rl, 64);
+                    for (int64_t i = lane; i < n_r; i += 64) ray_indices[s_r + i] = r0 + rl;
+                }
+                continue;
+            }
+        }
+        // The batch's records are staged EXP_RUNS_QMAX at a time: the rays [a, b) whose records fit (with the default, the
+        // worst case of 32 rays x 32 records, always one group: the smaller staging area that lifted expand_intervals from 14
+        // to 24 waves per CU does nothing for this kernel, which is bound by its write stream).
+        for (int a = 0; a < n_loc;) {
+        const int32_t before = __shfl(incl_all - c_all, a, 64);
+        const int b = a + __popcll(__ballot(lane >= a && lane < n_loc && incl_all - before <= EXP_RUNS_QMAX));
+        const bool own = lane >= a && lane < b;
+        const int32_t c = own ? c_all : 0;
+        const int32_t incl = incl_all - before;   // (lanes a .. b-1)
+        const int64_t W0 = __shfl(s, a, 64);
+        const int last_lane = b - 1;
         // (capacity: the output arrays may have been allocated before the total was known to the host; nothing is written
         //  beyond them, the caller re-runs the expansion in that case)
         const int64_t W1 = min((int64_t)__shfl(s + n, last_lane, 64), capacity);
-        int32_t incl = c;
-#pragma unroll
-        for (int off = 1; off < EXP_RPW; off <<= 1) {
-            const int32_t u = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += u;
-        }
-        const int32_t Q = __shfl(incl, EXP_RPW - 1, 64);
+        const int32_t Q = __shfl(incl, last_lane, 64);
         // overflow flag per local ray as a wave-uniform mask
         const unsigned long long ovf_mask = __ballot(own && c_real > max_runs);
-        if (MODE == EXP_RAY_INDICES && W1 - W0 >= ((int64_t)1 << 27)) {
-            // the packed 27-bit positions below cannot address this window (rays of millions of samples): plain
-            // cooperative fill, still coalesced
-            for (int rl = 0; rl <= last_lane; ++rl) {
-                const int64_t s_r = __shfl(s, rl, 64), n_r = __shfl(n, rl, 64);
-                for (int64_t i = lane; i < n_r; i += 64) ray_indices[s_r + i] = r0 + rl;
-            }
-            continue;
-        }
+        a = b;
         __builtin_amdgcn_wave_barrier();
         {   // staging: lane -> (ray rl, half); the two half-waves take alternate slots of every ray.  The loads of
             // different slots do not depend on each other (slot-major records: one 256 B line per slot and batch).
@@ -387,6 +407,7 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_runs_kernel(int64_t n_ray
             }
         }
         __builtin_amdgcn_wave_barrier();
+        }  // groups of rays
     }
 }
 
@@ -743,7 +764,7 @@ int nfa_expand_runs(int64_t n_rays, float step_size, const int32_t *run_cnts, co
     if (n_rays == 0) return NFA_OK;
     NFA_REQUIRE(run_cnts && runs && packed_info && ray_indices && (t_mids || (t_starts && t_ends)),
                 "expand_runs: null pointer");
-    NFA_REQUIRE(max_runs >= 1 && max_runs * EXP_RPW <= EXP_QMAX, "expand_runs: max_runs must be in [1, 32]");
+    NFA_REQUIRE(max_runs >= 1 && max_runs <= EXP_RUNS_QMAX && max_runs * EXP_RPW <= EXP_QMAX, "expand_runs: max_runs must be in [1, 32]");
     NFA_REQUIRE(step_size > 0.0f, "expand_runs: step_size must be > 0");
     const int vec = ((reinterpret_cast<uintptr_t>(t_starts) | reinterpret_cast<uintptr_t>(t_ends) |
                       reinterpret_cast<uintptr_t>(t_mids) | reinterpret_cast<uintptr_t>(ray_indices)) & 15) == 0;
@@ -767,7 +788,7 @@ int nfa_expand_cone_runs(int64_t n_rays, float step_size, float cone_angle, cons
     NFA_REQUIRE(n_rays >= 0, "expand_cone_runs: negative n_rays");
     if (n_rays == 0) return NFA_OK;
     NFA_REQUIRE(run_cnts && runs && packed_info && ray_indices && t_starts && t_ends, "expand_cone_runs: null pointer");
-    NFA_REQUIRE(max_runs >= 1 && max_runs * EXP_RPW <= EXP_QMAX, "expand_cone_runs: max_runs must be in [1, 32]");
+    NFA_REQUIRE(max_runs >= 1 && max_runs <= EXP_RUNS_QMAX && max_runs * EXP_RPW <= EXP_QMAX, "expand_cone_runs: max_runs must be in [1, 32]");
     NFA_REQUIRE(step_size > 0.0f && cone_angle > 0.0f, "expand_cone_runs: step_size and cone_angle must be > 0");
     const int vec = ((reinterpret_cast<uintptr_t>(t_starts) | reinterpret_cast<uintptr_t>(t_ends) |
                       reinterpret_cast<uintptr_t>(ray_indices)) & 15) == 0;
