@@ -395,7 +395,6 @@ def algorithmic_bytes(R, M, Mv, res, G=1):
         "nfa_traverse_grids[mode=0]": R * (24 + 8) + grid + R * 8,                 # rays + planes, grid, counts
         "nfa_traverse_grids[mode=1]": R * (24 + 8) + grid + M * (4 + 4 + 8) + R * 16,  # + samples, packed_info
         "nfa_traverse_runs": R * (24 + 8) + grid + R * 8,                            # one DDA walk: rays, grid, counts
-        "nfa_traverse_onepass": R * (24 + 8) + grid + M * (4 + 4 + 8) + R * 16,      # B_trav: walk and expansion at the same time (two streams)
         "nfa_traverse_cone_runs": R * (24 + 8) + grid + R * 8,
         "nfa_expand_runs": M * (4 + 4 + 8) + R * 16,                                 # the sampler's output, once
         "nfa_expand_cone_runs": M * (4 + 4 + 8) + R * 16,
@@ -413,7 +412,7 @@ def algorithmic_bytes(R, M, Mv, res, G=1):
 
 
 #: what bounds each native call: the walk is bound by instruction issue, everything else streams
-KERNEL_BOUND = {"nfa_traverse_runs": "issue", "nfa_traverse_onepass": "issue", "nfa_traverse_cone_runs": "issue", "nfa_traverse_grids[mode=0]": "issue",
+KERNEL_BOUND = {"nfa_traverse_runs": "issue", "nfa_traverse_cone_runs": "issue", "nfa_traverse_grids[mode=0]": "issue",
                 "nfa_traverse_grids[mode=1]": "issue"}
 
 
@@ -991,9 +990,8 @@ def main():
             kernels = kernel_table(ksum, ab)
             # Op-level view: one logical op of the reference API may be several launches here.
             groups = {
-                "traverse_grids (nfa_traverse_onepass: walk and expansion at the same time on two streams, offsets by look-back; or "
-                "nfa_traverse_runs + cumsum + nfa_expand_runs [+ nfa_traverse_grids fill of overflow rays])":
-                    ["nfa_traverse_onepass", "nfa_traverse_runs", "nfa_exclusive_cumsum_pairs_stats_i64", "nfa_expand_runs",
+                "traverse_grids (nfa_traverse_runs + cumsum + nfa_expand_runs [+ nfa_traverse_grids fill of overflow rays])":
+                    ["nfa_traverse_runs", "nfa_exclusive_cumsum_pairs_stats_i64", "nfa_expand_runs",
                      "nfa_traverse_grids[mode=0]", "nfa_traverse_grids[mode=1]"],
                 "rendering fwd (render_weight_from_density + 3 accumulations, one pass)": ["nfa_render_fused_fwd"],
                 "rendering bwd (3 accumulations + render_weight_from_density, one pass)": ["nfa_render_fused_bwd"],

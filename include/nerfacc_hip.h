@@ -159,34 +159,6 @@ int nfa_pack_walk_bits(const uint8_t *binaries, int32_t n_grids, const int32_t *
 int nfa_traverse_runs(const nfa_traverse_args *args, const uint32_t *bits, int32_t *run_cnts, uint64_t *runs,
                       int32_t max_runs, int32_t *overflow_count, float near_hint, const int32_t *ray_order,
                       int64_t n_order, nfa_stream_t stream);
-/* The sampler's traverse_grids without the serial chain count pass -> cumsum + host read -> fill pass (ref:
- * cuda/csrc/grid.cu:405-471, include/data_spec.hpp:86-96): the walk and the expansion of its run records are two launches
- * that run at the same time on two streams.
- *   nfa_traverse_onepass_begin   zeroes the scratch words both launches communicate through (enqueue it first; the other
- *                                two calls must be ordered after it: same stream, or an event);
- *   nfa_traverse_onepass_expand  a few persistent workgroups (n_workgroups; enqueue BEFORE the walk, on a second stream):
- *                                take units of 64 consecutive rays in order; as soon as every unit up to theirs has been
- *                                walked, a decoupled look-back over the units' totals gives the number of samples in front;
- *                                they write the unit's rows of packed_info ({start, count}: the exact exclusive cumsum of the
- *                                counts, in ray order), run_cnts (and sm_cnts if given) and expand the run records into
- *                                t_starts / t_ends / ray_indices.  The outputs hold `capacity` elements, chosen by the caller
- *                                before the total is known; nothing is written at or beyond it;
- *   nfa_traverse_onepass_walk    the walk of nfa_traverse_runs (same arguments), publishing per unit what the expander
- *                                needs with agent-scope stores.  args->terminate_planes optional; mode 0 or 2.
- * scratch: nfa_traverse_onepass_scratch_words(n_rays) int64.  When both launches have completed: scratch[0] = total samples
- * (when it exceeds capacity the caller re-runs with nfa_traverse_runs + nfa_expand_runs), scratch[1], scratch[2] = the
- * coherence sums of nfa_exclusive_cumsum_pairs_stats_i64, scratch[3] = rays with more than max_runs runs (to be filled with
- * nfa_traverse_grids(mode 1, ray_filter = run_cnts, ray_filter_min = max_runs); their output ranges are left untouched),
- * scratch[5] != 0: the expander stopped waiting because the walk made no progress (a device queue that is not serviced):
- * outputs incomplete, the caller takes the serial form. */
-int64_t nfa_traverse_onepass_scratch_words(int64_t n_rays);
-int nfa_traverse_onepass_begin(int64_t n_rays, int64_t *scratch, nfa_stream_t stream);
-int nfa_traverse_onepass_expand(int64_t n_rays, float step_size, int32_t *run_cnts, const uint64_t *runs, int32_t max_runs,
-                                int64_t *packed_info /*[n_rays,2]*/, float *t_starts, float *t_ends, int64_t *ray_indices,
-                                int64_t capacity, int64_t *sm_cnts /*[n_rays] or NULL*/, int64_t *scratch,
-                                int32_t n_workgroups, nfa_stream_t stream);
-int nfa_traverse_onepass_walk(const nfa_traverse_args *args, const uint32_t *bits, uint64_t *runs, int32_t max_runs,
-                              float near_hint, int64_t *scratch, nfa_stream_t stream);
 /* Lane -> ray assignment for nfa_traverse_runs (ray_order; NULL = identity): order[n_rays] = the ray ids sorted into 256
  * bins by the length of the ray's path through box[6] = {min xyz, max xyz} (the outermost grid box), so that the rays a
  * wave walks together are of similar length.  For batches of unrelated rays (training) the walk is ~1.6x faster;

@@ -38,9 +38,6 @@ constexpr int WK_EV = NFA_WK_EV;           // list slots per ray: 16 KiB of LDS 
 #else
 #define NFA_WALK_OCC
 #endif
-#ifndef NFA_WALK_OP_RL
-#define NFA_WALK_OP_RL 6
-#endif
 static_assert(NFA_WK_EV == 16, "the list-full test is one bit of the slot address: 16 slots");
 #ifndef NFA_WALK_LG
 #define NFA_WALK_LG 10   /* log2 of the bytes of one list slot = 4 bytes x threads per workgroup: 10 = 256 threads */
@@ -127,31 +124,19 @@ __device__ __forceinline__ void marcher_refresh(Marcher &s, float dt)
     }
 }
 
-// Where a ray's run records go: the first RL of them into the lane's LDS column (the one-pass kernel expands them from
-// there), the others -- all of them with RL == 0 -- into the slot-major global array runs[slot][ray].
-constexpr int WK_REC_STRIDE = WK_THREADS * 8;   // bytes between two slots of one lane: [RL][threads] records of 8 bytes
-// RL == WK_RL_AGENT + k: k LDS slots, and the global array written with agent-scope (write-through) 8-byte stores: the
-// records are read by a wave of another compute unit, possibly behind another L2, while this launch is still running
-// (expand_units_kernel).
-constexpr int WK_RL_AGENT = 64;
-template <int RL>
-__device__ __forceinline__ void store_run(const WalkParams &p, char *rec_col, int32_t slot, int64_t tid, unsigned long long rec)
+// A ray's run records go to the slot-major global array runs[slot][ray] (a slot of 32 consecutive rays is one 256-byte line
+// for the expansion)
+__device__ __forceinline__ void store_run(const WalkParams &p, int32_t slot, int64_t tid, unsigned long long rec)
 {
-    constexpr int LDS_SLOTS = RL >= WK_RL_AGENT ? RL - WK_RL_AGENT : RL;
-    if (LDS_SLOTS > 0 && slot < LDS_SLOTS) *reinterpret_cast<unsigned long long *>(rec_col + slot * WK_REC_STRIDE) = rec;
-    else if (slot < p.max_runs) {
-        if (RL >= WK_RL_AGENT) __hip_atomic_store((p.runs + tid) + (int64_t)slot * p.n_rays, rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else (p.runs + tid)[(int64_t)slot * p.n_rays] = rec;
-    }
+    if (slot < p.max_runs) (p.runs + tid)[(int64_t)slot * p.n_rays] = rec;
 }
 
 // n samples t0, t0 + inc, ... join the ray's run list; a run record {t_first : f32 | k_start : 31, continues_previous : 1}
 // is written when a run starts (its length is the next record's k_start, or the ray's count)
-template <int RL>
-__device__ __forceinline__ void marcher_emit(Marcher &s, float t0, float inc, uint32_t n, const WalkParams &p, int64_t tid, char *rec_col)
+__device__ __forceinline__ void marcher_emit(Marcher &s, float t0, float inc, uint32_t n, const WalkParams &p, int64_t tid)
 {
     if (!(s.continuous && inc == s.run_inc)) {
-        store_run<RL>(p, rec_col, s.n_runs, tid,
+        store_run(p, s.n_runs, tid,
                       (unsigned long long)f32_bits(t0) |
                           ((unsigned long long)((uint32_t)s.n_samples | (s.continuous ? 0x80000000u : 0u)) << 32));
         s.n_runs++;
@@ -192,9 +177,8 @@ __device__ __forceinline__ void marcher_approach(const WalkParams &p, const Appr
 // threshold", so progress never has to be remembered).  Returns 2: progress was made (call again if the loop declines the
 // entry again), 1: nothing to do here (if the loop declines again, the general path is next), 0: march.h's general stepper
 // has to do the entry.
-template <int RL>
 __device__ __forceinline__ int marcher_cross(Marcher &s, float thr, int type, float dt, float half, int32_t limit, const WalkParams &p,
-                                             const ApproachLds &tb, int64_t tid, char *rec_col)
+                                             const ApproachLds &tb, int64_t tid)
 {
     int progress = 0;
     if (s.at_near) {
@@ -227,7 +211,7 @@ __device__ __forceinline__ int marcher_cross(Marcher &s, float thr, int type, fl
             if (n_b == 0u || n_b * q > room || (n_b + 1u) * q <= room) return 0;
             if (!(bits_f32(bt + (n_b - 1u) * q) + half < thr)) break;      // it stops inside this binade: the lock-step loop's case
             n_b = min(n_b, budget);
-            if (type == WK_OCC) marcher_emit<RL>(s, t, s.fstep, n_b, p, tid, rec_col);
+            if (type == WK_OCC) marcher_emit(s, t, s.fstep, n_b, p, tid);
             s.t_last = bits_f32(bt + n_b * q);
             progress = 1;
             if (n_b == budget) break;
@@ -238,7 +222,7 @@ __device__ __forceinline__ int marcher_cross(Marcher &s, float thr, int type, fl
         if (!(t1 + half < thr)) break;
         const float tn = t1 + dt;
         if (tn == t1 || (f32_bits(tn) >> 23) == (f32_bits(t1) >> 23)) return 0;
-        if (type == WK_OCC) marcher_emit<RL>(s, t1, tn - t1, 1u, p, tid, rec_col);
+        if (type == WK_OCC) marcher_emit(s, t1, tn - t1, 1u, p, tid);
         s.t_last = tn;
         progress = 1;
     }
@@ -248,9 +232,8 @@ __device__ __forceinline__ int marcher_cross(Marcher &s, float thr, int type, fl
 
 // The same entry through march.h's stepper: binade boundaries, exact ties, the way from the near plane (tabulated),
 // denormal / huge distances, no-progress steps.
-template <int RL>
 __device__ __forceinline__ void marcher_general(Marcher &s, float thr, int type, float dt, float half, int32_t limit,
-                                                const WalkParams &p, int64_t tid, char *rec_col)
+                                                const WalkParams &p, int64_t tid)
 {
     Stepper stp;
     stepper_init(stp);
@@ -269,7 +252,7 @@ __device__ __forceinline__ void marcher_general(Marcher &s, float thr, int type,
             if (!emit) s.t_last = thr;
             break;
         }
-        if (emit) marcher_emit<RL>(s, t, inc, n, p, tid, rec_col);
+        if (emit) marcher_emit(s, t, inc, n, p, tid);
         s.t_last = tn;
     }
     if (type == WK_EMPTY) s.continuous = 0;
@@ -285,10 +268,9 @@ __device__ __forceinline__ void marcher_general(Marcher &s, float thr, int type,
 // flags as integers, the only branches are the run-record store and the loop itself.  A lane that cannot be served
 // (binade end, first march, no stable increment) stops consuming entries; when no lane can go on, those lanes cross
 // together (marcher_cross, or march.h's general stepper) and the loop resumes.
-template <bool HAS_LIMIT, int RL>
+template <bool HAS_LIMIT>
 __device__ __forceinline__ void marcher_run(Marcher &s, const char *col /* LDS column of this lane */, int32_t cnt, uint32_t ev_span,
-                                            float dt, int32_t limit_arg, const WalkParams &p, const ApproachLds &tb, int64_t tid,
-                                            char *rec_col /* LDS column of this lane's run records (RL > 0) */)
+                                            float dt, int32_t limit_arg, const WalkParams &p, const ApproachLds &tb, int64_t tid)
 {
     const int32_t limit = HAS_LIMIT ? limit_arg : 0;   // (traverse_steps_limit: the test-mode loop only)
     const float half = dt * 0.5f;
@@ -332,7 +314,7 @@ __device__ __forceinline__ void marcher_run(Marcher &s, const char *col /* LDS c
             // run records: a new one unless the samples continue the open run (same increment, no gap)
             const int32_t new_run = emit & ((s.continuous & (int32_t)(s.fstep == s.run_inc)) ^ 1);
             if (new_run)
-                store_run<RL>(p, rec_col, s.n_runs, tid,
+                store_run(p, s.n_runs, tid,
                               (unsigned long long)bt | ((unsigned long long)((uint32_t)s.n_samples | ((uint32_t)s.continuous << 31)) << 32));
             s.n_runs += new_run;
             s.n_chains += new_run & (s.continuous ^ 1);
@@ -350,10 +332,10 @@ __device__ __forceinline__ void marcher_run(Marcher &s, const char *col /* LDS c
         if (!__any(blocked)) break;
         if (blocked) {
             int r = 0;
-            if (!tried) r = marcher_cross<RL>(s, thr, type, dt, half, limit, p, tb, tid, rec_col);
+            if (!tried) r = marcher_cross(s, thr, type, dt, half, limit, p, tb, tid);
             tried = r == 1;
             if (r == 0) {
-                marcher_general<RL>(s, thr, type, dt, half, limit, p, tid, rec_col);
+                marcher_general(s, thr, type, dt, half, limit, p, tid);
                 if (is_span_entry(ev_span, k)) s.span_tmax = *reinterpret_cast<const float *>(col + ((k + 1) << WK_LG));
                 k += adv; s.ptype = next_ptype;
             }
@@ -408,7 +390,9 @@ __device__ __forceinline__ void walk_span_setup(const nfa_traverse_args &a, cons
         else if (ahead < 0) n = (st > 0 ? a.res[ax] - 1 - c : c) + 1;
         nst[ax] = max(1, min(n, WK_MAX_RES));
     }
-    sp.tx = tdist[0]; sp.ty = tdist[1]; sp.tz = tdist[2];
+    // (+0: a distance of -0 becomes +0, so that m - t == +0 singles out the minimum in dda_step; -0 < +0 is false in the
+    //  reference's comparisons too, the value is the same)
+    sp.tx = tdist[0] + 0.0f; sp.ty = tdist[1] + 0.0f; sp.tz = tdist[2] + 0.0f;
     sp.dx = delta[0]; sp.dy = delta[1]; sp.dz = delta[2];
     sp.rem = (uint32_t)(nst[0] - 1) | ((uint32_t)(nst[1] - 1) << 10) | ((uint32_t)(nst[2] - 1) << 20) | WK_GUARD;
     // an axis walked downwards counts its reflected coordinate (2^nb - 1 - c = c ^ (2^nb - 1)) upwards: every step is "+1"
@@ -425,6 +409,54 @@ __device__ __forceinline__ void walk_span_setup(const nfa_traverse_args &a, cons
     sp.widx = widx; sp.flip = flip;
 }
 
+// single_traversal (include/utils_grid.cuh:116-142) on the walk's state; returns the exit distance m of the cell the ray
+// leaves.  The reference steps x if tx < ty && tx < tz, else y if ty < tz, else z: that is "z if tz is the minimum, else y
+// if ty is, else x" (ties go z over y over x either way), and the chosen axis' distance IS m, so its update is m + delta.
+// Written against the issue rates of common.hip.h: ONE half-rate instruction (v_min3); "is the minimum" comes from the sign
+// of m - t, every select is a v_bitop3 on those masks (the first form -- two v_min, two v_cmp, ten v_cndmask, two v_bfi --
+// was 15 half-rate + 15 full-rate instructions per cell, this one is 5 + 27).  The distances are never -0 (walk_span_setup
+// adds +0), so m - t is +0 exactly for the minimum.
+__device__ __forceinline__ float dda_step(float dx, float dy, float dz, uint32_t mx, uint32_t my, uint32_t mz, float &tx, float &ty,
+                                          float &tz, uint32_t &rem, uint32_t &widx)
+{
+#if defined(NFA_DDA_FORM) && NFA_DDA_FORM == 0   /* A/B: the first form (compares + v_cndmask) */
+    const float n = vmin_f32(ty, tz);
+    const float m0 = vmin_f32(tx, n);
+    const bool s0 = tx < n;
+    const bool s1 = ty < tz;
+    const float dsel = s0 ? dx : (s1 ? dy : dz);
+    const float nm0 = m0 + dsel;
+    const float ty1 = s1 ? nm0 : ty, tz1 = s1 ? tz : nm0;
+    tx = s0 ? nm0 : tx;
+    ty = s0 ? ty : ty1;
+    tz = s0 ? tz : tz1;
+    rem -= s0 ? 1u : (s1 ? (1u << 10) : (1u << 20));
+    const uint32_t M0 = s0 ? mx : (s1 ? my : mz);
+    uint32_t filled0;
+    asm("v_bfi_b32 %0, %1, %2, -1" : "=v"(filled0) : "v"(M0), "v"(widx));
+    filled0 += M0 & 7u;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(widx) : "v"(M0), "v"(filled0), "v"(widx));
+    return m0;
+#endif
+    const float m = min3_f32(tx, ty, tz);
+    const uint32_t kz = mask_less(m, tz), ky = mask_less(m, ty);   // ~0: that axis is NOT the minimum
+    const uint32_t go_x = kz & ky, go_y = kz & ~ky;                // ~0: the step goes along x / along y (else z: ~kz)
+    const float nm = m + sel_mask(kz, sel_mask(ky, dx, dy), dz);
+    tx = sel_mask(go_x, nm, tx);
+    ty = sel_mask(go_y, nm, ty);
+    tz = sel_mask(kz, tz, nm);
+    rem -= sel_mask(kz, sel_mask(ky, 1u, 1u << 10), 1u << 20);
+    // +1 on the chosen axis' bits of the interleaved index: fill the other bits with ones so that the carry runs through
+    // them, add the axis' lowest bit, keep the axis' bits of the sum (a carry out of the top bit is dropped: one step
+    // outside the grid wraps to a valid cell, which is never used)
+    const uint32_t M = sel_mask(kz, sel_mask(ky, mx, my), mz);
+    uint32_t filled;
+    asm("v_bitop3_b32 %0, %1, %2, %2 bitop3:0xcf" : "=v"(filled) : "v"(M), "v"(widx));   // (M & widx) | ~M
+    filled += M & 7u;
+    widx = sel_mask(M, filled, widx);                                                   // (M & sum) | (~M & widx)
+    return m;
+}
+
 // One cell of the walk.  (w_cur, i_cur): the word of the grid copy that holds the occupancy bit of the cell the ray is in
 // and the bit's index -- requested when the ray entered the cell, one cell's worth of instructions ago; `open`: the kind of
 // the ray's open list entry.  Steps the DDA, looks at the current cell's bit, requests the next cell's word into the same
@@ -433,27 +465,7 @@ __device__ __forceinline__ void walk_cell(float dx, float dy, float dz, uint32_t
                                           float &ty, float &tz, uint32_t &rem, uint32_t &widx, uint32_t &ev_addr, float &m_out,
                                           uint32_t &w_cur, uint32_t &i_cur, int32_t &open, const uint32_t *__restrict__ bits, char *ev_lds)
 {
-    const float n = vmin_f32(ty, tz);
-    const float m = vmin_f32(tx, n);          // exit distance of this cell (clamped to this_tmax by phase 2)
-    // single_traversal (include/utils_grid.cuh:116-142): x if tx < ty && tx < tz, else y if ty < tz, else z.
-    // The chosen axis' distance IS m, so its update is m + delta.
-    const bool s0 = tx < n;
-    const bool s1 = ty < tz;
-    const float dsel = s0 ? dx : (s1 ? dy : dz);
-    const float nm = m + dsel;
-    const float ty1 = s1 ? nm : ty, tz1 = s1 ? tz : nm;
-    tx = s0 ? nm : tx;
-    ty = s0 ? ty : ty1;
-    tz = s0 ? tz : tz1;
-    rem -= s0 ? 1u : (s1 ? (1u << 10) : (1u << 20));
-    // +1 on the chosen axis' bits of the interleaved index: fill the other bits with ones so that the carry runs through
-    // them, add the axis' lowest bit, keep the axis' bits of the sum (a carry out of the top bit is dropped: one step
-    // outside the grid wraps to a valid cell, which is never used)
-    const uint32_t M = s0 ? mx : (s1 ? my : mz);
-    uint32_t filled;
-    asm("v_bfi_b32 %0, %1, %2, -1" : "=v"(filled) : "v"(M), "v"(widx));       // (M & widx) | ~M
-    filled += M & 7u;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(widx) : "v"(M), "v"(filled), "v"(widx));   // (M & sum) | (~M & widx)
+    const float m = dda_step(dx, dy, dz, mx, my, mz, tx, ty, tz, rem, widx);   // exit distance of this cell (clamped to this_tmax by phase 2)
     const uint32_t changed = __builtin_amdgcn_ubfe(w_cur, i_cur, 1u) ^ (uint32_t)open;   // bit (i_cur & 31) of the current cell's word
     i_cur = widx ^ flip;
 #if defined(NFA_WALK_EXP) && NFA_WALK_EXP == 1   /* timing experiment: no load at all */
@@ -490,10 +502,10 @@ __device__ __forceinline__ void approach_to_lds(ApproachLds &tb, const WalkParam
 }
 
 // One ray through the grid(s): phases 1 and 2 alternate until the event walk is over.  Leaves the marcher's state (sample
-// count, run count, chain count, last distance); run records go to store_run<RL>.
-template <bool FUSED, bool HAS_LIMIT, int RL>
+// count, run count, chain count, last distance); run records go to store_run.
+template <bool FUSED, bool HAS_LIMIT>
 __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkParams &p, int64_t tid, char *ev_lds, uint32_t lane_off,
-                                         char *rec_col, const ApproachLds &tb, Marcher &s)
+                                         const ApproachLds &tb, Marcher &s)
 {
     char *const col = ev_lds + lane_off;
     const float dt = a.step_size;
@@ -613,7 +625,7 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
         int32_t cnt = (int32_t)(ev_addr >> WK_LG);
         if (finished && has_open) { cnt += 1; has_open = 0; }
 #ifndef NFA_WALK_NO_PHASE2
-        marcher_run<HAS_LIMIT, RL>(s, col, cnt, ev_span, dt, limit, p, tb, tid, rec_col);
+        marcher_run<HAS_LIMIT>(s, col, cnt, ev_span, dt, limit, p, tb, tid);
 #endif
         if (finished || (limit > 0 && s.n_samples >= limit)) break;
         // the open entry moves to slot 0
@@ -643,7 +655,7 @@ NFA_WALK_OCC __global__ __launch_bounds__(WK_THREADS) void walk_kernel(const nfa
             continue;
         }
         Marcher s;
-        walk_ray<FUSED, HAS_LIMIT, 0>(a, p, tid, ev_lds, lane_off, nullptr, tb, s);
+        walk_ray<FUSED, HAS_LIMIT>(a, p, tid, ev_lds, lane_off, tb, s);
         if (a.terminate_planes) a.terminate_planes[tid] = s.t_last;
         a.sm_cnts[tid] = s.n_samples;
         if (a.iv_cnts) a.iv_cnts[tid] = s.n_samples + s.n_chains;  // edges = samples + one leading edge per chain
@@ -706,26 +718,10 @@ __device__ __forceinline__ bool cone_cell(const nfa_traverse_args &a, const Cone
 {
     const float step_size = a.step_size, cone = a.cone_angle;
     const int32_t limit = a.traverse_steps_limit;
-    const float n = vmin_f32(sp.ty, sp.tz);
-    const float m = vmin_f32(sp.tx, n);
-    const float t_traverse = vmin_f32(m, this_tmax);
     const uint32_t w_half = (i_cur & 32u) ? (uint32_t)(w_cur >> 32) : (uint32_t)w_cur;
     const bool occupied = __builtin_amdgcn_ubfe(w_half, i_cur, 1u) != 0u;   // bit (i_cur & 31) of the half
-    // single_traversal (include/utils_grid.cuh:116-142), as in walk_cell
-    const bool s0 = sp.tx < n;
-    const bool s1 = sp.ty < sp.tz;
-    const float dsel = s0 ? sp.dx : (s1 ? sp.dy : sp.dz);
-    const float nm = m + dsel;
-    const float ty1 = s1 ? nm : sp.ty, tz1 = s1 ? sp.tz : nm;
-    sp.tx = s0 ? nm : sp.tx;
-    sp.ty = s0 ? sp.ty : ty1;
-    sp.tz = s0 ? sp.tz : tz1;
-    sp.rem -= s0 ? 1u : (s1 ? (1u << 10) : (1u << 20));
-    const uint32_t M = s0 ? sp.mx : (s1 ? sp.my : sp.mz);
-    uint32_t filled;
-    asm("v_bfi_b32 %0, %1, %2, -1" : "=v"(filled) : "v"(M), "v"(sp.widx));
-    filled += M & 7u;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(sp.widx) : "v"(M), "v"(filled), "v"(sp.widx));
+    const float m = dda_step(sp.dx, sp.dy, sp.dz, sp.mx, sp.my, sp.mz, sp.tx, sp.ty, sp.tz, sp.rem, sp.widx);
+    const float t_traverse = vmin_f32(m, this_tmax);
     const bool done = (sp.rem & WK_GUARD) != WK_GUARD;
     // The next cell's bit: the low six index bits are two of each coordinate, so an aligned 64-bit word of the copy is a
     // 4 x 4 x 4 brick; it stays in registers while the ray is inside it (with unrelated rays every load of a wave is 64
@@ -1084,411 +1080,6 @@ __global__ __launch_bounds__(256) void cone_refill_kernel(const nfa_traverse_arg
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// traverse_grids without the serial chain walk -> cumsum -> expansion (the sampler's form of it: ray_indices, t_starts,
-// t_ends, packed_info; ref: cuda/csrc/grid.cu:405-471 runs count pass, cumsums + host read, fill pass).
-//
-// The walk is bound by instruction issue and touches almost no memory; the expansion of its run records is a pure
-// write stream.  One after the other they take 182 + 20 + 142 us on BASELINE cfg 2.  Here they are two launches that
-// run AT THE SAME TIME on two streams:
-//
-//   walk_publish_kernel  the walk, one workgroup per 256 rays as before; each wave (a UNIT of 64 consecutive rays) leaves
-//                        its run records and {samples, runs} per ray in global memory with agent-scope 8-byte stores,
-//                        waits for those stores and publishes status[unit] = {AGG, total of the 64 counts};
-//   expand_units_kernel  a few persistent waves (launched first, on the second stream) that take units in order from a
-//                        counter: a look-back over the status words (nearest published inclusive prefix + the totals in
-//                        between: rocPRIM's decoupled look-back, run by whoever expands the unit rather than by whoever
-//                        walked it) gives the number of samples in front of the unit as soon as every unit up to it
-//                        has been walked; the wave publishes {PFX, inclusive prefix}, writes the unit's rows of
-//                        packed_info and expands its records (staged in LDS) into the outputs.
-//
-// Why two kernels and not one: all waves of a launch get the same register budget.  Three single-launch forms were
-// built and measured (bit-exact, all slower than the two serial launches' 345 us): every wave expands the unit it has
-// just walked, 418 us (waves idle behind the slowest walk in front of them); persistent waves taking walk and
-// expansion jobs from two counters, never waiting while a walk job is left, 612 us (16 unrelated walks per compute unit:
-// the four waves of a workgroup must walk neighbouring rays at the same time to share the grid copy's lines in L1 -- the
-// walk alone 314 us instead of 203); the same in workgroup-synchronous rounds of 4 adjacent units, 429 us (at 128
-// registers only 4 waves fit a SIMD, so every expanding wave displaces a walking one, and the walk needs its 4 waves
-// to hide its own latencies).  Across launches the hardware does mix register budgets: 4 walking waves + an expanding one.
-//
-// Integers only: packed_info is the exact exclusive cumsum of the counts in ray order whatever the order of
-// completion (determinism).  The only data that crosses waves are 8-byte words written and read with
-// agent-scope atomics (status words, {samples, runs} per ray, run records), each published behind a full wait for the
-// producing wave's stores.  The expander waits only for walks, which never wait for anything; it holds a bounded
-// number of wave slots, so the walk's workgroups always find room; should the walk not run at all (a queue that is not
-// serviced) the expander gives up after a bounded number of polls and reports it, and the host takes the serial form.
-// The outputs were sized by the host before the total is known (capacity): nothing is written beyond them, the total
-// is reported, and the host falls back to the serial form when it was too small.
-// Register budgets: a SIMD has 512 registers per lane; the walk takes 109 (112 allocated), so 4 walking waves leave 64 for
-// one expanding wave beside them.  The expander wants 76; held to 64 (8 waves per SIMD) it spills a few values that are
-// reloaded once per unit, outside its chunk loop (checked in the generated code: no scratch access and no wait for
-// memory inside the loop -- see onepass_expand_chunks).
-#ifndef NFA_OP_EXP_WAVES
-#define NFA_OP_EXP_WAVES 8
-#endif
-#ifndef NFA_OP_WALK_WAVES
-#define NFA_OP_WALK_WAVES 5
-#endif
-#if NFA_OP_WALK_WAVES > 0
-#define NFA_OP_WALK_OCC __attribute__((amdgpu_waves_per_eu(NFA_OP_WALK_WAVES, NFA_OP_WALK_WAVES)))
-#else
-#define NFA_OP_WALK_OCC
-#endif
-#if NFA_OP_EXP_WAVES > 0
-#define NFA_OP_EXP_OCC __attribute__((amdgpu_waves_per_eu(NFA_OP_EXP_WAVES, NFA_OP_EXP_WAVES)))
-#else
-#define NFA_OP_EXP_OCC
-#endif
-constexpr int OP_RL = NFA_WALK_OP_RL;       // run records per ray staged in LDS by the expander; later ones are read from global memory
-constexpr int OP_SENTINEL = 32;             // entry index of "this ray's samples are filled by the serial kernel"
-constexpr int OP_WAVES = 4;                 // waves per expander workgroup (they never cooperate)
-constexpr unsigned long long ST_AGG = 1ull << 62, ST_PFX = 2ull << 62, ST_VAL = (1ull << 62) - 1ull;
-
-struct OnePassParams {
-    unsigned long long *status;   // [n_units], zeroed
-    uint32_t *gave_up;            // [1], zeroed: set when the expander stopped waiting for the walk
-    unsigned long long *meta;     // [3], zeroed: total samples, sum of wave maxima (sampled), sum of counts (sampled)
-    unsigned long long *cnt_runs; // [n_rays] {samples : 32 | runs : 32}, handed from the walk to the expander
-    longlong2 *packed_info;       // [n_rays] {start, count}
-    float *t_starts, *t_ends;     // [capacity]
-    int64_t *ray_indices;         // [capacity]
-    int64_t capacity;
-    int64_t n_units;              // ceil(n_rays / 64)
-    int32_t vec;                  // outputs 16-byte aligned
-    uint32_t max_polls;           // patience of a waiting expander wave
-    long long *profile;           // NFA_OP_PROFILE builds: 10 words per expander wave, else NULL
-};
-
-__device__ __forceinline__ int64_t wave_sum_i64(int64_t v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-// a value every lane holds, moved to scalar registers (the compiler cannot know that a shuffle result is uniform)
-__device__ __forceinline__ int64_t uniform_i64(int64_t v)
-{
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
-    return (int64_t)(((uint64_t)hi << 32) | lo);
-}
-__device__ __forceinline__ uint32_t wave_ticket(uint32_t *counter)
-{
-    uint32_t t = 0;
-    if (lane_id() == 0) t = atomicAdd(counter, 1u);
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-}
-
-template <bool FUSED, bool HAS_LIMIT>
-NFA_OP_WALK_OCC __global__ __launch_bounds__(WK_THREADS) void walk_publish_kernel(const nfa_traverse_args a, const WalkParams p, const OnePassParams q)
-{
-    __shared__ __attribute__((aligned(16))) char ev_lds[(WK_EV + 1) << WK_LG];   // [WK_EV + 1][256] floats
-    __shared__ ApproachLds tb;
-    // The rays' first OP_RL run records wait in LDS and leave together when the unit is done.  (Stored one by one from the
-    // marcher with write-through stores they stalled the walk: the cell loop's wait for its grid word is a wait for
-    // every earlier memory operation of the wave, and a write-through store is acknowledged by memory -- microseconds
-    // while the expander's write stream saturates it: the walk took 850 us beside the expander instead of 181.)
-    __shared__ __attribute__((aligned(16))) unsigned long long rec_lds[OP_RL * WK_THREADS];   // [OP_RL][threads]
-    approach_to_lds(tb, p);
-    __syncthreads();
-    const int lane = lane_id();
-    const uint32_t lane_off = 4u * threadIdx.x;
-    char *const rec_col = reinterpret_cast<char *>(rec_lds) + 8u * threadIdx.x;
-    const int64_t unit = (int64_t)blockIdx.x * (WK_THREADS / 64) + (threadIdx.x >> 6);
-    if (unit >= q.n_units) return;   // (the whole wave)
-    const int64_t tid = unit * 64 + lane;
-    const bool active = tid < a.n_rays;
-    int32_t n = 0, c_real = 0;
-    if (active) {
-        if (a.mode == 2 && a.rays_mask != nullptr && !a.rays_mask[tid]) {
-            if (a.terminate_planes) a.terminate_planes[tid] = a.near_planes[tid];
-        } else {
-            Marcher s;
-            walk_ray<FUSED, HAS_LIMIT, WK_RL_AGENT + OP_RL>(a, p, tid, ev_lds, lane_off, rec_col, tb, s);
-            if (a.terminate_planes) a.terminate_planes[tid] = s.t_last;
-            n = s.n_samples;
-            c_real = s.n_runs;
-            if (n > (1 << 21) && c_real <= p.max_runs) c_real = p.max_runs + 1;   // (27-bit positions inside a unit's window)
-        }
-    }
-    const int64_t total = wave_sum_i64((int64_t)n);
-    if (total >= ((int64_t)1 << 30)) c_real = n > 0 ? p.max_runs + 1 : c_real;   // rays of millions of samples: all of them to the serial fill
-    if (active) {
-        __hip_atomic_store(&q.cnt_runs[tid], (unsigned long long)(uint32_t)n | ((unsigned long long)(uint32_t)c_real << 32),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (c_real > p.max_runs) atomicAdd(p.overflow, 1);
-    }
-    {   // the records kept in LDS: slot-major, one 512-byte line per slot and wave
-        const int32_t c_st = (active && c_real <= p.max_runs) ? min(c_real, OP_RL) : 0;
-        int32_t c_max = c_st;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) c_max = max(c_max, __shfl_xor(c_max, off, 64));
-        for (int32_t i = 0; i < c_max; ++i)
-            if (i < c_st)
-                __hip_atomic_store((p.runs + tid) + (int64_t)i * p.n_rays, *reinterpret_cast<const unsigned long long *>(rec_col + i * WK_REC_STRIDE),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if ((unit & 7) == 0) {   // coherence sample for the caller's next batch (nfa_exclusive_cumsum_pairs_stats_i64's measure)
-        int32_t m = n;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
-        if (lane == 0) { atomicAdd(&q.meta[1], (unsigned long long)m); atomicAdd(&q.meta[2], (unsigned long long)total); }
-    }
-    // every store of this wave (run records, counts) has left before the unit is announced
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0)
-        __hip_atomic_store(&q.status[unit], ST_AGG | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// A waiting expander wave's patience: after max_polls polls of its own (or, looked at every 1024 polls, once another wave has
-// run out of patience) it stops: the walk is not running.
-__device__ __forceinline__ bool onepass_give_up(const OnePassParams &q, uint32_t polls)
-{
-    if (polls > q.max_polls) {
-        if (lane_id() == 0) __hip_atomic_store(q.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return true;
-    }
-    if ((polls & 1023u) == 0u) {
-        uint32_t g = 0u;
-        if (lane_id() == 0) g = __hip_atomic_load(q.gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return __builtin_amdgcn_readfirstlane((int)g) != 0;
-    }
-    return false;
-}
-
-// Number of samples in front of unit e, once every unit up to e has been walked; publishes the unit's inclusive prefix.
-// false: gave up waiting (q.max_polls polls without the walk making the needed progress).
-__device__ __forceinline__ bool onepass_resolve(const OnePassParams &q, int64_t e, int64_t &base)
-{
-    const int lane = lane_id();
-    uint32_t polls = 0;
-    // first the unit itself, one 8-byte load per poll (a thousand waves polling 64-word windows is half a TB/s of loads that
-    // go past every cache: the walk took 6x as long)
-    for (;;) {
-        unsigned long long st = 0ull;
-        if (lane == 0) st = __hip_atomic_load(&q.status[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__builtin_amdgcn_readfirstlane((int)(uint32_t)(st >> 32)) != 0) break;
-        if (onepass_give_up(q, ++polls)) return false;
-        __builtin_amdgcn_s_sleep(127);
-    }
-    for (;;) {
-        int64_t acc = 0, total_e = 0;
-        int64_t win = e;          // lane l looks at unit win - l; lane 0 of the first window is unit e itself
-        bool ready = true;
-        for (int hop = 0; ; ++hop) {
-            const int64_t idx = win - lane;
-            unsigned long long st = ST_PFX;   // (in front of unit 0: prefix 0)
-            if (idx >= 0) st = __hip_atomic_load(&q.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t fl = (uint32_t)(st >> 62);
-            const bool own = hop == 0 && lane == 0;
-            if (hop == 0) total_e = (int64_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)st)) |
-                                    ((int64_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(st >> 32)) & 0x3FFFFFFFu) << 32);
-            const unsigned long long pfx = __ballot(fl == 2u && !own), inv = __ballot(fl == 0u);
-            const int fp = pfx ? __builtin_ctzll(pfx) : 64;                 // nearest unit in front whose inclusive prefix is known
-            const unsigned long long need = fp == 64 ? ~0ull : ((2ull << fp) - 1ull);   // lanes 0 .. fp
-            if (inv & need) { ready = false; break; }                        // a unit in between is still being walked
-            acc += wave_sum_i64((lane <= fp && !own) ? (int64_t)(st & ST_VAL) : 0);
-            if (fp < 64) break;
-            win -= 64;
-        }
-        if (ready) {
-            acc = uniform_i64(acc);
-            base = acc;
-            if (lane == 0)
-                __hip_atomic_store(&q.status[e], ST_PFX | (unsigned long long)(acc + total_e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return true;
-        }
-        if (onepass_give_up(q, ++polls)) return false;
-        __builtin_amdgcn_s_sleep(64);
-    }
-}
-
-// The chunk loop of an expansion job: 256 outputs per step; the entries that start inside the chunk are scattered into an LDS
-// line by a cursor per ray, a "most recent entry" scan gives every output its run (traverse2.hip: expand_runs_kernel).
-// SPILL: some ray of the unit has more records than the OP_RL staged in LDS, the others are read from global memory.
-// Two instances because a global load anywhere in the loop makes the loop wait for memory: vmcnt counts loads and stores
-// together, so the wait for a (never executed) load is a wait for the previous chunk's output stores to be acknowledged --
-// the first version ran at 0.5 TB/s (1017 us for cfg 2's 516 MB) until the common case had no load in its loop.
-template <bool SPILL>
-__device__ __forceinline__ void onepass_expand_chunks(const WalkParams &p, const OnePassParams &q, float dt, int lane, int32_t *slot,
-                                                      const unsigned long long *recs, int64_t r0, int64_t tid, int64_t W0, int64_t W1,
-                                                      int32_t s_rel, int32_t c, bool ovf, int32_t n)
-{
-        // cursor over the lane's own entries: entry id = lane | index << 6; its position = s_rel + k_start
-    int32_t cur = 0;
-    int32_t next_pos = (c > 0 && n > 0) ? s_rel : 0x7FFFFFFF;   // (the first record of a ray starts at its sample 0)
-    const int64_t c_first = (W0 / 256) * 256;
-    int32_t carry_j = -1;
-    for (int64_t cb = c_first; cb < W1; cb += 256) {
-        const int32_t lo = (int32_t)(cb - W0), hi = lo + 256;
-        {   // (the -1 is made here: as a loop invariant the four registers of the vector were spilled under the kernel's register
-            //  budget and reloaded -- a load, hence a wait for the previous chunk's stores -- in every chunk)
-            int32_t m1 = -1;
-            asm volatile("" : "+v"(m1));
-            *reinterpret_cast<int4 *>(slot + 4 * lane) = make_int4(m1, m1, m1, m1);
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (;;) {
-            const bool take = next_pos < hi;
-            if (!__any(take)) break;
-            if (take) {
-                slot[next_pos - lo] = lane | ((ovf ? OP_SENTINEL : cur) << 6);
-                ++cur;
-                next_pos = 0x7FFFFFFF;
-                if (cur < c) {
-                    const uint32_t hi32 = (!SPILL || cur < OP_RL) ? (uint32_t)(recs[cur * 64 + lane] >> 32)
-                                                      : (uint32_t)(__hip_atomic_load((p.runs + tid) + (int64_t)cur * p.n_rays, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
-                    next_pos = s_rel + (int32_t)(hi32 & 0x7FFFFFFFu);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int4 o4 = *reinterpret_cast<const int4 *>(slot + 4 * lane);
-        __builtin_amdgcn_wave_barrier();
-        // most recent entry at or before each element
-        int32_t j4[4] = {o4.x, o4.y, o4.z, o4.w};
-#pragma unroll
-        for (int k = 1; k < 4; ++k) j4[k] = j4[k] >= 0 ? j4[k] : j4[k - 1];
-        int32_t ah = j4[3];
-        { int32_t u = dpp_step<0>(-1, ah); ah = ah >= 0 ? ah : u; }
-        { int32_t u = dpp_step<1>(-1, ah); ah = ah >= 0 ? ah : u; }
-        { int32_t u = dpp_step<2>(-1, ah); ah = ah >= 0 ? ah : u; }
-        { int32_t u = dpp_step<3>(-1, ah); ah = ah >= 0 ? ah : u; }
-        { int32_t u = dpp_step<4>(-1, ah); ah = ah >= 0 ? ah : u; }
-        { int32_t u = dpp_step<5>(-1, ah); ah = ah >= 0 ? ah : u; }
-        int32_t pj = dpp_prev_lane(-1, ah);
-        if (pj < 0) pj = carry_j;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) j4[k] = j4[k] >= 0 ? j4[k] : pj;
-        carry_j = nfa::last_lane(j4[3]);
-
-        const int64_t p0 = cb + 4 * lane;
-        bool valid[4];
-        float ts4[4], te4[4];
-        int64_t ri4[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int64_t pa = p0 + k;
-            const int32_t j = j4[k];
-            valid[k] = false;
-            ts4[k] = te4[k] = 0.f; ri4[k] = 0;
-            const int32_t rl = j & 63, i = j >> 6;
-            const int32_t srl = __shfl(s_rel, rl, 64);        // (all lanes take part)
-            if (pa < W0 || pa >= W1 || j < 0 || i == OP_SENTINEL) continue;   // sentinel: filled by the serial kernel
-            const unsigned long long rec = (!SPILL || i < OP_RL) ? recs[i * 64 + rl]
-                                                     : __hip_atomic_load(p.runs + (int64_t)i * p.n_rays + r0 + rl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float t0 = bits_f32((uint32_t)rec);
-            const uint32_t kk = (uint32_t)((int32_t)(pa - W0) - srl) - ((uint32_t)(rec >> 32) & 0x7FFFFFFFu);
-            const float inc = (t0 + dt) - t0;  // the run's exact per-step increment
-            // t0 + k * inc is exactly representable for every sample of a run: one fused multiply-add reproduces the serial sums
-            ts4[k] = __builtin_fmaf((float)kk, inc, t0);
-            te4[k] = __builtin_fmaf((float)(kk + 1), inc, t0);
-            ri4[k] = r0 + rl;
-            valid[k] = true;
-        }
-        if (q.vec && valid[0] && valid[1] && valid[2] && valid[3]) {
-            store_f4<true>(q.t_starts + p0, ts4[0], ts4[1], ts4[2], ts4[3]);
-            store_f4<true>(q.t_ends + p0, te4[0], te4[1], te4[2], te4[3]);
-            store_l2<true>(q.ray_indices + p0, ri4[0], ri4[1]);
-            store_l2<true>(q.ray_indices + p0 + 2, ri4[2], ri4[3]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (valid[k]) { q.t_starts[p0 + k] = ts4[k]; q.t_ends[p0 + k] = te4[k]; q.ray_indices[p0 + k] = ri4[k]; }
-        }
-    }
-}
-
-// persistent: every wave takes units in order until none is left
-NFA_OP_EXP_OCC __global__ __launch_bounds__(64 * OP_WAVES) void expand_units_kernel(int64_t n_rays, float dt, const WalkParams p, const OnePassParams q,
-                                                                    int64_t *__restrict__ sm_cnts)
-{
-    __shared__ __attribute__((aligned(16))) unsigned long long rec_lds[OP_WAVES][OP_RL * 64];   // staged run records, [slot][lane]
-    __shared__ __attribute__((aligned(16))) int32_t slot_lds[OP_WAVES][256];                    // entry that starts at each output of a chunk
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    int32_t *const slot = slot_lds[wave];
-    unsigned long long *const recs = rec_lds[wave];
-#ifndef NFA_OP_NOPRIO
-    __builtin_amdgcn_s_setprio(3);   // few waves beside many walking ones: they must not starve for issue slots
-#endif
-#ifdef NFA_OP_PROFILE
-    long long pf[6] = {0, 0, 0, 0, 0, 0};   // ticket, resolve, header, chunks, units, -
-    const long long pf_t0 = wall_clock64();
-#define PF_T() clock64()
-#define PF_ADD(i, t) pf[i] += clock64() - (t)
-#else
-#define PF_T() 0
-#define PF_ADD(i, t) (void)(t)
-#endif
-    // Units are dealt round-robin: wave w of the grid takes units w, w + n_waves, ...  (No counter: a returning atomic on ONE
-    // address, and likewise a write-through load of one address, is served by memory at about 60 ns apiece whoever asks; one
-    // ticket per unit -- 16 384 of them on cfg 2 -- put a floor of 1 ms under the kernel however many waves it had, the atomic
-    // itself took 18 us and every other memory operation queued behind it.  Tickets for blocks of 8 units removed the floor
-    // but a wave then sat on its block until the walk reached it and needed 200 us for it afterwards.)  Neighbouring units go
-    // to different waves, so the dense part of an image is spread over all of them.  A workgroup of the grid that is not
-    // resident delays its own units only: nobody waits for an expander wave.
-    const int32_t n_waves = (int32_t)gridDim.x * OP_WAVES, n_units = (int32_t)q.n_units;       // (n_units < 2^25; scalars)
-    int32_t e = __builtin_amdgcn_readfirstlane((int32_t)blockIdx.x * OP_WAVES + wave);
-    for (; e < n_units;) {
-        int64_t base = 0;
-        const long long t_b = PF_T();
-        if (!onepass_resolve(q, e, base)) break;
-        PF_ADD(1, t_b);
-        const long long t_c = PF_T();
-        const int64_t unit = e;
-        e += n_waves;
-        const int64_t r0 = unit * 64, tid = r0 + lane;
-        const bool active = tid < n_rays;
-        unsigned long long cr = 0ull;
-        if (active) cr = __hip_atomic_load(&q.cnt_runs[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int32_t n = (int32_t)(uint32_t)cr, c_real = (int32_t)(uint32_t)(cr >> 32);
-        const int64_t incl = wave_incl_sum_i64((int64_t)n);
-        const int64_t total = uniform_i64(__shfl(incl, 63, 64));
-        if (active) {
-            q.packed_info[tid] = make_longlong2(base + incl - n, (int64_t)n);
-            p.run_cnts[tid] = c_real;
-            if (sm_cnts) sm_cnts[tid] = n;
-        }
-        if (unit == q.n_units - 1 && lane == 0) q.meta[0] = (unsigned long long)(base + total);
-        const int64_t W0 = base, W1 = min(base + total, q.capacity);
-        if (total >= ((int64_t)1 << 30) || W1 <= W0) continue;
-        const bool ovf = c_real > p.max_runs;
-        const int32_t c = ovf ? 1 : c_real;
-        {   // stage the rays' first OP_RL records in LDS (slot-major in memory: one 512-byte line per slot, independent loads)
-            const int32_t c_st = ovf ? 0 : min(c, OP_RL);
-            int32_t c_max = c_st;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) c_max = max(c_max, __shfl_xor(c_max, off, 64));
-            for (int i0 = 0; i0 < c_max; i0 += 4) {   // (four loads in flight per lane)
-                unsigned long long rec[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    rec[u] = (i0 + u < OP_RL && i0 + u < c_st) ? __hip_atomic_load((p.runs + tid) + (int64_t)(i0 + u) * p.n_rays, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (i0 + u < OP_RL && i0 + u < c_max) recs[(i0 + u) * 64 + lane] = rec[u];
-            }
-        }
-        const int32_t s_rel = (int32_t)(incl - n);          // the ray's first output, relative to W0
-        PF_ADD(2, t_c);
-        const long long t_d = PF_T();
-        if (__any(c > OP_RL)) onepass_expand_chunks<true>(p, q, dt, lane, slot, recs, r0, tid, W0, W1, s_rel, c, ovf, n);
-        else onepass_expand_chunks<false>(p, q, dt, lane, slot, recs, r0, tid, W0, W1, s_rel, c, ovf, n);
-        PF_ADD(3, t_d);
-#ifdef NFA_OP_PROFILE
-        pf[4]++;
-#endif
-        __builtin_amdgcn_wave_barrier();
-    }
-#ifdef NFA_OP_PROFILE
-    if (lane == 0 && q.profile) {
-        long long *o = q.profile + ((int64_t)blockIdx.x * OP_WAVES + wave) * 10;
-        for (int i = 0; i < 6; ++i) o[i] = pf[i];
-        o[8] = pf_t0; o[9] = wall_clock64();
-    }
-#endif
-}
-
 }  // namespace nfa
 
 using namespace nfa;
@@ -1629,114 +1220,6 @@ int nfa_traverse_cone_walk(const nfa_traverse_args *pa, const uint32_t *bits, in
         else       hipLaunchKernelGGL((cone_walk_kernel<false>), dim3(grid), dim3(256), 0, s, a, p);
     }
     NFA_CHECK_LAUNCH("traverse_cone_walk");
-    return NFA_OK;
-}
-
-int64_t nfa_traverse_onepass_scratch_words(int64_t n_rays) { return 8 + (n_rays + 63) / 64 + n_rays; }
-
-// scratch: [0] total samples, [1], [2] coherence sums, [3] rays with too many runs, [5] "the expander gave
-// up", [8 ...] one status word per unit of 64 rays (all of that zeroed by _begin), then {samples, runs} per ray
-static void onepass_params(OnePassParams &q, int64_t n_rays, int64_t *scratch)
-{
-    const int64_t n_units = (n_rays + 63) / 64;
-    q.meta = reinterpret_cast<unsigned long long *>(scratch);
-    q.gave_up = reinterpret_cast<uint32_t *>(scratch + 5);
-    q.status = reinterpret_cast<unsigned long long *>(scratch + 8);
-    q.cnt_runs = reinterpret_cast<unsigned long long *>(scratch + 8 + n_units);
-    q.packed_info = nullptr; q.t_starts = q.t_ends = nullptr; q.ray_indices = nullptr;
-    q.capacity = 0; q.n_units = n_units; q.vec = 0; q.max_polls = 0;
-    q.profile = nullptr;
-#ifdef NFA_OP_PROFILE
-    {   // debugging aid: env NFA_OP_PROFILE_PTR = address of a device buffer of 10 int64 per expander wave
-        const char *e = getenv("NFA_OP_PROFILE_PTR");
-        if (e) q.profile = reinterpret_cast<long long *>(strtoull(e, nullptr, 0));
-    }
-#endif
-}
-
-int nfa_traverse_onepass_begin(int64_t n_rays, int64_t *scratch, nfa_stream_t stream)
-{
-    NFA_REQUIRE(n_rays >= 0 && n_rays < (int64_t)1 << 31 && scratch, "traverse_onepass_begin: bad arguments");
-    if (hipMemsetAsync(scratch, 0, sizeof(int64_t) * (size_t)(8 + (n_rays + 63) / 64), as_stream(stream)) != hipSuccess) {
-        set_error("traverse_onepass_begin: memset failed");
-        return NFA_EHIP;
-    }
-    return NFA_OK;
-}
-
-int nfa_traverse_onepass_expand(int64_t n_rays, float step_size, int32_t *run_cnts, const uint64_t *runs, int32_t max_runs,
-                                int64_t *packed_info, float *t_starts, float *t_ends, int64_t *ray_indices, int64_t capacity,
-                                int64_t *sm_cnts, int64_t *scratch, int32_t n_workgroups, nfa_stream_t stream)
-{
-    NFA_REQUIRE(n_rays >= 0 && n_rays < (int64_t)1 << 31 && scratch, "traverse_onepass_expand: bad arguments");
-    if (n_rays == 0) return NFA_OK;
-    NFA_REQUIRE(run_cnts && runs && packed_info, "traverse_onepass_expand: null pointer");
-    NFA_REQUIRE(capacity >= 0 && (capacity == 0 || (t_starts && t_ends && ray_indices)), "traverse_onepass_expand: outputs missing");
-    NFA_REQUIRE(max_runs >= 1 && max_runs <= 32, "traverse_onepass_expand: max_runs must be in [1, 32]");
-    NFA_REQUIRE(step_size > 0.0f, "traverse_onepass_expand: step_size must be > 0");
-    NFA_REQUIRE(n_workgroups >= 1 && n_workgroups <= 4096, "traverse_onepass_expand: 1..4096 workgroups");
-    WalkParams p;
-    memset(&p, 0, sizeof(p));
-    p.run_cnts = run_cnts;
-    p.runs = reinterpret_cast<unsigned long long *>(const_cast<uint64_t *>(runs));
-    p.max_runs = max_runs;
-    p.n_rays = n_rays;
-    OnePassParams q;
-    onepass_params(q, n_rays, scratch);
-    q.packed_info = reinterpret_cast<longlong2 *>(packed_info);
-    q.t_starts = t_starts; q.t_ends = t_ends; q.ray_indices = ray_indices;
-    q.capacity = capacity;
-    q.vec = ((reinterpret_cast<uintptr_t>(t_starts) | reinterpret_cast<uintptr_t>(t_ends) | reinterpret_cast<uintptr_t>(ray_indices)) & 15) == 0;
-    q.max_polls = 50000u;   // ~0.1 s of waiting for one unit: the walk is not running
-    const unsigned grid = (unsigned)min((int64_t)n_workgroups, (q.n_units + OP_WAVES - 1) / OP_WAVES);
-    hipLaunchKernelGGL(expand_units_kernel, dim3(grid), dim3(64 * OP_WAVES), 0, as_stream(stream), n_rays, step_size, p, q, sm_cnts);
-    NFA_CHECK_LAUNCH("traverse_onepass_expand");
-    return NFA_OK;
-}
-
-int nfa_traverse_onepass_walk(const nfa_traverse_args *pa, const uint32_t *bits, uint64_t *runs, int32_t max_runs, float near_hint,
-                              int64_t *scratch, nfa_stream_t stream)
-{
-    NFA_REQUIRE(pa != nullptr, "traverse_onepass_walk: null args");
-    const nfa_traverse_args &a = *pa;
-    NFA_REQUIRE(a.n_rays >= 0 && a.n_rays < (int64_t)1 << 31, "traverse_onepass_walk: n_rays out of range");
-    NFA_REQUIRE(scratch, "traverse_onepass_walk: scratch is null");
-    if (a.n_rays == 0) return NFA_OK;
-    NFA_REQUIRE(a.step_size > 0.0f && a.cone_angle == 0.0f, "traverse_onepass_walk: needs step_size > 0 and cone_angle == 0");
-    NFA_REQUIRE(a.mode == 0 || a.mode == 2, "traverse_onepass_walk: mode must be 0 (all rays) or 2 (rays_mask + limit)");
-    NFA_REQUIRE(a.mode != 2 || a.traverse_steps_limit > 0, "traverse_steps_limit must be > 0 when over_allocate is true");
-    NFA_REQUIRE(a.rays_o && a.rays_d && a.aabbs && a.near_planes && a.far_planes && bits && runs, "traverse_onepass_walk: null pointer");
-    NFA_REQUIRE(max_runs >= 1 && max_runs <= 32, "traverse_onepass_walk: max_runs must be in [1, 32]");
-    NFA_REQUIRE(a.n_grids >= 1 && a.res[0] > 0 && a.res[1] > 0 && a.res[2] > 0, "traverse_onepass_walk: bad grid shape");
-    NFA_REQUIRE(a.res[0] <= WK_MAX_RES && a.res[1] <= WK_MAX_RES && a.res[2] <= WK_MAX_RES,
-                "traverse_onepass_walk: at most 512 cells per axis (use nfa_traverse_grids beyond)");
-    const bool fused = !a.t_sorted && !a.t_indices && !a.hits;
-    NFA_REQUIRE(fused || (a.t_sorted && a.t_indices && a.hits), "traverse_onepass_walk: t_sorted, t_indices and hits must be given together");
-    NFA_REQUIRE(!fused || a.n_grids == 1, "traverse_onepass_walk: in-kernel intersection supports one grid");
-    WalkParams p;
-    p.bits = bits;
-    p.lay = walk_layout(a.res);
-    NFA_REQUIRE(p.lay.bits >= 5 && ((int64_t)a.n_grids << p.lay.bits) < ((int64_t)1 << 31), "traverse_onepass_walk: grid too large");
-    p.run_cnts = nullptr;
-    p.runs = reinterpret_cast<unsigned long long *>(runs);
-    p.max_runs = max_runs;
-    p.n_rays = a.n_rays;
-    p.overflow = reinterpret_cast<int32_t *>(scratch + 3);
-    p.order = nullptr;
-    p.n_order = a.n_rays;
-    if (near_hint == near_hint) approach_table_build(p.approach, near_hint, a.step_size);
-    else p.approach.n = 0;
-    OnePassParams q;
-    onepass_params(q, a.n_rays, scratch);
-    hipStream_t s = as_stream(stream);
-    constexpr int UPW = WK_THREADS / 64;
-    const unsigned grid = (unsigned)((q.n_units + UPW - 1) / UPW);
-    const bool lim = a.traverse_steps_limit > 0;
-    if (fused && !lim)      hipLaunchKernelGGL((walk_publish_kernel<true, false>), dim3(grid), dim3(WK_THREADS), 0, s, a, p, q);
-    else if (fused)         hipLaunchKernelGGL((walk_publish_kernel<true, true>), dim3(grid), dim3(WK_THREADS), 0, s, a, p, q);
-    else if (!lim)          hipLaunchKernelGGL((walk_publish_kernel<false, false>), dim3(grid), dim3(WK_THREADS), 0, s, a, p, q);
-    else                    hipLaunchKernelGGL((walk_publish_kernel<false, true>), dim3(grid), dim3(WK_THREADS), 0, s, a, p, q);
-    NFA_CHECK_LAUNCH("traverse_onepass_walk");
     return NFA_OK;
 }
 

@@ -335,89 +335,6 @@ def _pinned_meta(dev) -> Tensor:
     return buf
 
 
-# 1: walk and expansion at the same time on two streams (csrc/walk.hip: walk_publish_kernel + expand_units_kernel).  Off by
-# default: bit-identical results, but on MI355X the walk loses more from sharing its compute units with the expander
-# (181 -> 230-290 us on BASELINE cfg 2) than the overlap gives back: 390-410 us against 345 us for the serial form
-# ("one-pass traversal").
-ONEPASS = os.environ.get("NERFACC_AMD_ONEPASS", "0") != "0"
-ONEPASS_SERIAL = os.environ.get("NERFACC_AMD_ONEPASS_SERIAL", "0") != "0"
-EXPANDER_WGS = int(os.environ.get("NERFACC_AMD_EXPANDER_WGS", "512"))   # persistent expander workgroups (4 waves each)
-
-
-def _traverse_onepass(dev, rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indices, hits, near_planes, far_planes,
-                      step_size, limit, masked, near_hint, return_terminate, stats_sink, spec_key):
-    """The constant-step traversal with the walk and the expansion running at the same time (``nfa_traverse_onepass_*``:
-    the expander on a second stream takes units of 64 rays as the walk finishes them).  Returns what
-    :func:`_traverse_samples` returns, or None when the remembered capacity was too small for this batch (or the expander
-    gave up waiting for a walk that was not running) -- the caller then takes the serial path, which sizes its outputs
-    from the counts."""
-    n_rays = rays_o.shape[0]
-    cap = _SPEC_CAPACITY[spec_key]
-    terminate = torch.empty(n_rays, dtype=torch.float32, device=dev) if return_terminate else None
-    a = _traverse_args(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indices, hits, near_planes, far_planes,
-                       step_size, 0.0, limit, 2 if masked else 0)
-    a.terminate_planes = B.ptr(terminate)
-    bits = _get_walk_bits(binaries)
-    run_cnts = torch.empty(n_rays, dtype=torch.int32, device=dev)
-    runs = torch.empty((MAX_RUNS, n_rays), dtype=torch.int64, device=dev)  # slot-major run records
-    packed_info = torch.empty((n_rays, 2), dtype=torch.int64, device=dev)
-    scratch = torch.empty(int(B.load().nfa_traverse_onepass_scratch_words(n_rays)), dtype=torch.int64, device=dev)
-    t_starts = torch.empty(cap, dtype=torch.float32, device=dev)
-    t_ends = torch.empty(cap, dtype=torch.float32, device=dev)
-    ray_indices = torch.empty(cap, dtype=torch.int64, device=dev)
-    main = torch.cuda.current_stream()
-    side = _side_stream(dev)
-
-    def launch():
-        B.call("nfa_traverse_onepass_begin", n_rays, B.ptr(scratch), B.stream())
-        if ONEPASS_SERIAL:   # (measurements: the same two kernels one after the other on one stream)
-            B.call("nfa_traverse_onepass_walk", C.byref(a), B.ptr(bits), B.ptr(runs), MAX_RUNS,
-                   float("nan") if near_hint is None else float(near_hint), B.ptr(scratch), B.stream())
-            B.call("nfa_traverse_onepass_expand", n_rays, float(step_size), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
-                   B.ptr(packed_info), B.ptr(t_starts), B.ptr(t_ends), B.ptr(ray_indices), cap, None, B.ptr(scratch),
-                   EXPANDER_WGS, B.stream())
-            return
-        ready = torch.cuda.Event(); ready.record(main)
-        with torch.cuda.stream(side):       # the expander first: it holds a few wave slots and waits for the walk's units
-            side.wait_event(ready)
-            B.call("nfa_traverse_onepass_expand", n_rays, float(step_size), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
-                   B.ptr(packed_info), B.ptr(t_starts), B.ptr(t_ends), B.ptr(ray_indices), cap, None, B.ptr(scratch),
-                   EXPANDER_WGS, B.stream())
-            expanded = torch.cuda.Event(); expanded.record(side)
-        B.call("nfa_traverse_onepass_walk", C.byref(a), B.ptr(bits), B.ptr(runs), MAX_RUNS,
-               float("nan") if near_hint is None else float(near_hint), B.ptr(scratch), B.stream())
-        main.wait_event(expanded)
-
-    B.call_group("nfa_traverse_onepass", launch)
-    host = _pinned_meta(dev)
-    host.copy_(scratch[:8], non_blocking=True)
-    done = torch.cuda.Event(); done.record()
-    done.synchronize()
-    n_sm, s_max, s_sum, n_overflow, _, gave_up = (int(v) for v in host[:6].tolist())  # the one device->host read of the traversal
-    n_overflow &= 0xFFFFFFFF
-    if gave_up & 0xFFFFFFFF:
-        return None
-    _SPEC_CAPACITY[spec_key] = ((int(n_sm * 1.03) + 4096) // 4096) * 4096
-    if stats_sink is not None and s_sum > 0:
-        stats_sink["max_over_mean"] = 64.0 * s_max / s_sum
-    if n_sm > cap:
-        return None
-    t_starts, t_ends, ray_indices = t_starts[:n_sm], t_ends[:n_sm], ray_indices[:n_sm]
-    if n_overflow > 0 and n_sm > 0:
-        # rays with more run records than the walk keeps: the serial kernel fills their (untouched) output ranges
-        sm_starts, sm_cnts = packed_info[:, 0].contiguous(), packed_info[:, 1].contiguous()
-        a.mode = 1
-        a.terminate_planes = None
-        a.sm_starts, a.sm_cnts = B.ptr(sm_starts), B.ptr(sm_cnts)
-        a.sm_t_starts, a.sm_t_ends, a.sm_ray_indices = B.ptr(t_starts), B.ptr(t_ends), B.ptr(ray_indices)
-        a.ray_filter, a.ray_filter_min = B.ptr(run_cnts), MAX_RUNS
-        _launch(a)
-    info = tag_trusted(packed_info, n_sm)
-    tag_ray_indices(ray_indices, n_rays, info)
-    out = (ray_indices, t_starts, t_ends, packed_info)
-    return (*out, terminate) if return_terminate else out
-
-
 CONE_RUNS = os.environ.get("NERFACC_AMD_CONE_RUNS", "1") != "0"   # 0: the serial count + fill passes (A/B testing)
 ALIVE_LIST_FRACTION = float(os.environ.get("NERFACC_AMD_ALIVE_FRACTION", "0.75"))   # test-mode loop: below this share of alive rays only they are walked
 CONE_WALK = os.environ.get("NERFACC_AMD_CONE_WALK", "1") != "0"   # 0: the count pass over the brick-packed grid (grid.hip) instead of walk.hip's DDA (A/B testing)
@@ -466,13 +383,6 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
         masked = rays_mask is not None or limit > 0
         spec_key = (n_rays, dev.index)
         binned = bool(bin_rays) and n_rays >= 4096
-        if use_runs and ONEPASS and SPECULATE and not binned and _SPEC_CAPACITY.get(spec_key, 0) > 0:
-            # one launch: walk + device-side output offsets + expansion (csrc/walk.hip: walk_onepass_kernel), into arrays
-            # sized from the previous batch of this shape
-            out = _traverse_onepass(dev, rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indices, hits, near_planes,
-                                    far_planes, step_size, limit, masked, near_hint, return_terminate, stats_sink, spec_key)
-            if out is not None:
-                return out
         alive = None   # ids of the alive rays, when only they are walked
         if (alive_list is not None and n_alive is not None and rays_mask is not None and (use_runs or use_cone_runs) and not binned
                 and 0 <= n_alive <= alive_list.numel() and alive_list.dtype == torch.int32 and alive_list.device == dev):

@@ -1813,12 +1813,13 @@ def test_speculative_expansion_capacity(dev, oracle):
     assert sizes[1] > 2 * sizes[0] and sizes[2] < sizes[1] and sizes[4] == 0
 
 
-def _onepass_traversal_cases(dev, oracle):
-    """nfa_traverse_onepass_* (the walk and a persistent expander running at the same time on two streams, offsets from a
-    decoupled look-back: csrc/walk.hip) against the serial form (walk, cumsum, expansion) and the oracle, bit for bit: packed_info is the exact exclusive cumsum in ray order whatever order the waves finish
-    in.  Cases: one level with in-kernel intersection, nested levels, ray counts that are not multiples of 64 or 256,
-    speckled grids (more run records per ray than the LDS slots: spill; more than MAX_RUNS: serial fill), a mask with a
-    step limit, per-ray near planes, capacities equal to / just below / far above the total, an empty grid."""
+def test_speculative_expansion_capacity_and_oracle(dev, oracle):
+    """The sampler launches the expansion of the run records into arrays sized from the PREVIOUS batch of the same shape,
+    before this batch's total has reached the host (grid.py: _SPEC_CAPACITY): whatever capacity was remembered -- equal to
+    the total, just below it, far above it -- the results are those of the plain order (read the total, then allocate),
+    and the oracle's.  Cases: one level with in-kernel intersection, nested levels, ray counts that are not multiples of
+    64 or 256, speckled grids (more run records per ray than MAX_RUNS: serial fill), a mask with a step limit, per-ray near
+    planes, an empty grid."""
     from nerfacc_amd import grid as G
     rng = np.random.default_rng(77)
     cases = [  # (R, res, levels, occupancy kind, step, masked)
@@ -1826,63 +1827,40 @@ def _onepass_traversal_cases(dev, oracle):
         (33_333, 32, 2, 0.5, 0.02, True), (63, 16, 1, 0.2, 0.01, False), (20_000, 40, 1, 0.0, 0.01, False),
         (50_000, 128, 1, 0.1, 2 * 3 ** 0.5 / 1024, False)]
     import bench
-    for R, res, levels, occ, step, masked in cases:
-        if occ == "shell":
-            b = bench.make_grid(res, "shell10")
-        elif occ == "checker":
-            b = np.broadcast_to((np.indices((res,) * 3).sum(0) % 2 == 0), (levels, res, res, res)).copy()
-        else:
-            b = rng.random((levels, res, res, res)) < occ
-        o = (rng.random((R, 3)) * 3 - 1.5).astype(np.float32)
-        d = rng.standard_normal((R, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
-        est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=res, levels=levels).to(dev)
-        ab = est.aabbs
-        near = T((rng.random(R) * 0.3).astype(np.float32), dev) if levels == 3 else torch.zeros(R, device=dev)
-        far = torch.full((R,), 1e10, device=dev)
-        kw = dict(return_terminate=True, near_hint=None if levels == 3 else 0.0)
-        if masked:
-            kw.update(rays_mask=T(rng.random(R) < 0.6, dev), traverse_steps_limit=11)
-        args = (T(o, dev), T(d, dev), T(b, dev), ab, near, far, step, 0.0)
-        G.ONEPASS = False
-        ref = G._traverse_samples(*args, **kw)
-        G.ONEPASS = True
-        total = ref[0].numel()
-        key = (R, dev.index)
-        for cap in (total, ((total + 4095) // 4096) * 4096 + 8192, max(total - 1, 1), total * 3 + 100):
-            G._SPEC_CAPACITY[key] = max(cap, 1)
-            calls = []
-            orig = G.B.call
-            G.B.call = lambda name, *a, **k: (calls.append(name), orig(name, *a, **k))[1]
-            try:
-                got = G._traverse_samples(*args, **kw)
-            finally:
-                G.B.call = orig
-            assert "nfa_traverse_onepass_walk" in calls and "nfa_traverse_onepass_expand" in calls, calls
-            if cap >= total:   # no second walk
-                assert "nfa_traverse_runs" not in calls and "nfa_expand_runs" not in calls, calls
-            assert all(torch.equal(x, y) for x, y in zip(ref, got)), (R, res, levels, occ, cap, total)
-            assert got[0].is_contiguous() and got[1].is_contiguous()
-        if not masked:
-            ori, ots, ote = oracle.occgrid_sampling(o, d, b, ab.cpu().numpy(), render_step_size=step) if levels != 3 else (None,) * 3
-            if ori is not None:
-                assert (ref[0].cpu().numpy() == ori).all() and (ref[1].cpu().numpy() == ots).all() and (ref[2].cpu().numpy() == ote).all()
-    # the estimator takes the one-launch path from its second batch on
-    est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=64).to(dev)
-    est.binaries = T(bench.make_grid(64, "shell10"), dev)
-    o = (rng.random((12_345, 3)) * 3 - 1.5).astype(np.float32)
-    d = rng.standard_normal((12_345, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
-    a1 = est.sampling(T(o, dev), T(d, dev), render_step_size=5e-3)
-    a2 = est.sampling(T(o, dev), T(d, dev), render_step_size=5e-3)
-    assert all(torch.equal(x, y) for x, y in zip(a1, a2)) and a1[0].numel() > 10_000
-
-
-def test_onepass_traversal_equals_two_launches_and_oracle(dev, oracle):
-    from nerfacc_amd import grid as G
-    saved = G.ONEPASS
+    saved = G.SPECULATE
     try:
-        _onepass_traversal_cases(dev, oracle)
+        for R, res, levels, occ, step, masked in cases:
+            if occ == "shell":
+                b = bench.make_grid(res, "shell10")
+            elif occ == "checker":
+                b = np.broadcast_to((np.indices((res,) * 3).sum(0) % 2 == 0), (levels, res, res, res)).copy()
+            else:
+                b = rng.random((levels, res, res, res)) < occ
+            o = (rng.random((R, 3)) * 3 - 1.5).astype(np.float32)
+            d = rng.standard_normal((R, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+            est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=res, levels=levels).to(dev)
+            ab = est.aabbs
+            near = T((rng.random(R) * 0.3).astype(np.float32), dev) if levels == 3 else torch.zeros(R, device=dev)
+            far = torch.full((R,), 1e10, device=dev)
+            kw = dict(return_terminate=True, near_hint=None if levels == 3 else 0.0)
+            if masked:
+                kw.update(rays_mask=T(rng.random(R) < 0.6, dev), traverse_steps_limit=11)
+            args = (T(o, dev), T(d, dev), T(b, dev), ab, near, far, step, 0.0)
+            G.SPECULATE = False
+            ref = G._traverse_samples(*args, **kw)
+            G.SPECULATE = True
+            total = ref[0].numel()
+            key = (R, dev.index)
+            for cap in (total, ((total + 4095) // 4096) * 4096 + 8192, max(total - 1, 1), total * 3 + 100):
+                G._SPEC_CAPACITY[key] = max(cap, 1)
+                got = G._traverse_samples(*args, **kw)
+                assert all(torch.equal(x, y) for x, y in zip(ref, got)), (R, res, levels, occ, cap, total)
+                assert got[0].is_contiguous() and got[1].is_contiguous()
+            if not masked and levels != 3:
+                ori, ots, ote = oracle.occgrid_sampling(o, d, b, ab.cpu().numpy(), render_step_size=step)
+                assert (ref[0].cpu().numpy() == ori).all() and (ref[1].cpu().numpy() == ots).all() and (ref[2].cpu().numpy() == ote).all()
     finally:
-        G.ONEPASS = saved
+        G.SPECULATE = saved
 
 
 def test_speculative_compaction_capacity(dev):
