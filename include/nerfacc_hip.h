@@ -137,12 +137,15 @@ int nfa_traverse_grids(const nfa_traverse_args *args, nfa_stream_t stream);
  *   nfa_traverse_runs  per ray: sample count (args->sm_cnts), edge count (args->iv_cnts, optional), terminate plane,
  *                      run count and up to max_runs (<= 32) run records {t_first:f32 | k_start:31, continues_previous:1}
  *                      in runs[max_runs][n_rays] (slot-major: record i of ray r at runs[i * n_rays + r]); rays with
- *                      more runs are counted in *overflow_count and must be filled with
+ *                      more runs are counted in overflow_count[0] and must be filled with
  *                      nfa_traverse_grids(mode 1, ray_filter = run_cnts, ray_filter_min = max_runs).
  *                      args->mode: 0 = all rays, 2 = honour rays_mask (+ traverse_steps_limit).  At most 512 cells
- *                      per axis.  near_hint: the value (most of) args->near_planes hold, NaN if unknown; a pure
- *                      accelerator (the march from a common near plane to the grid is tabulated once on
- *                      the host), rays with another near plane are unaffected, results never change.
+ *                      per axis.  near_hint: the value EVERY entry of args->near_planes holds, NaN if there is no such
+ *                      value.  With it the march runs on the lattice near, near + step, ... that all rays share (one
+ *                      table built on the host from the two numbers); same results.  overflow_count is int32[2]:
+ *                      overflow_count[1] != 0 reports rays the table did not serve (a near plane that differs from
+ *                      near_hint, a march beyond the tabulated part of the sequence): the outputs are then
+ *                      incomplete and the caller repeats the call with near_hint = NaN (the per-ray marcher).
  *   nfa_pack_bricks    torch.bool grid -> 4x4x4-cell 64-bit bricks + 1 bit per brick ("coarse") for the serial
  *                      kernels of nfa_traverse_grids (args->bricks / args->coarse);
  *                      bricks has nfa_bricks_words() entries, coarse (words+31)/32 uint32.

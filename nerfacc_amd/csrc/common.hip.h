@@ -111,6 +111,19 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8: MI355X_MICROARCH.md), and an XCD only
+// takes the blocks dealt to it.  A cost that is periodic in the block index with a period that divides 8 therefore lands
+// on a few XCDs: the rays of a 1024-pixel image row are four 256-ray blocks, the two middle ones cross the most cells, and
+// XCDs 1, 2, 5, 6 were still walking them while the other four had been idle for the last third of the launch (wave
+// time stamps, scripts/walk_timeline.py: 4096 busy waves, then 2000).  Within each group of 8 consecutive blocks the work
+// items are rotated by the group's number, so every XCD sees every residue; a bijection on [0, n_blocks).
+__device__ __forceinline__ int64_t xcd_fair_block(uint32_t b, uint32_t n_blocks)
+{
+    const uint32_t group = b >> 3;
+    if (((group + 1u) << 3) > n_blocks) return b;   // (the last, partial group)
+    return (int64_t)((b & ~7u) | ((b + group) & 7u));
+}
+
 // ---------------------------------------------------------------- issue rates (gfx950, scripts/valu_probe.hip)
 // One SIMD issues a wave64 v_add / v_sub / v_mul / v_fma (f32), v_add / v_sub (u32), v_and / v_or / v_xor, v_lshrrev,
 // v_ashrrev, v_mov, v_cndmask (VOP2 form, condition in vcc) and v_bitop3 every 2 cycles, and every 4 cycles: v_min / v_max

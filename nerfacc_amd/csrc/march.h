@@ -23,8 +23,10 @@
 
 #if defined(__HIPCC__)
 #define NFA_HD __host__ __device__ __forceinline__
+#define NFA_HDM __host__ __device__ __forceinline__   /* member functions */
 #else
 #define NFA_HD static inline
+#define NFA_HDM inline
 #endif
 // reciprocal for ESTIMATES that are verified afterwards (1 ulp hardware rcp on the device)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -259,6 +261,174 @@ NFA_HD void approach_table_apply(const ApproachTable &tb, Stepper &s, float &t, 
             return;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// The lattice.  With a constant step every ray that starts at the same near plane stands, at every moment of its march, on
+// a point of ONE sequence L[0] = near, L[j + 1] = fl(L[j] + dt): skipping and sampling both move t_last by whole steps
+// (grid.cu:159-160, 201-202, 214-245).  The state of a march is therefore an INDEX, and "march while t + dt/2 < thr" is
+//      J(thr) = min { j : !(L[j] + dt/2 < thr) }          (the march stands at max(j, J(thr)) afterwards)
+// a pure function of the threshold, monotone in it; the samples of an occupied stretch of cells are the lattice points
+// between two such indices.  Nothing is carried from one threshold to the next: no stable increment to refresh, no binade
+// end to cross, no first march from the near plane -- the cases the marcher of round 2 (walk.hip: marcher_run) serves by
+// stopping a lane and re-running the loop, 2.4 trips per list entry on BASELINE cfg 2.
+// The table lists the sequence as ROWS: maximal runs of consecutive points inside one binade whose neighbours differ by the
+// same number q of ulps (n >= 1 points A, A + q ulp, ...).  Rows are contiguous in j; the step from a row's last point to the
+// next row's first has an increment of its own (it crosses a binade end, or is the odd first step of an exact-tie binade).
+// Built on the host from (near, dt) alone by running the serial accumulation with exact jumps (the argument of this file's
+// header); tests/test_march_cpu.py compares tables and J against the serial loop.
+constexpr int LATTICE_MAX_ROWS = 64;
+constexpr int LATTICE_MAX_BINADES = 48;
+constexpr uint32_t LATTICE_FAIL = 0xFFFFFFFFu;       // lattice_J_fast: not served (the exact search decides)
+constexpr uint32_t LATTICE_OFF_TABLE = 0xFFFFFFFEu;  // the march leaves the tabulated part of the sequence
+constexpr int LATTICE_ROW_BITS = 6;                   // packed position: index << 6 | row
+constexpr uint32_t LATTICE_MAX_INDEX = (1u << (32 - LATTICE_ROW_BITS)) - 2u;
+static_assert(LATTICE_MAX_ROWS <= (1 << LATTICE_ROW_BITS), "row index bits");
+struct LatticeTable {
+    uint32_t near_bits, dt_bits;
+    uint32_t n_rows;                          // 0: no table
+    uint32_t e_lo, n_binades;                 // main_row[i]: the last row of binade (biased exponent) e_lo + i
+    uint32_t j_end;                           // indices [0, j_end) are tabulated
+    uint32_t A[LATTICE_MAX_ROWS];             // bit pattern of the row's first point
+    uint32_t jA[LATTICE_MAX_ROWS];            // its index
+    uint32_t q[LATTICE_MAX_ROWS];             // ulps between neighbours (0: single point)
+    uint32_t n[LATTICE_MAX_ROWS];             // points
+    uint8_t main_row[LATTICE_MAX_BINADES];    // 0xFF: none
+};
+
+NFA_HD void lattice_table_build(LatticeTable &tb, float near, float dt)
+{
+    tb.near_bits = f32_bits(near); tb.dt_bits = f32_bits(dt);
+    tb.n_rows = 0; tb.e_lo = 0; tb.n_binades = 0; tb.j_end = 0;
+    for (int i = 0; i < LATTICE_MAX_ROWS; ++i) { tb.A[i] = 0u; tb.jA[i] = 0u; tb.q[i] = 0u; tb.n[i] = 0u; }
+    for (int i = 0; i < LATTICE_MAX_BINADES; ++i) tb.main_row[i] = 0xFFu;
+    if (!(dt > 0.0f) || !(near >= 0.0f) || !(near < 3.0e38f) || !(dt < 3.0e38f)) return;
+    float t = near;
+    uint32_t j = 0u;
+    int r = 0;
+    tb.A[0] = f32_bits(t); tb.jA[0] = 0u; tb.q[0] = 0u; tb.n[0] = 1u;
+    int equal_steps = 0;   // consecutive equal in-binade increments that ended at t
+    for (;;) {
+        const float tn = t + dt;
+        if (tn == t || !(tn < 3.0e38f)) break;                       // no progress: the sequence ends here
+        const uint32_t bt = f32_bits(t), bn = f32_bits(tn);
+        const bool same = (bt >> 23) == (bn >> 23) && (bt >> 23) != 0u;   // same binade, normal
+        const uint32_t inc = bn - bt;
+        if (same && (tb.n[r] == 1u || inc == tb.q[r])) {
+            equal_steps = (tb.n[r] == 1u) ? 1 : equal_steps + 1;
+            tb.q[r] = inc; tb.n[r] += 1u; t = tn; j += 1u;
+            if (equal_steps >= 2) {
+                // two equal in-binade increments in a row: every further step that stays inside the binade adds the same
+                // (this file's header); take them all at once
+                const uint32_t room = (bn | 0x7FFFFFu) - bn;
+                const uint32_t m = room / inc;
+                if (m > 0u) {
+                    if (j + m > LATTICE_MAX_INDEX) break;
+                    tb.n[r] += m; j += m; t = bits_f32(bn + m * inc);
+                }
+            }
+            if (j > LATTICE_MAX_INDEX) break;
+            continue;
+        }
+        // the step leaves the row: tn opens the next one
+        if (r + 1 >= LATTICE_MAX_ROWS || j + 1u > LATTICE_MAX_INDEX) break;
+        ++r;
+        tb.A[r] = bn; tb.jA[r] = j + 1u; tb.q[r] = 0u; tb.n[r] = 1u;
+        equal_steps = 0;
+        t = tn; j += 1u;
+    }
+    tb.n_rows = (uint32_t)(r + 1);
+    tb.j_end = tb.jA[r] + tb.n[r];
+    // the last row of each binade, for the rows of normal numbers
+    bool have = false;
+    for (int i = 0; i <= r; ++i) {
+        const uint32_t e = tb.A[i] >> 23;
+        if (e == 0u) continue;
+        if (!have) { tb.e_lo = e; have = true; }
+        const uint32_t b = e - tb.e_lo;
+        if (b < (uint32_t)LATTICE_MAX_BINADES) { tb.main_row[b] = (uint8_t)i; if (b + 1u > tb.n_binades) tb.n_binades = b + 1u; }
+    }
+}
+
+// point j of the sequence (j < j_end), by its row
+NFA_HD float lattice_point_in_row(const LatticeTable &tb, uint32_t r, uint32_t j) { return bits_f32(tb.A[r] + (j - tb.jA[r]) * tb.q[r]); }
+NFA_HD float lattice_point(const LatticeTable &tb, uint32_t j)
+{
+    uint32_t r = 0u;
+    while (r + 1u < tb.n_rows && tb.jA[r + 1u] <= j) ++r;
+    return lattice_point_in_row(tb, r, j);
+}
+NFA_HD uint32_t lattice_pack(uint32_t j, uint32_t row) { return (j << LATTICE_ROW_BITS) | row; }
+
+// J(thr) inside ONE row, when the answer is an interior point of it: an fp32 estimate of the step count, then the condition
+// itself on three consecutive points (true, ?, false pins the answer; anything else is declined).  rcp = 1 / (q ulp) serves
+// the estimate only.  Returns the packed position or LATTICE_FAIL.
+NFA_HD uint32_t lattice_J_fast(uint32_t A, uint32_t jA, uint32_t q, uint32_t n, float rcp, uint32_t row, float thr, float half)
+{
+    const float c = thr - half;
+    const float est = (c - bits_f32(A)) * rcp;
+    if (!(est >= 1.0f && est < 4194304.0f)) return LATTICE_FAIL;
+    const uint32_t a = (uint32_t)est - 1u;                       // floor(est) - 1 >= 0
+    if (n < 3u || a > n - 3u) return LATTICE_FAIL;               // the three points a, a + 1, a + 2 must exist
+    const uint32_t b0 = A + a * q;                               // (a q < 2^23: a < n, and the row stays inside its binade)
+    const bool f0 = bits_f32(b0) + half < thr, f1 = bits_f32(b0 + q) + half < thr, f2 = bits_f32(b0 + 2u * q) + half < thr;
+    if (!f0 || f2) return LATTICE_FAIL;
+    const uint32_t j = jA + a + 1u + (f1 ? 1u : 0u);
+    return lattice_pack(j, row);
+}
+
+// J(thr) exactly, for any threshold: the first row whose last point fails the condition (the condition is monotone along
+// the sequence), then the first such point inside it.  LATTICE_OFF_TABLE when even the last tabulated point passes.
+// ROWS: anything with n_rows() and row(r) -> {A, jA, q, n} (the host table, or the kernels' copy in LDS).
+struct LatticeRow { uint32_t A, jA, q, n; };
+struct LatticeRowsHost {
+    const LatticeTable &tb;
+    NFA_HDM uint32_t n_rows() const { return tb.n_rows; }
+    NFA_HDM LatticeRow row(uint32_t r) const { return LatticeRow{tb.A[r], tb.jA[r], tb.q[r], tb.n[r]}; }
+};
+template <class ROWS>
+NFA_HD uint32_t lattice_J_search_rows(const ROWS &rows, float thr, float half)
+{
+    const uint32_t nr = rows.n_rows();
+    if (nr == 0u) return LATTICE_OFF_TABLE;
+    uint32_t lo = 0u, hi = nr - 1u;
+    {
+        const LatticeRow z = rows.row(hi);
+        if (bits_f32(z.A + (z.n - 1u) * z.q) + half < thr) return LATTICE_OFF_TABLE;
+    }
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const LatticeRow z = rows.row(mid);
+        if (bits_f32(z.A + (z.n - 1u) * z.q) + half < thr) lo = mid + 1u; else hi = mid;
+    }
+    const LatticeRow rr = rows.row(lo);
+    uint32_t klo = 0u, khi = rr.n - 1u;                          // the condition fails at khi
+    while (klo < khi) {
+        const uint32_t mid = (klo + khi) >> 1;
+        if (bits_f32(rr.A + mid * rr.q) + half < thr) klo = mid + 1u; else khi = mid;
+    }
+    return lattice_pack(rr.jA + klo, lo);
+}
+NFA_HD uint32_t lattice_J_search(const LatticeTable &tb, float thr, float half) { return lattice_J_search_rows(LatticeRowsHost{tb}, thr, half); }
+
+// the row whose binade holds thr - dt/2 (the estimate's starting point); rows beyond the binade table: its last entry
+NFA_HD uint32_t lattice_main_row(const LatticeTable &tb, float thr, float half)
+{
+    const int32_t e = (int32_t)f32_bits(thr - half) >> 23;      // (a negative value: below every row)
+    int32_t b = e - (int32_t)tb.e_lo;
+    if (b < 0) b = 0;
+    if (b >= (int32_t)tb.n_binades) b = (int32_t)tb.n_binades - 1;
+    return b >= 0 ? (uint32_t)tb.main_row[b] : 0xFFu;
+}
+NFA_HD uint32_t lattice_J(const LatticeTable &tb, float thr, float half)
+{
+    const uint32_t r = lattice_main_row(tb, thr, half);
+    if (r < tb.n_rows && tb.q[r] != 0u) {
+        const float rcp = 1.0f / ldexpf((float)tb.q[r], (int)(tb.A[r] >> 23) - 150);
+        const uint32_t w = lattice_J_fast(tb.A[r], tb.jA[r], tb.q[r], tb.n[r], rcp, r, thr, half);
+        if (w != LATTICE_FAIL) return w;
+    }
+    return lattice_J_search(tb, thr, half);
 }
 
 // The whole march of one event in one shot, straight-line code for the cases that make up > 99.9 % of the events of a

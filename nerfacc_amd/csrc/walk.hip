@@ -31,7 +31,8 @@ namespace nfa {
 #endif
 constexpr int WK_EV = NFA_WK_EV;           // list slots per ray: 16 KiB of LDS per 256 rays -> 8 workgroups per CU
 #ifndef NFA_WALK_WAVES
-#define NFA_WALK_WAVES 0
+#define NFA_WALK_WAVES 5   /* 100 -> 95 registers (one 8-byte spill outside the loops): 5 waves per SIMD instead of 4 fill a part of the
+                              time a slot waits for its next workgroup (scripts/walk_timeline.py): 168 -> 160 us on cfg 2, 384 -> 351 at 256^3 */
 #endif
 #if NFA_WALK_WAVES > 0
 #define NFA_WALK_OCC __attribute__((amdgpu_waves_per_eu(NFA_WALK_WAVES, NFA_WALK_WAVES)))
@@ -80,6 +81,11 @@ struct WalkParams {
     const int32_t *order;        // lane -> ray assignment or NULL
     int64_t n_order;             // entries of `order` (< n_rays: only the listed rays are walked; the others keep their outputs)
     ApproachTable approach;      // march.h; n == 0: none
+    LatticeTable lat;            // march.h: the lattice of the launch's near plane and step (walk_kernel<.., LATTICE = true>)
+#ifdef NFA_WALK_STAMPS
+    unsigned long long *stamps;  // debugging aid (scripts/walk_timeline.py): [waves][4] = {start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID}
+    const int32_t *tile_order;   // experiment: workgroup b walks tile tile_order[b]
+#endif
 };
 
 enum { WK_EMPTY = 0, WK_OCC = 1, WK_SPAN = 2 };
@@ -343,6 +349,135 @@ __device__ __forceinline__ void marcher_run(Marcher &s, const char *col /* LDS c
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Phase 2 on the lattice (march.h: LatticeTable).  Every ray of the launch starts at the same near plane and marches with
+// the same step, so it always stands on a point of ONE sequence; a list entry "march until the threshold" is the index
+// J(thr) of a lattice point, whatever came before it.  Pass A turns the lane's list into such indices, slot by slot, with
+// no state: the row of the binade the threshold falls into, an fp32 estimate of the step count, the condition itself on
+// three consecutive points (lattice_J_fast); what that declines (answers next to a row end, the first steps behind the
+// near plane) goes to the exact search, once per call, for all the lanes that have any.  Pass B walks the list with
+// integers: samples of an occupied entry = difference of two indices, run records cut where the increment changes (the
+// end of a row: the step across a binade end is a record of its own).
+struct LatticeLds {
+    uint4 row[LATTICE_MAX_ROWS];          // {A, jA, q, n}
+    uint4 main_a[LATTICE_MAX_BINADES];    // the same for the last row of binade e_lo + i (n = 0: none)
+    uint2 main_b[LATTICE_MAX_BINADES];    // {bits of 1 / (q ulp), row}
+};
+struct LatticeRowsLds {
+    const LatticeLds &t;
+    uint32_t nr;
+    __device__ __forceinline__ uint32_t n_rows() const { return nr; }
+    __device__ __forceinline__ LatticeRow row(uint32_t r) const { const uint4 v = t.row[r]; return LatticeRow{v.x, v.y, v.z, v.w}; }
+};
+// position of one ray on the lattice and what its samples add up to
+struct LatState {
+    uint32_t jr;                 // index << 6 | row
+    uint32_t jmax;               // the same for this_tmax of the span the entries belong to
+    int32_t cont, ptype;
+    int32_t n_samples, n_chains, n_runs;
+};
+__device__ __forceinline__ float lattice_value(const LatticeLds &lt, uint32_t w)
+{
+    const uint4 R = lt.row[w & (LATTICE_MAX_ROWS - 1)];
+    return bits_f32(R.x + ((w >> LATTICE_ROW_BITS) - R.y) * R.z);
+}
+// the packed position of index j, which lies in row r or behind it
+__device__ __forceinline__ uint32_t lattice_word_of(const LatticeLds &lt, uint32_t j, uint32_t r, uint32_t n_rows)
+{
+    while (r + 1u < n_rows && j >= lt.row[r].y + lt.row[r].w) ++r;
+    return lattice_pack(j, r);
+}
+// `count` samples from the position w on: one record per stretch of equal increments
+__device__ __forceinline__ void lattice_emit(LatState &s, const LatticeLds &lt, uint32_t w, uint32_t count, const WalkParams &p, int64_t tid)
+{
+    uint32_t j0 = w >> LATTICE_ROW_BITS, r = w & (LATTICE_MAX_ROWS - 1);
+    const uint32_t j1 = j0 + count;
+    uint32_t k_start = (uint32_t)s.n_samples, cflag = (uint32_t)s.cont;
+    do {
+        const uint4 R = lt.row[r];
+        const uint32_t cross = R.y + R.w - 1u;     // the sample that starts on the row's last point has an increment of its own
+        if (j0 < cross) {
+            const uint32_t cut = min(j1, cross);
+            store_run(p, s.n_runs, tid, (unsigned long long)(R.x + (j0 - R.y) * R.z) | ((unsigned long long)(k_start | (cflag << 31)) << 32));
+            s.n_runs++;
+            k_start += cut - j0; j0 = cut; cflag = 1u;
+        }
+        if (j0 < j1) {
+            store_run(p, s.n_runs, tid, (unsigned long long)(R.x + (R.w - 1u) * R.z) | ((unsigned long long)(k_start | (cflag << 31)) << 32));
+            s.n_runs++;
+            k_start += 1u; j0 += 1u; cflag = 1u; ++r;
+        }
+    } while (j0 < j1);
+}
+
+template <bool HAS_LIMIT>
+__device__ __forceinline__ void lattice_run(LatState &s, char *col /* LDS column of this lane */, int32_t cnt, uint32_t ev_span, float half,
+                                            int32_t limit_arg, const WalkParams &p, const LatticeLds &lt, int64_t tid)
+{
+    const int32_t limit = HAS_LIMIT ? limit_arg : 0;
+    const uint32_t n_rows = p.lat.n_rows;
+    const int32_t e_lo = (int32_t)p.lat.e_lo, b_hi = (int32_t)p.lat.n_binades - 1;
+    const float near_f = bits_f32(p.lat.near_bits);
+    // ---- pass A: thresholds -> lattice positions
+    uint32_t failed = 0u;
+    for (int32_t k = 0; k < cnt; ++k) {
+        float *slot = reinterpret_cast<float *>(col + (k << WK_LG));
+        const float v = *slot;
+        int32_t b = ((int32_t)f32_bits(v - half) >> 23) - e_lo;     // (a negative value: below every row)
+        b = max(0, min(b, b_hi));
+        const uint4 ra = lt.main_a[b];
+        const uint2 rb = lt.main_b[b];
+        uint32_t w = lattice_J_fast(ra.x, ra.y, ra.z, ra.w, bits_f32(rb.x), rb.y, v, half);
+        w = (near_f + half < v) ? w : lattice_pack(0u, 0u);          // no step at all: the ray stays on the near plane
+        failed |= (w == LATTICE_FAIL ? 1u : 0u) << k;
+        *reinterpret_cast<uint32_t *>(slot) = w == LATTICE_FAIL ? f32_bits(v) : w;
+    }
+    if (failed != 0u) {
+        const LatticeRowsLds rows{lt, n_rows};
+        do {
+            const int32_t k = __builtin_ctz(failed);
+            failed &= failed - 1u;
+            float *slot = reinterpret_cast<float *>(col + (k << WK_LG));
+            uint32_t w = lattice_J_search_rows(rows, *slot, half);
+            if (w == LATTICE_OFF_TABLE) {   // beyond the tabulated sequence: the caller repeats the traversal without the table
+                atomicOr(reinterpret_cast<unsigned int *>(p.overflow + 1), 1u);
+                w = lattice_pack(p.lat.j_end - 1u, n_rows - 1u);
+            }
+            *reinterpret_cast<uint32_t *>(slot) = w;
+        } while (failed != 0u);
+    }
+    // ---- pass B: the list, in integers (grid.cu:153-163 span start, :193-206 empty cells, :207-262 occupied cells)
+    int32_t k = 0;
+    while (k < cnt) {
+        if (limit > 0 && s.n_samples >= limit) break;                // grid.cu:184: nothing moves once the limit is hit
+        const uint32_t w0 = *reinterpret_cast<const uint32_t *>(col + (k << WK_LG));
+        const uint32_t w1 = *reinterpret_cast<const uint32_t *>(col + ((k + 1) << WK_LG));   // (slot k + 1 <= WK_EV exists)
+        const bool is_span = (ev_span >> k) & 1u;
+        const uint32_t tgt = is_span ? w0 : min(w0, s.jmax);          // thresholds are clamped to this_tmax: J is monotone
+        const int32_t type = is_span ? WK_SPAN : s.ptype;
+        const bool skip = is_span && s.cont != 0;                     // grid.cu:153: `if (!continuous)`
+        uint32_t target = skip ? s.jr : max(s.jr, tgt);
+        if (type == WK_OCC) {
+            uint32_t count = (target >> LATTICE_ROW_BITS) - (s.jr >> LATTICE_ROW_BITS);
+            if (limit > 0 && count > (uint32_t)(limit - s.n_samples)) {
+                count = (uint32_t)(limit - s.n_samples);
+                target = lattice_word_of(lt, (s.jr >> LATTICE_ROW_BITS) + count, s.jr & (LATTICE_MAX_ROWS - 1), n_rows);
+            }
+            if (count > 0u) {
+                lattice_emit(s, lt, s.jr, count, p, tid);
+                s.n_samples += (int32_t)count;
+                s.n_chains += s.cont ^ 1;
+                s.cont = 1;
+            }
+        } else if (type == WK_EMPTY) {
+            s.cont = 0;                                               // whether or not it marched
+        }
+        s.jr = target;
+        if (is_span) { s.jmax = w1; s.ptype = (int32_t)((ev_span >> (16 + k)) & 1u); k += 2; }
+        else { s.ptype ^= 1; k += 1; }
+    }
+}
+
 // DDA state of the span being walked
 struct WalkSpan {
     float tx, ty, tz, dx, dy, dz;
@@ -501,12 +636,38 @@ __device__ __forceinline__ void approach_to_lds(ApproachLds &tb, const WalkParam
 #endif
 }
 
+// The lattice table of the launch, staged the same way; the rows of the binade table with what lattice_J_fast needs
+__device__ __forceinline__ void lattice_to_lds(LatticeLds &lt)
+{
+    const char *ka = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr size_t p_off = (sizeof(nfa_traverse_args) + alignof(WalkParams) - 1) / alignof(WalkParams) * alignof(WalkParams);
+    const LatticeTable *tk = &reinterpret_cast<const WalkParams *>(ka + p_off)->lat;
+    const uint32_t t = threadIdx.x;
+    if (t < (uint32_t)LATTICE_MAX_ROWS) lt.row[t] = make_uint4(tk->A[t], tk->jA[t], tk->q[t], tk->n[t]);
+    if (t < (uint32_t)LATTICE_MAX_BINADES) {
+        const uint32_t r = tk->main_row[t];
+        uint4 a = make_uint4(0u, 0u, 0u, 0u);
+        uint2 b = make_uint2(0u, 0u);
+        if (r < (uint32_t)LATTICE_MAX_ROWS && tk->q[r] != 0u) {
+            a = make_uint4(tk->A[r], tk->jA[r], tk->q[r], tk->n[r]);
+            b = make_uint2(f32_bits(NFA_RCP(ldexpf((float)a.z, (int)(a.x >> 23) - 150))), r);
+        }
+        lt.main_a[t] = a; lt.main_b[t] = b;
+    }
+}
+
 // One ray through the grid(s): phases 1 and 2 alternate until the event walk is over.  Leaves the marcher's state (sample
 // count, run count, chain count, last distance); run records go to store_run.
-template <bool FUSED, bool HAS_LIMIT>
+struct WalkOut {
+    float t_last;
+    int32_t n_samples, n_chains, n_runs;
+};
+template <bool FUSED, bool HAS_LIMIT, bool LATTICE>
 __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkParams &p, int64_t tid, char *ev_lds, uint32_t lane_off,
-                                         const ApproachLds &tb, Marcher &s)
+                                         const ApproachLds &tb, const LatticeLds &lt, WalkOut &out)
 {
+    Marcher s;
+    LatState ls;
     char *const col = ev_lds + lane_off;
     const float dt = a.step_size;
     const int32_t limit = HAS_LIMIT ? a.traverse_steps_limit : 0;
@@ -516,6 +677,7 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
     const float d[3] = {a.rays_d[3 * tid], a.rays_d[3 * tid + 1], a.rays_d[3 * tid + 2]};
     s.t_last = near_plane; s.continuous = 0; s.n_samples = 0; s.n_chains = 0; s.n_runs = 0; s.run_inc = 0.f;
     s.span_tmax = 0.f; s.ptype = 0; s.at_near = 1; s.fe = 0xFFFFFFFFu; s.fq = 0u; s.fstep = 0.f; s.frcp = 0.f;
+    ls.jr = lattice_pack(0u, 0u); ls.jmax = 0u; ls.cont = 0; ls.ptype = 0; ls.n_samples = 0; ls.n_chains = 0; ls.n_runs = 0;
 
     float f_tmin = 0.f, f_tmax = 0.f;
     bool f_pending = false;
@@ -543,6 +705,12 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
     // A ray with a non-finite origin or direction has no geometry: upstream its NaN planes survive fmaxf / fminf as
     // [near, far] and the ray is sampled all the way to the far plane (1e10 by default).  Here it gets no samples.
     if (!(isfinite(o[0]) && isfinite(o[1]) && isfinite(o[2]) && isfinite(d[0]) && isfinite(d[1]) && isfinite(d[2]))) {
+        f_pending = false;
+        next_i = 2 * G;
+    }
+    if (LATTICE && f32_bits(near_plane) != p.lat.near_bits) {
+        // not a ray of this lattice (near_hint did not hold for it): the caller repeats the traversal without the table
+        atomicOr(reinterpret_cast<unsigned int *>(p.overflow + 1), 1u);
         f_pending = false;
         next_i = 2 * G;
     }
@@ -614,9 +782,13 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
             // some path into it leaves an LDS read or a kernel-argument load in flight (in the single-launch forms of the one-pass traversal: every cell
             // then waited for its own ds_write, the walk took 3x as long).  lgkmcnt(0), vmcnt / expcnt untouched:
             __builtin_amdgcn_s_waitcnt(0xC07F);
+#if defined(NFA_WALK_EXP) && NFA_WALK_EXP == 5   /* timing experiment: everything but the cell loop */
+            rem = 0u;
+#else
             do {
                 walk_cell(dx, dy, dz, mx, my, mz, flip, tx, ty, tz, rem, widx, ev_addr, m_last, w_cur, i_cur, open_type, bits, ev_lds);
             } while (!walk_stop(rem, ev_addr));
+#endif
             sp.tx = tx; sp.ty = ty; sp.tz = tz; sp.rem = rem; sp.widx = widx;
             if ((rem & WK_GUARD) != WK_GUARD) in_span = 0;
             else break;  // list full
@@ -625,26 +797,41 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
         int32_t cnt = (int32_t)(ev_addr >> WK_LG);
         if (finished && has_open) { cnt += 1; has_open = 0; }
 #ifndef NFA_WALK_NO_PHASE2
-        marcher_run<HAS_LIMIT>(s, col, cnt, ev_span, dt, limit, p, tb, tid);
+        if (LATTICE) lattice_run<HAS_LIMIT>(ls, col, cnt, ev_span, dt * 0.5f, limit, p, lt, tid);
+        else marcher_run<HAS_LIMIT>(s, col, cnt, ev_span, dt, limit, p, tb, tid);
 #endif
-        if (finished || (limit > 0 && s.n_samples >= limit)) break;
+        if (finished || (limit > 0 && (LATTICE ? ls.n_samples : s.n_samples) >= limit)) break;
         // the open entry moves to slot 0
         ev_span = 0u;
         ev_addr = lane_off;
         if (has_open) *reinterpret_cast<float *>(col) = m_last;
     }
+    if (LATTICE) { out.t_last = lattice_value(lt, ls.jr); out.n_samples = ls.n_samples; out.n_chains = ls.n_chains; out.n_runs = ls.n_runs; }
+    else { out.t_last = s.t_last; out.n_samples = s.n_samples; out.n_chains = s.n_chains; out.n_runs = s.n_runs; }
 }
 
-template <bool FUSED, bool HAS_LIMIT>
+// LATTICE: every ray starts at near_hint and the table of that near plane is in p.lat (phase 2 = lattice_run); otherwise
+// the per-ray marcher (per-ray near planes: the API's traverse_grids with a tensor of them, the chunks of the test-mode loop)
+template <bool FUSED, bool HAS_LIMIT, bool LATTICE>
 NFA_WALK_OCC __global__ __launch_bounds__(WK_THREADS) void walk_kernel(const nfa_traverse_args a, const WalkParams p)
 {
     __shared__ __attribute__((aligned(16))) char ev_lds[(WK_EV + 1) << WK_LG];   // [WK_EV + 1][256] floats
     __shared__ ApproachLds tb;
-    approach_to_lds(tb, p);
+    __shared__ LatticeLds lt;
+#ifdef NFA_WALK_STAMPS
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (LATTICE) lattice_to_lds(lt);
+    else approach_to_lds(tb, p);
     __syncthreads();
     const uint32_t lane_off = 4u * threadIdx.x;
     const int64_t n_walk = p.order ? p.n_order : a.n_rays;
-    for (int64_t slot_i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; slot_i < n_walk;
+#ifdef NFA_WALK_STAMPS
+    const int64_t bid = p.tile_order ? (int64_t)p.tile_order[blockIdx.x] : xcd_fair_block(blockIdx.x, gridDim.x);
+#else
+    const int64_t bid = xcd_fair_block(blockIdx.x, gridDim.x);
+#endif
+    for (int64_t slot_i = bid * blockDim.x + threadIdx.x; slot_i < n_walk;
          slot_i += (int64_t)blockDim.x * gridDim.x) {
         const int64_t tid = p.order ? (int64_t)p.order[slot_i] : slot_i;
         if (a.mode == 2 && a.rays_mask != nullptr && !a.rays_mask[tid]) {
@@ -654,8 +841,8 @@ NFA_WALK_OCC __global__ __launch_bounds__(WK_THREADS) void walk_kernel(const nfa
             p.run_cnts[tid] = 0;
             continue;
         }
-        Marcher s;
-        walk_ray<FUSED, HAS_LIMIT>(a, p, tid, ev_lds, lane_off, tb, s);
+        WalkOut s;
+        walk_ray<FUSED, HAS_LIMIT, LATTICE>(a, p, tid, ev_lds, lane_off, tb, lt, s);
         if (a.terminate_planes) a.terminate_planes[tid] = s.t_last;
         a.sm_cnts[tid] = s.n_samples;
         if (a.iv_cnts) a.iv_cnts[tid] = s.n_samples + s.n_chains;  // edges = samples + one leading edge per chain
@@ -665,6 +852,13 @@ NFA_WALK_OCC __global__ __launch_bounds__(WK_THREADS) void walk_kernel(const nfa
         p.run_cnts[tid] = n_runs;
         if (n_runs > p.max_runs) atomicAdd(p.overflow, 1);
     }
+#ifdef NFA_WALK_STAMPS
+    if (p.stamps && (threadIdx.x & 63) == 0) {
+        unsigned long long *o = p.stamps + (bid * (WK_THREADS / 64) + (threadIdx.x >> 6)) * 4;
+        o[0] = st_t0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+        o[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -944,7 +1138,7 @@ __global__ __launch_bounds__(256) void cone_walk_kernel(const nfa_traverse_args 
 {
     const int64_t n_walk = p.order ? p.n_order : a.n_rays;
     const int32_t limit = a.traverse_steps_limit;
-    for (int64_t slot_i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; slot_i < n_walk;
+    for (int64_t slot_i = xcd_fair_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; slot_i < n_walk;
          slot_i += (int64_t)blockDim.x * gridDim.x) {
         const int64_t tid = p.order ? (int64_t)p.order[slot_i] : slot_i;
         if (cone_ray_masked(a, p, tid)) continue;
@@ -991,7 +1185,7 @@ __global__ __launch_bounds__(256) void cone_refill_kernel(const nfa_traverse_arg
     const int lane = lane_id();
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
     const int64_t n_walk = p.order ? p.n_order : a.n_rays;
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t wave = xcd_fair_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     int64_t next = wave * p.chunk;  // (wave-uniform) first entry not handed out yet
     const int64_t end = next + p.chunk < n_walk ? next + p.chunk : n_walk;
     const int32_t limit = a.traverse_steps_limit;
@@ -1114,7 +1308,7 @@ int nfa_traverse_runs(const nfa_traverse_args *pa, const uint32_t *bits, int32_t
     NFA_REQUIRE(a.n_rays >= 0 && a.n_rays < (int64_t)1 << 31, "traverse_runs: n_rays out of range");
     NFA_REQUIRE(overflow_count, "traverse_runs: overflow_count is null");
     hipStream_t s = as_stream(stream);
-    if (hipMemsetAsync(overflow_count, 0, sizeof(int32_t), s) != hipSuccess) { set_error("traverse_runs: memset failed"); return NFA_EHIP; }
+    if (hipMemsetAsync(overflow_count, 0, 2 * sizeof(int32_t), s) != hipSuccess) { set_error("traverse_runs: memset failed"); return NFA_EHIP; }
     if (a.n_rays == 0) return NFA_OK;
     NFA_REQUIRE(a.step_size > 0.0f && a.cone_angle == 0.0f, "traverse_runs: needs step_size > 0 and cone_angle == 0");
     NFA_REQUIRE(a.mode == 0 || a.mode == 2, "traverse_runs: mode must be 0 (all rays) or 2 (rays_mask + limit)");
@@ -1143,15 +1337,34 @@ int nfa_traverse_runs(const nfa_traverse_args *pa, const uint32_t *bits, int32_t
     if (ray_order && n_order == 0) return NFA_OK;
     // near_hint: the value most (or all) entries of near_planes hold, NaN if unknown.  Rays whose near plane
     // differs bit-wise simply do not use the table.
-    if (near_hint == near_hint) approach_table_build(p.approach, near_hint, a.step_size);
-    else p.approach.n = 0;
+    // With a near plane that holds for every ray, phase 2 runs on the lattice of (near, step): its table is built here, from
+    // the two numbers.  Rays the table does not serve (a near plane that differs, a march beyond the tabulated sequence)
+    // raise overflow_count[1], and the caller repeats the call with near_hint = NaN: the per-ray marcher.
+    p.approach.n = 0;
+    p.lat.n_rows = 0;
+    if (near_hint == near_hint && !getenv("NFA_WALK_NO_LATTICE")) lattice_table_build(p.lat, near_hint, a.step_size);
+    const bool lattice = p.lat.n_rows >= 1 && p.lat.n_binades >= 1;
+    if (!lattice && near_hint == near_hint) approach_table_build(p.approach, near_hint, a.step_size);
+#ifdef NFA_WALK_STAMPS
+    { const char *e = getenv("NFA_WALK_STAMPS_PTR"); p.stamps = e ? reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 0)) : nullptr; }
+    { const char *e = getenv("NFA_WALK_ORDER_PTR"); p.tile_order = e ? reinterpret_cast<const int32_t *>(strtoull(e, nullptr, 0)) : nullptr; }
+#endif
     const size_t shmem = 0;  // the lists are static LDS
     const unsigned grid = grid_1d(p.n_order, WK_THREADS, 1 << 20);
     const bool lim = a.traverse_steps_limit > 0;
-    if (fused && !lim)      hipLaunchKernelGGL((walk_kernel<true, false>), dim3(grid), dim3(WK_THREADS), shmem, s, a, p);
-    else if (fused)         hipLaunchKernelGGL((walk_kernel<true, true>), dim3(grid), dim3(WK_THREADS), shmem, s, a, p);
-    else if (!lim)          hipLaunchKernelGGL((walk_kernel<false, false>), dim3(grid), dim3(WK_THREADS), shmem, s, a, p);
-    else                    hipLaunchKernelGGL((walk_kernel<false, true>), dim3(grid), dim3(WK_THREADS), shmem, s, a, p);
+#define NFA_WALK_LAUNCH(F, L, T) hipLaunchKernelGGL((walk_kernel<F, L, T>), dim3(grid), dim3(WK_THREADS), shmem, s, a, p)
+    if (lattice) {
+        if (fused && !lim)      NFA_WALK_LAUNCH(true, false, true);
+        else if (fused)         NFA_WALK_LAUNCH(true, true, true);
+        else if (!lim)          NFA_WALK_LAUNCH(false, false, true);
+        else                    NFA_WALK_LAUNCH(false, true, true);
+    } else {
+        if (fused && !lim)      NFA_WALK_LAUNCH(true, false, false);
+        else if (fused)         NFA_WALK_LAUNCH(true, true, false);
+        else if (!lim)          NFA_WALK_LAUNCH(false, false, false);
+        else                    NFA_WALK_LAUNCH(false, true, false);
+    }
+#undef NFA_WALK_LAUNCH
     NFA_CHECK_LAUNCH("traverse_runs");
     return NFA_OK;
 }

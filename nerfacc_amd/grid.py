@@ -195,11 +195,17 @@ def traverse_grids(
             bits = _get_walk_bits(binaries)
             run_cnts = torch.empty(n_rays, dtype=torch.int32, device=dev)
             runs = torch.empty((MAX_RUNS, n_rays), dtype=torch.int64, device=dev)
-            B.call("nfa_traverse_runs", C.byref(a), B.ptr(bits), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
-                   B.ptr(meta[2:3]), float("nan") if near_hint is None else near_hint, None, 0, B.stream())
-            iv_packed = _cumsum_packed(iv_cnts, meta[0:1])
-            sm_packed = _cumsum_packed(sm_cnts, meta[1:2])
-            n_iv, n_sm, n_overflow = (int(v) for v in meta.tolist())  # the one device->host read
+            while True:
+                B.call("nfa_traverse_runs", C.byref(a), B.ptr(bits), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
+                       B.ptr(meta[2:3]), float("nan") if near_hint is None else near_hint, None, 0, B.stream())
+                iv_packed = _cumsum_packed(iv_cnts, meta[0:1])
+                sm_packed = _cumsum_packed(sm_cnts, meta[1:2])
+                n_iv, n_sm, n_overflow = (int(v) for v in meta.tolist())  # the one device->host read
+                n_overflow, off_lattice = n_overflow & 0xFFFFFFFF, n_overflow >> 32
+                if not off_lattice or near_hint is None:
+                    break
+                near_hint = None   # rays that are not on the lattice of near_hint (csrc/walk.hip): the per-ray marcher
+                meta.zero_()
             iv_vals = torch.empty(n_iv, dtype=torch.float32, device=dev)
             iv_ri = torch.empty(n_iv, **i64)
             iv_l = torch.empty(n_iv, dtype=torch.bool, device=dev)
@@ -472,6 +478,15 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
             n_sm, s_max, s_sum, n_overflow, c_max, c_sum = (int(v) for v in host[:6].tolist())
         else:
             n_sm, s_max, s_sum, n_overflow, c_max, c_sum = (int(v) for v in meta.tolist())  # the one device->host read of the traversal
+        n_overflow, off_lattice = n_overflow & 0xFFFFFFFF, n_overflow >> 32
+        if off_lattice and use_runs and near_hint is not None:
+            # rays that are not on the lattice of near_hint (a near plane that differs from it, a march beyond the tabulated
+            # sequence: csrc/walk.hip): the same traversal with the per-ray marcher
+            return _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size, cone_angle,
+                                     rays_mask=rays_mask, traverse_steps_limit=traverse_steps_limit, t_sorted=t_sorted,
+                                     t_indices=t_indices, hits=hits, return_terminate=return_terminate, near_hint=None,
+                                     bin_rays=bin_rays, stats_sink=stats_sink, speculate=speculate, n_alive=n_alive,
+                                     alive_list=alive_list)
         if stats_sink is not None and c_sum > 0:
             stats_sink["cells_max_over_mean"] = 64.0 * c_max / c_sum
         if SPECULATE and use_runs:

@@ -13,6 +13,7 @@ HARNESS = r'''
 #include "march.h"
 #include <math.h>
 #include <vector>
+#include <stdint.h>
 extern "C" void ff_batch(const float* t, const float* target, const float* dt, long n, float* a, float* b) {
     for (long i = 0; i < n; ++i) {
         a[i] = nfa::fast_forward_serial(t[i], target[i], dt[i]);
@@ -116,6 +117,90 @@ extern "C" long ray_events(float t0, float dt, const float* thr, const int* emit
             if (w < cap) { ts_b[w] = fmaf((float)i, r.inc, r.t0); te_b[w] = fmaf((float)(i + 1), r.inc, r.t0); }
     *n_b_out = nb; *n_jumps = jumps;
     return na;
+}
+
+// The lattice table (march.h): every tabulated point equals the serial accumulation, rows are contiguous, and J(thr)
+// (fast form or exact search) equals the serial loop's step count for thresholds around row ends, around lattice
+// points and at random.  Returns the number of thresholds checked; bad[0..2] = wrong points, wrong J, J served by the fast form.
+extern "C" long lattice_check(float near, float dt, long max_steps, unsigned seed, long n_random, long* bad, unsigned* shape) {
+    nfa::LatticeTable tb;
+    nfa::lattice_table_build(tb, near, dt);
+    bad[0] = bad[1] = bad[2] = 0;
+    shape[0] = tb.n_rows; shape[1] = tb.j_end; shape[2] = tb.n_binades;
+    if (tb.n_rows == 0) return 0;
+    // rows contiguous
+    for (unsigned r = 0; r + 1 < tb.n_rows; ++r) if (tb.jA[r] + tb.n[r] != tb.jA[r + 1]) bad[0]++;
+    if (tb.jA[0] != 0 || tb.A[0] != nfa::f32_bits(near)) bad[0]++;
+    // the serial sequence
+    std::vector<float> L;
+    {
+        float t = near;
+        for (long j = 0; j < max_steps; ++j) { L.push_back(t); const float tn = t + dt; if (tn == t) break; t = tn; }
+    }
+    const long n_pts = (long)L.size() < (long)tb.j_end ? (long)L.size() : (long)tb.j_end;
+    if ((long)L.size() < max_steps && (long)tb.j_end != (long)L.size()) bad[0]++;   // the whole sequence fits: same length
+    {
+        unsigned r = 0;
+        for (long j = 0; j < n_pts; ++j) {
+            while (r + 1 < tb.n_rows && tb.jA[r + 1] <= (unsigned)j) ++r;
+            if (nfa::f32_bits(nfa::lattice_point_in_row(tb, r, (unsigned)j)) != nfa::f32_bits(L[j])) { bad[0]++; if (bad[0] > 10) break; }
+        }
+    }
+    const float half = dt * 0.5f;
+    auto serial_J = [&](float thr) -> long {   // first j with !(L[j] + half < thr), -1 when beyond the points we have
+        long lo = 0, hi = n_pts;               // the condition is monotone along the sequence
+        while (lo < hi) { const long mid = (lo + hi) >> 1; if (L[mid] + half < thr) lo = mid + 1; else hi = mid; }
+        return lo < n_pts ? lo : -1;
+    };
+    long checked = 0;
+    auto check = [&](float thr) {
+        const long want = serial_J(thr);
+        if (want < 0) return;
+        const uint32_t r = nfa::lattice_main_row(tb, thr, half);
+        uint32_t wf = nfa::LATTICE_FAIL;
+        if (r < tb.n_rows && tb.q[r] != 0u) {
+            const float rcp = 1.0f / ldexpf((float)tb.q[r], (int)(tb.A[r] >> 23) - 150);
+            wf = nfa::lattice_J_fast(tb.A[r], tb.jA[r], tb.q[r], tb.n[r], rcp * (1.0f + 1e-6f), r, thr, half);   // (a 1-ulp-ish reciprocal, as on the device)
+        }
+        const uint32_t ws = nfa::lattice_J_search(tb, thr, half);
+        const uint32_t w = nfa::lattice_J(tb, thr, half);
+        if (wf != nfa::LATTICE_FAIL) { bad[2]++; if ((long)(wf >> nfa::LATTICE_ROW_BITS) != want || wf != ws) bad[1]++; }
+        if (ws == nfa::LATTICE_OFF_TABLE || (long)(ws >> nfa::LATTICE_ROW_BITS) != want) bad[1]++;
+        else {
+            const uint32_t row = ws & ((1u << nfa::LATTICE_ROW_BITS) - 1u), j = ws >> nfa::LATTICE_ROW_BITS;
+            if (!(row < tb.n_rows && j >= tb.jA[row] && j < tb.jA[row] + tb.n[row])) bad[1]++;
+        }
+        if (w != ws) bad[1]++;
+        checked++;
+    };
+    // around every row end and start, and around the lattice points themselves
+    for (unsigned r = 0; r < tb.n_rows; ++r)
+        for (long d = -4; d <= 4; ++d) {
+            const long js[2] = {(long)tb.jA[r] + d, (long)tb.jA[r] + (long)tb.n[r] - 1 + d};
+            for (long j : js) {
+                if (j < 0 || j >= n_pts) continue;
+                const float base = L[j] + half;
+                float v = base;
+                for (int u = 0; u < 3; ++u) { check(v); v = nextafterf(v, 3.0e38f); }
+                v = base;
+                for (int u = 0; u < 3; ++u) { v = nextafterf(v, -3.0e38f); check(v); }
+                check(L[j]); check(L[j] + dt * 0.25f); check(L[j] + dt * 0.75f);
+            }
+        }
+    uint64_t st = seed * 6364136223846793005ull + 1442695040888963407ull;
+    auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (double)(st >> 11) / 9007199254740992.0; };
+    for (long i = 0; i < n_random; ++i) {
+        const long j = (long)(rnd() * (double)n_pts);
+        check(L[j < n_pts ? j : n_pts - 1] + (float)(rnd() * 2.0 - 0.5) * dt);
+        check((float)(rnd() * (double)L[n_pts - 1]));
+        check(near - dt * (float)rnd());
+    }
+    // beyond the table
+    if ((long)L.size() < max_steps) {
+        const float far = L.back() * 1.5f + dt;
+        if (nfa::lattice_J(tb, far, half) != nfa::LATTICE_OFF_TABLE) bad[1]++;
+    }
+    return checked;
 }
 '''
 
@@ -247,3 +332,27 @@ def test_stepper_matches_serial(tmp_path):
         c1 = lib.approach_calls(C.c_float(0.0), C.c_float(2 * 3 ** 0.5 / 1024), C.c_float(thr), 1, C.byref(out[1]))
         assert out[0].value == out[1].value == float(a_serial(lib, 0.0, thr, 2 * 3 ** 0.5 / 1024))
         assert c0 >= 15 and c1 <= 4, (thr, c0, c1)
+
+
+def test_lattice_table_and_J_match_the_serial_loop(tmp_path):
+    """march.h's lattice table (rows of the sequence near, near + dt, ...) reproduces the serial accumulation point by
+    point, and J(thr) -- the fast three-probe form and the exact search -- is the serial loop's step count, for steps
+    with exact ties, power-of-two steps, near planes at 0 / inside a binade / at a binade edge, thresholds at row ends."""
+    lib = _build(tmp_path)
+    lib.lattice_check.restype = C.c_long
+    rng = np.random.default_rng(5)
+    cases = [(0.0, 2 * 3 ** 0.5 / 1024), (0.2, 1e-3), (0.0, 1e-3), (0.0, 0.01), (2.0, 0.01), (0.05, 5e-3), (0.0, 2.0 ** -8),
+             (0.0, 1.5 * 2.0 ** -9), (1.999999, 2.0 ** -9), (4.0, 2 * 3 ** 0.5 / 1024), (0.0, 0.3), (1e-3, 1e-5), (7.3, 0.11),
+             (0.0, 3.0), (100.0, 0.5)]
+    for _ in range(40):
+        cases.append((float(rng.choice([0.0, rng.random() * 3, 2.0 ** rng.integers(-3, 3)])), float(10 ** rng.uniform(-4.0, -0.5))))
+    total = fast = 0
+    for near, dt in cases:
+        bad = (C.c_long * 3)()
+        shape = (C.c_uint * 3)()
+        n = lib.lattice_check(C.c_float(near), C.c_float(dt), C.c_long(3_000_000), C.c_uint(int(rng.integers(1, 1 << 30))), C.c_long(3000),
+                              bad, shape)
+        assert shape[0] >= 1 and bad[0] == 0 and bad[1] == 0, (near, dt, list(bad), list(shape))
+        assert n > 3000
+        total += n; fast += bad[2]
+    assert fast > 0.5 * total      # the fast form serves most thresholds
