@@ -1020,7 +1020,7 @@ def main():
                 pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
             except Exception:
                 pass
-            sym = {"nfa_traverse_runs": "walk_kernel<", "nfa_expand_runs": "expand_runs_kernel",
+            sym = {"nfa_traverse_runs": "walk_", "nfa_expand_runs": "expand_runs_kernel",
                    "nfa_render_from_density_fwd": "DensityFwdOp", "nfa_render_from_density_bwd": "DensityBwdOp",
                    "nfa_render_accumulate_fwd": "RenderAccumOp", "nfa_render_accumulate_bwd": "RenderAccumBwdOp",
                    "nfa_render_fused_fwd": "RenderFusedFwdOp", "nfa_render_fused_bwd": "RenderFusedBwdOp",

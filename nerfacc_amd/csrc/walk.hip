@@ -813,7 +813,7 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
 // LATTICE: every ray starts at near_hint and the table of that near plane is in p.lat (phase 2 = lattice_run); otherwise
 // the per-ray marcher (per-ray near planes: the API's traverse_grids with a tensor of them, the chunks of the test-mode loop)
 template <bool FUSED, bool HAS_LIMIT, bool LATTICE>
-NFA_WALK_OCC __global__ __launch_bounds__(WK_THREADS) void walk_kernel(const nfa_traverse_args a, const WalkParams p)
+__device__ __forceinline__ void walk_body(const nfa_traverse_args &a, const WalkParams &p)
 {
     __shared__ __attribute__((aligned(16))) char ev_lds[(WK_EV + 1) << WK_LG];   // [WK_EV + 1][256] floats
     __shared__ ApproachLds tb;
@@ -859,6 +859,17 @@ NFA_WALK_OCC __global__ __launch_bounds__(WK_THREADS) void walk_kernel(const nfa
         o[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
     }
 #endif
+}
+// (two kernels: the register budget of the lattice form is held to 5 waves per SIMD, the per-ray marcher keeps what it needs)
+template <bool FUSED, bool HAS_LIMIT>
+NFA_WALK_OCC __global__ __launch_bounds__(WK_THREADS) void walk_lattice_kernel(const nfa_traverse_args a, const WalkParams p)
+{
+    walk_body<FUSED, HAS_LIMIT, true>(a, p);
+}
+template <bool FUSED, bool HAS_LIMIT>
+__global__ __launch_bounds__(WK_THREADS) void walk_kernel(const nfa_traverse_args a, const WalkParams p)
+{
+    walk_body<FUSED, HAS_LIMIT, false>(a, p);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1352,17 +1363,17 @@ int nfa_traverse_runs(const nfa_traverse_args *pa, const uint32_t *bits, int32_t
     const size_t shmem = 0;  // the lists are static LDS
     const unsigned grid = grid_1d(p.n_order, WK_THREADS, 1 << 20);
     const bool lim = a.traverse_steps_limit > 0;
-#define NFA_WALK_LAUNCH(F, L, T) hipLaunchKernelGGL((walk_kernel<F, L, T>), dim3(grid), dim3(WK_THREADS), shmem, s, a, p)
+#define NFA_WALK_LAUNCH(K, F, L) hipLaunchKernelGGL((K<F, L>), dim3(grid), dim3(WK_THREADS), shmem, s, a, p)
     if (lattice) {
-        if (fused && !lim)      NFA_WALK_LAUNCH(true, false, true);
-        else if (fused)         NFA_WALK_LAUNCH(true, true, true);
-        else if (!lim)          NFA_WALK_LAUNCH(false, false, true);
-        else                    NFA_WALK_LAUNCH(false, true, true);
+        if (fused && !lim)      NFA_WALK_LAUNCH(walk_lattice_kernel, true, false);
+        else if (fused)         NFA_WALK_LAUNCH(walk_lattice_kernel, true, true);
+        else if (!lim)          NFA_WALK_LAUNCH(walk_lattice_kernel, false, false);
+        else                    NFA_WALK_LAUNCH(walk_lattice_kernel, false, true);
     } else {
-        if (fused && !lim)      NFA_WALK_LAUNCH(true, false, false);
-        else if (fused)         NFA_WALK_LAUNCH(true, true, false);
-        else if (!lim)          NFA_WALK_LAUNCH(false, false, false);
-        else                    NFA_WALK_LAUNCH(false, true, false);
+        if (fused && !lim)      NFA_WALK_LAUNCH(walk_kernel, true, false);
+        else if (fused)         NFA_WALK_LAUNCH(walk_kernel, true, true);
+        else if (!lim)          NFA_WALK_LAUNCH(walk_kernel, false, false);
+        else                    NFA_WALK_LAUNCH(walk_kernel, false, true);
     }
 #undef NFA_WALK_LAUNCH
     NFA_CHECK_LAUNCH("traverse_runs");

@@ -20,7 +20,7 @@ for d in ("${TAG}_sq1", "${TAG}_sq2", "${TAG}_sq3"):
     agg = collections.defaultdict(list)
     for f in glob.glob("$OUT/" + d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            if "walk_kernel" not in row["Kernel_Name"]: continue
+            if "walk_lattice_kernel" not in row["Kernel_Name"] and "walk_kernel" not in row["Kernel_Name"]: continue
             agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
     for c, x in agg.items(): tot[c] = sum(x) / len(x)
 w = tot.get("SQ_WAVES", 1)
