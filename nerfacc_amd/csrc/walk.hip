@@ -592,15 +592,47 @@ __device__ __forceinline__ float dda_step(float dx, float dy, float dz, uint32_t
     return m;
 }
 
+// The same step with the per-axis constants in LDS (the constant-step walk's cell loop): row a of the lane's table holds
+// {axis a's delta in component a, +0 in the others; the axis' bits of the interleaved index}, so the chosen axis' row IS the
+// update of the three distances (t + 0 = t exactly: the distances are never -0) and no constant is selected in registers:
+// 5 half-rate + 22 full-rate instructions and one 16-byte LDS read per cell (registers: 5 + 27, and six registers more).
+// Rows of 16 bytes, lanes 16 bytes apart, axes 4096 bytes apart: a quad of lanes reads four different bank groups
+// whichever rows its lanes pick.
+constexpr uint32_t WK_TAB_AXIS = WK_THREADS * 16;
+static_assert((WK_TAB_AXIS & (WK_TAB_AXIS - 1)) == 0, "the row address is formed by OR-ing the axis offset into the lane's");
+__device__ __forceinline__ float dda_step_lds(const char *lds, uint32_t ax /* the lane's x row */, uint32_t az /* its z row */, float &tx,
+                                              float &ty, float &tz, uint32_t &rem, uint32_t &widx)
+{
+    const float m = min3_f32(tx, ty, tz);
+    const uint32_t kz = mask_less(m, tz), ky = mask_less(m, ty);   // ~0: that axis is NOT the minimum
+    uint32_t addr, dec;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xce" : "=v"(addr) : "v"(ky), "v"(ax), "s"(WK_TAB_AXIS));   // ky ? x row : y row  (b | (~a & c))
+    addr = sel_mask(kz, addr, az);
+    const nfa_v4f row = *reinterpret_cast<const nfa_v4f *>(lds + addr);
+    // (plain adds: left to itself the compiler pairs two of them into a half-rate v_pk_add_f32 behind two moves)
+    asm("v_add_f32 %0, %0, %1" : "+v"(tx) : "v"(row.x));
+    asm("v_add_f32 %0, %0, %1" : "+v"(ty) : "v"(row.y));
+    asm("v_add_f32 %0, %0, %1" : "+v"(tz) : "v"(row.z));
+    asm("v_bitop3_b32 %0, %1, 1, %2 bitop3:0xca" : "=v"(dec) : "v"(ky), "s"(1u << 10));          // ky ? 1 : 1 << 10
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca" : "=v"(dec) : "v"(kz), "v"(dec), "s"(1u << 20));  // kz ? that : 1 << 20
+    rem -= dec;
+    const uint32_t M = f32_bits(row.w);
+    uint32_t filled;
+    asm("v_bitop3_b32 %0, %1, %2, %2 bitop3:0xcf" : "=v"(filled) : "v"(M), "v"(widx));   // (M & widx) | ~M
+    filled += M & 7u;
+    widx = sel_mask(M, filled, widx);                                                   // (M & sum) | (~M & widx)
+    return m;
+}
+
 // One cell of the walk.  (w_cur, i_cur): the word of the grid copy that holds the occupancy bit of the cell the ray is in
 // and the bit's index -- requested when the ray entered the cell, one cell's worth of instructions ago; `open`: the kind of
 // the ray's open list entry.  Steps the DDA, looks at the current cell's bit, requests the next cell's word into the same
 // registers, closes the open entry when the occupancy flips and records the cell's exit distance in the open entry's slot.
-__device__ __forceinline__ void walk_cell(float dx, float dy, float dz, uint32_t mx, uint32_t my, uint32_t mz, uint32_t flip, float &tx,
+__device__ __forceinline__ void walk_cell(const char *tab_lds, uint32_t ax, uint32_t az, uint32_t flip, float &tx,
                                           float &ty, float &tz, uint32_t &rem, uint32_t &widx, uint32_t &ev_addr, float &m_out,
                                           uint32_t &w_cur, uint32_t &i_cur, int32_t &open, const uint32_t *__restrict__ bits, char *ev_lds)
 {
-    const float m = dda_step(dx, dy, dz, mx, my, mz, tx, ty, tz, rem, widx);   // exit distance of this cell (clamped to this_tmax by phase 2)
+    const float m = dda_step_lds(tab_lds, ax, az, tx, ty, tz, rem, widx);   // exit distance of this cell (clamped to this_tmax by phase 2)
     const uint32_t changed = __builtin_amdgcn_ubfe(w_cur, i_cur, 1u) ^ (uint32_t)open;   // bit (i_cur & 31) of the current cell's word
     i_cur = widx ^ flip;
 #if defined(NFA_WALK_EXP) && NFA_WALK_EXP == 1   /* timing experiment: no load at all */
@@ -663,8 +695,8 @@ struct WalkOut {
     int32_t n_samples, n_chains, n_runs;
 };
 template <bool FUSED, bool HAS_LIMIT, bool LATTICE>
-__device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkParams &p, int64_t tid, char *ev_lds, uint32_t lane_off,
-                                         const ApproachLds &tb, const LatticeLds &lt, WalkOut &out)
+__device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkParams &p, int64_t tid, char *ev_lds, char *tab_lds,
+                                         uint32_t lane_off, const ApproachLds &tb, const LatticeLds &lt, WalkOut &out)
 {
     Marcher s;
     LatState ls;
@@ -763,6 +795,12 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
                 *reinterpret_cast<float *>(col + ((kk + 1u) << WK_LG)) = this_tmax;
                 ev_span |= 1u << kk;
                 walk_span_setup(a, p.lay, o, d, level, this_tmin, this_tmax, sp);
+                {   // the span's per-axis constants: the lane's three rows of the table (dda_step_lds)
+                    char *row = tab_lds + 16u * threadIdx.x;
+                    *reinterpret_cast<nfa_v4f *>(row) = nfa_v4f{sp.dx, 0.0f, 0.0f, bits_f32(sp.mx)};
+                    *reinterpret_cast<nfa_v4f *>(row + WK_TAB_AXIS) = nfa_v4f{0.0f, sp.dy, 0.0f, bits_f32(sp.my)};
+                    *reinterpret_cast<nfa_v4f *>(row + 2 * WK_TAB_AXIS) = nfa_v4f{0.0f, 0.0f, sp.dz, bits_f32(sp.mz)};
+                }
                 const uint32_t idx0 = sp.widx ^ sp.flip;
                 w_cur = bits[idx0 >> 5]; i_cur = idx0;
                 open_type = (int32_t)((w_cur >> (idx0 & 31u)) & 1u);
@@ -773,8 +811,8 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
             }
             // the reference's cell loop (grid.cu:184-272) reduced to the DDA
             float tx = sp.tx, ty = sp.ty, tz = sp.tz;
-            const float dx = sp.dx, dy = sp.dy, dz = sp.dz;
-            const uint32_t mx = sp.mx, my = sp.my, mz = sp.mz, flip = sp.flip;
+            const uint32_t flip = sp.flip;
+            const uint32_t ax = 16u * threadIdx.x, az = ax + 2u * WK_TAB_AXIS;
             uint32_t rem = sp.rem;
             uint32_t widx = sp.widx;
             // Nothing in the cell loop reads LDS or scalar memory.  Without this the compiler's wait-count pass, which
@@ -786,7 +824,7 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
             rem = 0u;
 #else
             do {
-                walk_cell(dx, dy, dz, mx, my, mz, flip, tx, ty, tz, rem, widx, ev_addr, m_last, w_cur, i_cur, open_type, bits, ev_lds);
+                walk_cell(tab_lds, ax, az, flip, tx, ty, tz, rem, widx, ev_addr, m_last, w_cur, i_cur, open_type, bits, ev_lds);
             } while (!walk_stop(rem, ev_addr));
 #endif
             sp.tx = tx; sp.ty = ty; sp.tz = tz; sp.rem = rem; sp.widx = widx;
@@ -816,6 +854,7 @@ template <bool FUSED, bool HAS_LIMIT, bool LATTICE>
 __device__ __forceinline__ void walk_body(const nfa_traverse_args &a, const WalkParams &p)
 {
     __shared__ __attribute__((aligned(16))) char ev_lds[(WK_EV + 1) << WK_LG];   // [WK_EV + 1][256] floats
+    __shared__ __attribute__((aligned(16))) char tab_lds[3 * WK_TAB_AXIS];         // [3][256] rows of the DDA's per-axis constants
     __shared__ ApproachLds tb;
     __shared__ LatticeLds lt;
 #ifdef NFA_WALK_STAMPS
@@ -842,7 +881,7 @@ __device__ __forceinline__ void walk_body(const nfa_traverse_args &a, const Walk
             continue;
         }
         WalkOut s;
-        walk_ray<FUSED, HAS_LIMIT, LATTICE>(a, p, tid, ev_lds, lane_off, tb, lt, s);
+        walk_ray<FUSED, HAS_LIMIT, LATTICE>(a, p, tid, ev_lds, tab_lds, lane_off, tb, lt, s);
         if (a.terminate_planes) a.terminate_planes[tid] = s.t_last;
         a.sm_cnts[tid] = s.n_samples;
         if (a.iv_cnts) a.iv_cnts[tid] = s.n_samples + s.n_chains;  // edges = samples + one leading edge per chain
