@@ -39,7 +39,7 @@ constexpr int WK_EV = NFA_WK_EV;           // list slots per ray: 16 KiB of LDS 
 #else
 #define NFA_WALK_OCC
 #endif
-static_assert(NFA_WK_EV == 16, "the list-full test is one bit of the slot address: 16 slots");
+static_assert(NFA_WK_EV == 16 || NFA_WK_EV == 8, "the list-full test is one bit of the slot address: a power of two");
 #ifndef NFA_WALK_LG
 #define NFA_WALK_LG 10   /* log2 of the bytes of one list slot = 4 bytes x threads per workgroup: 10 = 256 threads */
 #endif
