@@ -1014,10 +1014,14 @@ def main():
                              "achieved_GBps": nbytes / (t_ms * 1e-3) / 1e9, "frac_of_hbm_peak": nbytes / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
             # HBM traffic from the PMC passes committed under profiles/ (collected with
             # scripts/collect_profiles.sh in separate rocprofv3 --pmc runs; 2 x FETCH_SIZE + WRITE_SIZE)
-            pmc, prof = {}, None
+            pmc, prof, stale = {}, None, None
             try:
+                from nerfacc_amd import _build as _nb
                 prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_hbm_traffic.json"))[-1]
                 pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
+                if pmc.pop("_library_source_hash", None) != _nb._source_hash():
+                    # counters of another build of the library say nothing about this one: not quoted
+                    stale, pmc = "profiles/" + prof + " was collected with another build of the library (scripts/collect_profiles.sh)", {}
             except Exception:
                 pass
             sym = {"nfa_traverse_runs": "walk_", "nfa_expand_runs": "expand_runs_kernel",
@@ -1050,7 +1054,7 @@ def main():
             out["roofline"] = {"bound": rated[dom]["bound"] if rated[dom]["bound"] != "issue" else "hbm", "kernel": dom,
                                "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a / HBM_PEAK_GBPS,
                                "traffic": rated[dom].get("hbm_traffic_bytes"),
-                               "traffic_source": rated[dom].get("hbm_traffic_source"),
+                               "traffic_source": rated[dom].get("hbm_traffic_source") or stale,
                                "ms_per_launch": rated[dom]["ms_per_launch"],
                                "algorithmic_bytes_per_launch": rated[dom]["algorithmic_bytes_per_launch"],
                                "limiter": rated[dom]["bound"]}

@@ -38,7 +38,14 @@ extern "C" {
 typedef void *nfa_stream_t; /* hipStream_t */
 
 const char *nfa_last_error(void);
-int nfa_version(void);          /* 10000*major + 100*minor + patch */
+/* The version of THIS header.  Bumped whenever an entry point changes its arguments or what it expects of them; a caller
+ * built against another value must not call the library (nerfacc_amd/_backend.py refuses to load it). */
+#define NFA_VERSION 400
+int nfa_version(void);          /* NFA_VERSION of the header the library was built from */
+/* Knobs of the A/B tests and measurement scripts (which of two equivalent kernels a call takes, tile sizes); value NULL
+ * or "" unsets.  Names: NFA_REFILL, NFA_REFILL_ALL, NFA_CONE_STAGED, NFA_SEG_TILE, NFA_WALK_NO_LATTICE.  Results never
+ * depend on them.  Not thread-safe: set before the calls that should see them. */
+int nfa_set_tuning(const char *name, const char *value);
 int nfa_device_arch(char *buf, int buflen); /* gcnArchName of the current device */
 
 /* ------------------------------------------------------------------ utilities */

@@ -102,6 +102,7 @@ _SIGS = {
     "nfa_cumsum_scratch_bytes": [_i64],
     "nfa_last_error": [],
     "nfa_version": [],
+    "nfa_set_tuning": [C.c_char_p, C.c_char_p],
     "nfa_device_arch": [C.c_char_p, _int],
 }
 _RESTYPES = {"nfa_grid_rebinarize_scratch_bytes": _i64, "nfa_bricks_words": _i64, "nfa_walk_bits_words": _i64, "nfa_pdf_loss_partials": _i64, "nfa_cumsum_scratch_bytes": _i64, "nfa_seg_table_rows": _i64, "nfa_seg_plan": None, "nfa_last_error": C.c_char_p}
@@ -133,8 +134,19 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError => header and library disagree
             fn.argtypes = argtypes
             fn.restype = _RESTYPES[name] if name in _RESTYPES else _int
+        if lib.nfa_version() != ABI_VERSION:
+            raise RuntimeError(f"nerfacc_amd: {path} was built from include/nerfacc_hip.h version {lib.nfa_version()}, these "
+                               f"bindings are written for {ABI_VERSION}: rebuild the library (nerfacc_amd._build.build(force=True))")
         _lib = lib
     return _lib
+
+
+ABI_VERSION = 400   # include/nerfacc_hip.h: NFA_VERSION
+
+
+def set_tuning(name: str, value: Optional[str]) -> None:
+    """A/B knobs of the tests and measurement scripts (include/nerfacc_hip.h: nfa_set_tuning); None unsets."""
+    call("nfa_set_tuning", name.encode(), None if value is None else str(value).encode())
 
 
 class NativeError(RuntimeError):

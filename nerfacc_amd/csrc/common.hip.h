@@ -32,6 +32,10 @@ void set_error(const char *fmt, ...);
         }                                                                            \
     } while (0)
 
+// Knobs of the A/B tests and measurement scripts, set through nfa_set_tuning (grid.hip); the entry points do not read the
+// environment.  NULL: not set.
+const char *tuning_env(const char *name);
+
 static inline hipStream_t as_stream(nfa_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 __host__ __device__ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

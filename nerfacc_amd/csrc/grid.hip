@@ -25,6 +25,17 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+// knobs of the A/B tests and measurement scripts (nfa_set_tuning): a handful of {name, value} pairs
+struct TuningKnob { char name[32]; char value[64]; };
+static TuningKnob g_knobs[8];
+static int g_n_knobs = 0;
+const char *tuning_env(const char *name)
+{
+    for (int i = 0; i < g_n_knobs; ++i)
+        if (strcmp(g_knobs[i].name, name) == 0) return g_knobs[i].value[0] ? g_knobs[i].value : nullptr;
+    return nullptr;
+}
+
 // ------------------------------------------------------------------------------------------
 // Slab test, grid.cu:284-313 / include/utils_grid.cuh:10-55.
 __device__ __forceinline__ bool slab_test(const float o[3], const float inv[3], const float *bmin,
@@ -755,7 +766,20 @@ using namespace nfa;
 extern "C" {
 
 const char *nfa_last_error(void) { return g_err; }
-int nfa_version(void) { return 100; }
+int nfa_version(void) { return NFA_VERSION; }
+int nfa_set_tuning(const char *name, const char *value)
+{
+    NFA_REQUIRE(name && strlen(name) > 0 && strlen(name) < sizeof(g_knobs[0].name), "set_tuning: bad name");
+    NFA_REQUIRE(!value || strlen(value) < sizeof(g_knobs[0].value), "set_tuning: value too long");
+    int i = 0;
+    while (i < g_n_knobs && strcmp(g_knobs[i].name, name) != 0) ++i;
+    if (i == g_n_knobs) {
+        NFA_REQUIRE(g_n_knobs < (int)(sizeof(g_knobs) / sizeof(g_knobs[0])), "set_tuning: too many knobs");
+        strcpy(g_knobs[g_n_knobs++].name, name);
+    }
+    strcpy(g_knobs[i].value, value ? value : "");
+    return NFA_OK;
+}
 
 int nfa_device_arch(char *buf, int buflen)
 {
@@ -907,8 +931,8 @@ int nfa_traverse_cone_runs(const nfa_traverse_args *pa, int32_t *run_cnts, uint6
     ro.n_order = ray_order ? n_order : a.n_rays;
     NFA_REQUIRE(!ray_order || (n_order >= 0 && n_order <= a.n_rays), "traverse_cone_runs: n_order out of range");
     if (ray_order && n_order == 0) return NFA_OK;
-    const char *refill_env = getenv("NFA_REFILL");  // "0": one ray per lane; "chunk,min_busy": tuning
-    const char *refill_all = getenv("NFA_REFILL_ALL");
+    const char *refill_env = tuning_env("NFA_REFILL");  // "0": one ray per lane; "chunk,min_busy": tuning
+    const char *refill_all = tuning_env("NFA_REFILL_ALL");
     if ((a.traverse_steps_limit > 0 || (refill_all && refill_all[0] == '1')) && !(refill_env && refill_env[0] == '0')) {
         // slots per wave: enough of them that a lane is refilled several times, as long as the launch still fills the chip
         const int64_t n_walk = ro.n_order;

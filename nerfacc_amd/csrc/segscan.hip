@@ -1830,7 +1830,7 @@ void nfa_seg_plan(int64_t n_elems, int64_t n_rays, int64_t *tile_elems, int64_t 
     // One wave per tile.  Measured on MI355X (scripts/sweep_seg.sh, 32 M samples): 1024-element tiles
     // (4 steps per wave, ~120 waves per CU) are fastest; longer tiles lose to the tail of the last
     // wave round, shorter ones to the per-tile prologue.  A tile also ends after SEG_TILE_ROWS rays.
-    static const int64_t t_env = getenv("NFA_SEG_TILE") ? atoll(getenv("NFA_SEG_TILE")) : 0;  // tuning knob (multiple of 4), read once
+    const int64_t t_env = tuning_env("NFA_SEG_TILE") ? atoll(tuning_env("NFA_SEG_TILE")) : 0;  // tuning knob (multiple of 4), read once
     const int64_t t = t_env > 0 ? t_env : 1024;
     *tile_elems = t;
     *n_tiles = n_elems / t + (n_rays > 0 ? n_rays : 0) / SEG_TILE_ROWS + 1;

@@ -1392,7 +1392,7 @@ int nfa_traverse_runs(const nfa_traverse_args *pa, const uint32_t *bits, int32_t
     // raise overflow_count[1], and the caller repeats the call with near_hint = NaN: the per-ray marcher.
     p.approach.n = 0;
     p.lat.n_rows = 0;
-    if (near_hint == near_hint && !getenv("NFA_WALK_NO_LATTICE")) lattice_table_build(p.lat, near_hint, a.step_size);
+    if (near_hint == near_hint && !tuning_env("NFA_WALK_NO_LATTICE")) lattice_table_build(p.lat, near_hint, a.step_size);
     const bool lattice = p.lat.n_rows >= 1 && p.lat.n_binades >= 1;
     if (!lattice && near_hint == near_hint) approach_table_build(p.approach, near_hint, a.step_size);
 #ifdef NFA_WALK_STAMPS
@@ -1460,8 +1460,8 @@ int nfa_traverse_cone_walk(const nfa_traverse_args *pa, const uint32_t *bits, in
         p.profile = e ? reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 0)) : nullptr;
     }
 #endif
-    const char *refill_env = getenv("NFA_REFILL");  // "0": one ray per lane also for limited walks; "chunk,min_busy": tuning
-    const char *refill_all = getenv("NFA_REFILL_ALL");   // "1": the refilling kernel for unlimited walks too (measurements)
+    const char *refill_env = tuning_env("NFA_REFILL");  // "0": one ray per lane also for limited walks; "chunk,min_busy": tuning
+    const char *refill_all = tuning_env("NFA_REFILL_ALL");   // "1": the refilling kernel for unlimited walks too (measurements)
     if ((a.traverse_steps_limit > 0 || (refill_all && refill_all[0] == '1')) && !(refill_env && refill_env[0] == '0')) {
         // entries per wave: enough of them that a lane is refilled several times, as long as the launch still fills the chip
         int64_t chunk = ((p.n_order + 4095) / 4096 + 63) / 64 * 64;
@@ -1471,7 +1471,7 @@ int nfa_traverse_cone_walk(const nfa_traverse_args *pa, const uint32_t *bits, in
         p.chunk = (int32_t)chunk; p.min_busy = min_busy;
         const int64_t n_waves = (p.n_order + chunk - 1) / chunk;
         const unsigned grid = (unsigned)((n_waves + 3) / 4);
-        const char *staged_env = getenv("NFA_CONE_STAGED");   // "0": event lists read from memory (A/B)
+        const char *staged_env = tuning_env("NFA_CONE_STAGED");   // "0": event lists read from memory (A/B)
         const bool staged = !fused && 2 * a.n_grids <= CONE_EV_MAX && !(staged_env && staged_env[0] == '0');
         if (fused)       hipLaunchKernelGGL((cone_refill_kernel<true, false>), dim3(grid), dim3(256), 0, s, a, p);
         else if (staged) hipLaunchKernelGGL((cone_refill_kernel<false, true>), dim3(grid), dim3(256), 0, s, a, p);

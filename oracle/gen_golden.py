@@ -539,8 +539,44 @@ def occgrid_fixtures():
     save("occgrid", **out)
 
 
+# ----------------------------------------------------------------------------- 8. the public signatures
+API_NAMES = ["inclusive_prod", "exclusive_prod", "inclusive_sum", "exclusive_sum", "pack_info",
+             "render_visibility_from_alpha", "render_visibility_from_density", "render_weight_from_alpha",
+             "render_weight_from_density", "render_transmittance_from_alpha", "render_transmittance_from_density",
+             "accumulate_along_rays", "rendering", "importance_sampling", "searchsorted", "RayIntervals",
+             "RaySamples", "ray_aabb_intersect", "traverse_grids", "OccGridEstimator", "PropNetEstimator"]
+API_METHODS = {"OccGridEstimator": ["__init__", "sampling", "update_every_n_steps", "mark_invisible_cells"],
+               "PropNetEstimator": ["__init__", "sampling", "update_every_n_steps", "compute_loss"]}
+
+
+def signature_table(pkg):
+    """{name: [[parameter, kind, default or None], ...]} of a package's public callables (nerfacc/__init__.py:23-46)."""
+    import inspect
+
+    def params(fn):
+        return [[p.name, p.kind.name, None if p.default is inspect.Parameter.empty else repr(p.default)]
+                for p in inspect.signature(fn).parameters.values()]
+    out = {}
+    for n in API_NAMES:
+        obj = getattr(pkg, n)
+        out[n] = params(obj)
+        for m in API_METHODS.get(n, []):
+            out[f"{n}.{m}"] = params(getattr(obj, m))
+    return out
+
+
+def api_signatures():
+    import json
+    path = os.path.join(OUT, "api_signatures.json")
+    with open(path, "w") as f:
+        json.dump(signature_table(nerfacc), f, indent=1, sort_keys=True)
+        f.write("\n")
+    print(f"  wrote api_signatures.json ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
 if __name__ == "__main__":
-    for fn in (ragged_packed, batched_volrend, ray_aabb, pdf_fixtures, traversal_fixtures, propnet_fixtures, occgrid_fixtures):
+    for fn in (ragged_packed, batched_volrend, ray_aabb, pdf_fixtures, traversal_fixtures, propnet_fixtures, occgrid_fixtures,
+               api_signatures):
         print(fn.__name__)
         fn()
     print("oracle pinned against the reference; fixtures written to", OUT)

@@ -22,7 +22,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SRC = os.path.join(_HERE, "nerfacc_oracle.c")
 _BUILD = os.path.join(_HERE, "_build")
-_SO = os.path.join(_BUILD, "libnerfacc_oracle.so")
+# ORACLE_SANITIZE=1: a second build with AddressSanitizer + UndefinedBehaviorSanitizer (oracle/sanitize.sh runs the CPU
+# tests against it; the sanitizer runtime must then be preloaded into python)
+_SANITIZE = os.environ.get("ORACLE_SANITIZE", "0") != "0"
+_SO = os.path.join(_BUILD, "libnerfacc_oracle_san.so" if _SANITIZE else "libnerfacc_oracle.so")
 
 _lib = None
 
@@ -33,6 +36,8 @@ def build(force: bool = False) -> str:
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
         cmd = ["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-shared", "-fPIC",
                "-fvisibility=hidden", "-o", _SO + ".tmp", _SRC, "-lm"]
+        if _SANITIZE:
+            cmd[1:2] = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
         subprocess.run(cmd, check=True)
         os.replace(_SO + ".tmp", _SO)
     return _SO

@@ -4,10 +4,11 @@
 # with trace domains other than kernel-trace).  Outputs land in gpurun_out/<tag>_*; summarise with
 # scripts/summarize_profiles.py, which writes the files committed under profiles/.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
+(cd $R && python -c "from nerfacc_amd import _build; _build.build(); print(_build._source_hash())" > $OUT/${TAG}_source_hash.txt)   # ties the counters to the library they were taken from
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-pipelined --no-extras"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- $CMD > $OUT/${TAG}_trace.log 2>&1

@@ -56,7 +56,12 @@ for k in sorted(set(fetch) | set(write)):
     out[k] = {"avg_us": avg_us.get(k), "FETCH_SIZE_bytes_raw": fb, "WRITE_SIZE_bytes": wb,
               "hbm_bytes_per_launch": 2 * fb + wb,
               "hbm_GBps": (2 * fb + wb) / (avg_us[k] * 1e-6) / 1e9 if avg_us.get(k) else None}
+# the content hash of the library sources the counters were taken with (collect_profiles.sh); bench.py quotes the traffic
+# only while the library it runs still has this hash
+hash_file = os.path.join(src, f"{tag}_source_hash.txt")
+out["_library_source_hash"] = open(hash_file).read().strip().splitlines()[-1] if os.path.exists(hash_file) else None
 json.dump(out, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1)
+out.pop("_library_source_hash")
 print(f"wrote profiles/{tag}_kernel_stats.csv and profiles/{tag}_hbm_traffic.json")
 for k, v in sorted(out.items(), key=lambda kv: -(kv[1]["avg_us"] or 0))[:12]:
     print(f"  {v['avg_us']:8.1f} us  {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB  {v['hbm_GBps']:8.1f} GB/s  {k[:70]}")

@@ -1,9 +1,11 @@
-"""Results of the packed ops must not depend on the tiling: run with NFA_SEG_TILE=256 / 1024 / 4096 (read once per process)
+"""Results of the packed ops must not depend on the tiling: run with NFA_SEG_TILE=256 / 1024 / 4096 in the environment (handed to nfa_set_tuning)
 and compare the digests.  Random ragged batches: empty rays, runs of tiny rays, long rays."""
 import hashlib, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nerfacc_amd as na
+from nerfacc_amd import _backend as NB
+NB.set_tuning("NFA_SEG_TILE", os.environ.get("NFA_SEG_TILE"))   # (the knob of include/nerfacc_hip.h: nfa_set_tuning)
 dev = torch.device("cuda:0")
 h = hashlib.sha256()
 for seed in range(12):

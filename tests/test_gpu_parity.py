@@ -50,7 +50,8 @@ def test_cone_walk_forms_agree_and_match_oracle(dev, oracle):
         (2, (50, 24, 30), 0.3, 3_000, 5e-3, 0.05, 40, False, True),
         (5, (16, 16, 16), 0.05, 6_000, 1e-2, 0.004, 5, True, True),    # ten events per ray: the refill kernel reads them from memory
     ]
-    saved = (na.grid.CONE_WALK, os.environ.get("NFA_REFILL"))
+    from nerfacc_amd import _backend as NB
+    saved = (na.grid.CONE_WALK,)
     try:
         for levels, res, occ, R, step, cone, limit, masked, inside in cases:
             est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=list(res), levels=levels).to(dev)
@@ -68,10 +69,7 @@ def test_cone_walk_forms_agree_and_match_oracle(dev, oracle):
             for form, (walk, refill) in {"walk": (True, None), "walk, one ray per lane": (True, "0"), "bricks": (False, None),
                                          "bricks, one ray per lane": (False, "0"), "walk, small chunks": (True, "64,40")}.items():
                 na.grid.CONE_WALK = walk
-                if refill is None:
-                    os.environ.pop("NFA_REFILL", None)
-                else:
-                    os.environ["NFA_REFILL"] = refill
+                NB.set_tuning("NFA_REFILL", refill)
                 outs[form] = na.grid._traverse_samples(*args, **kw)
             ref = outs["walk"]
             assert ref[0].numel() > 500, (levels, res, ref[0].numel())
@@ -97,16 +95,13 @@ def test_cone_walk_forms_agree_and_match_oracle(dev, oracle):
             outs2 = []
             for walk, refill in ((True, None), (False, None), (True, "0")):
                 na.grid.CONE_WALK = walk
-                os.environ.pop("NFA_REFILL", None) if refill is None else os.environ.__setitem__("NFA_REFILL", refill)
+                NB.set_tuning("NFA_REFILL", refill)
                 outs2.append(na.grid._traverse_samples(*args2, **kw))
             assert all(torch.equal(x, y) for got in outs2[1:] for x, y in zip(outs2[0], got))
             assert (outs2[0][3][:5, 1] == 0).all()
     finally:
         na.grid.CONE_WALK = saved[0]
-        if saved[1] is None:
-            os.environ.pop("NFA_REFILL", None)
-        else:
-            os.environ["NFA_REFILL"] = saved[1]
+        NB.set_tuning("NFA_REFILL", None)
 
 
 # ----------------------------------------------------------------------------- pack / scans
@@ -1994,7 +1989,7 @@ print("OK captured", ok, captured.replays)
 def test_results_do_not_depend_on_the_tiling():
     """The packed ops (rendering forward / backward, visibility, weights, accumulation, scans) on twelve random ragged
     batches -- empty rays, runs of tiny rays, rays of thousands of samples -- give the same bits whatever the tile size:
-    the library reads NFA_SEG_TILE once per process, so each size runs in a child process (scripts/tiling_invariance.py)
+    each size runs in a child process (scripts/tiling_invariance.py hands NFA_SEG_TILE to nfa_set_tuning)
     and the digests of all outputs are compared."""
     import subprocess
     import sys

@@ -9,14 +9,31 @@ from conftest import assert_close, load_golden
 
 
 def test_api_surface_matches_reference():
-    # nerfacc/__init__.py:23-46
-    names = ["inclusive_prod", "exclusive_prod", "inclusive_sum", "exclusive_sum", "pack_info",
-             "render_visibility_from_alpha", "render_visibility_from_density", "render_weight_from_alpha",
-             "render_weight_from_density", "render_transmittance_from_alpha", "render_transmittance_from_density",
-             "accumulate_along_rays", "rendering", "importance_sampling", "searchsorted", "RayIntervals",
-             "RaySamples", "ray_aabb_intersect", "traverse_grids", "OccGridEstimator", "PropNetEstimator"]
-    for n in names:
-        assert hasattr(na, n), n
+    """Every public callable of the reference (nerfacc/__init__.py:23-46) and the estimators' methods exist with the
+    reference's parameters -- same names, order, kinds and defaults; tests/golden/api_signatures.json was written by
+    oracle/gen_golden.py from the imported reference.  Extensions are allowed only as further parameters WITH defaults
+    behind the reference's (or keyword-only), so every call the reference accepts means the same here."""
+    import inspect
+    import json
+    import os
+    from conftest import ROOT
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "api_signatures.json")))
+    assert len(ref) >= 29
+    for name, want in ref.items():
+        obj = na
+        for part in name.split("."):
+            assert hasattr(obj, part), name
+            obj = getattr(obj, part)
+        got = [[p.name, p.kind.name, None if p.default is inspect.Parameter.empty else repr(p.default)]
+               for p in inspect.signature(obj).parameters.values()]
+        var_kw = [p for p in want if p[1] == "VAR_KEYWORD"]
+        want_fixed = [p for p in want if p[1] != "VAR_KEYWORD"]
+        got_fixed = [p for p in got if p[1] != "VAR_KEYWORD"]
+        assert got_fixed[:len(want_fixed)] == want_fixed, (name, got_fixed[:len(want_fixed)], want_fixed)
+        for extra in got_fixed[len(want_fixed):]:
+            assert extra[2] is not None or extra[1] == "KEYWORD_ONLY", (name, extra)
+        if var_kw:
+            assert any(p[1] == "VAR_KEYWORD" for p in got), name
 
 
 def test_batched_paths_match_reference_outputs():
