@@ -297,11 +297,13 @@ class OccGridEstimator(AbstractEstimator):
         The reference filters with a boolean index and a ``nonzero`` per level (each a device synchronisation, three per
         level).  Here the two selections are stable compactions by prefix sum + scatter for all levels at once, with ONE
         host read (the levels' output sizes); same cells in the same order as the reference's expressions."""
-        if self.occs.is_cuda:
+        if self.occs.is_cuda and self.levels * self.cells_per_lvl <= self.ONE_READ_MAX_CELLS:
             return self._sample_cells_one_read(n)
+        # (CPU tensors, and grids so large that the one-read form's all-level prefix sums would take gigabytes -- 4 x 512^3:
+        #  the reference's per-level expressions, whose temporaries are one level's draws and its occupied cells)
         dev, L, cells = self.occs.device, self.levels, self.cells_per_lvl
         out = []
-        for lvl in range(L):   # (CPU tensors: the reference's expressions)
+        for lvl in range(L):
             uni = torch.randint(cells, (n,), device=dev)
             uni = uni[self.occs[lvl * cells + uni] >= 0.0]
             occ = torch.nonzero(self.binaries[lvl].flatten())[:, 0]
@@ -310,14 +312,19 @@ class OccGridEstimator(AbstractEstimator):
             out.append(torch.cat([uni, occ], dim=0))
         return out
 
+    #: largest grid (cells over all levels) whose cell selection runs in the one-read form: its prefix sums and draws are
+    #: int32 arrays over all levels at once (2^27 cells: ~1.3 GB of temporaries)
+    ONE_READ_MAX_CELLS = 1 << 27
+
     @torch.no_grad()
     def _sample_cells_one_read(self, n: int) -> List[Tensor]:
         dev, L, cells = self.occs.device, self.levels, self.cells_per_lvl
         uni = torch.randint(cells, (L, n), device=dev)                                     # ref :350
         uni_ok = self.occs.view(L, cells).gather(1, uni) >= 0.0                             # ref :352-353
-        uni_pos = torch.cumsum(uni_ok, dim=1)                                               # 1-based slot of every kept draw
+        # (int32: a level has fewer than 2^31 cells; half the memory of the default int64 prefix sums)
+        uni_pos = torch.cumsum(uni_ok, dim=1, dtype=torch.int32)                            # 1-based slot of every kept draw
         occ_flag = self.binaries.view(L, cells)
-        occ_pos = torch.cumsum(occ_flag, dim=1)
+        occ_pos = torch.cumsum(occ_flag, dim=1, dtype=torch.int32)
         sizes = torch.stack([uni_pos[:, -1], occ_pos[:, -1]], dim=1).tolist()              # the one device -> host read
         out = []
         cell_ids = torch.arange(cells, device=dev)
@@ -325,15 +332,15 @@ class OccGridEstimator(AbstractEstimator):
             n_uni, n_occ = int(n_uni), int(n_occ)
             if n < n_occ:   # ref :356-360: n of the occupied cells, drawn with replacement = the k-th occupied cell for random k
                 k = torch.randint(n_occ, (n,), device=dev)
-                occ = torch.searchsorted(occ_pos[lvl], k + 1)                               # first cell whose count reaches k + 1
+                occ = torch.searchsorted(occ_pos[lvl], (k + 1).to(torch.int32))             # first cell whose count reaches k + 1
                 n_take = n
             else:
                 occ, n_take = None, n_occ
             res = torch.empty(n_uni + n_take + 1, dtype=torch.int64, device=dev)            # (+1: the slot dropped entries land in)
             dump = n_uni + n_take
-            res.scatter_(0, torch.where(uni_ok[lvl], uni_pos[lvl] - 1, dump), uni[lvl])
+            res.scatter_(0, torch.where(uni_ok[lvl], uni_pos[lvl] - 1, dump).long(), uni[lvl])
             if occ is None:
-                res.scatter_(0, torch.where(occ_flag[lvl], n_uni + occ_pos[lvl] - 1, dump), cell_ids)
+                res.scatter_(0, torch.where(occ_flag[lvl], n_uni + occ_pos[lvl] - 1, dump).long(), cell_ids)
             else:
                 res[n_uni:dump] = occ
             out.append(res[:dump])
