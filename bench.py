@@ -238,6 +238,9 @@ def make_workload(dev, n_rays: int = 1024 * 1024, res: int = 128, grid: str = "s
                 n_rays=n_rays, res=res, sigma_scale=float(sigma_scale))
 
 
+_DIST_INFO: dict = {}   # what the distributed glue did in this process (reported on the JSON line under "distributed")
+
+
 def shared_grid(dev, res: int, grid: str, rank: int, world: int) -> torch.Tensor:
     """BASELINE cfg 4: ONE occupancy grid for all ranks.  Rank 0 builds it and broadcasts it once, bit-packed (res^3 / 8
     bytes over RCCL), every rank unpacks it into the torch.bool layout the estimator keeps."""
@@ -247,6 +250,9 @@ def shared_grid(dev, res: int, grid: str, rank: int, world: int) -> torch.Tensor
         packed.copy_(torch.from_numpy(np.packbits(make_grid(res, grid).reshape(-1))).to(dev))
     if world > 1 or _group_live():
         torch.distributed.broadcast(packed, src=0)
+    import hashlib
+    _DIST_INFO["shared_grid_sha256"] = hashlib.sha256(packed.cpu().numpy().tobytes()).hexdigest()   # what this rank received
+    _DIST_INFO["shared_grid_bytes"] = int(packed.numel())
     shifts = torch.arange(7, -1, -1, device=dev, dtype=torch.uint8)
     bits = ((packed[:, None] >> shifts) & 1).reshape(-1)[:n]
     return bits.bool().reshape(1, res, res, res)
@@ -307,6 +313,7 @@ def allreduce_grads(params, world: int):
     if world > 1 or _group_live():
         for p in params:
             torch.distributed.all_reduce(p.grad, op=torch.distributed.ReduceOp.SUM)
+        _DIST_INFO["grad_allreduces"] = _DIST_INFO.get("grad_allreduces", 0) + len(params)
 
 
 def _group_live() -> bool:
@@ -493,25 +500,54 @@ def extra_cfg4_per_rank(dev, args, res=256):
             "native_ms_per_step": sum(v["ms_per_step"] for v in ks.values())}
 
 
+def _cfg3_fields(p0=3.0, p1=4.0):
+    """numpy twins of the cfg-3 density callbacks (NativePropField / the torch lambdas of extra_cfg3) and d sigma / d p."""
+    f = np.float32
+    prop = lambda ts, te: (np.exp(-((ts + te) * f(0.5) - f(p1)) ** 2) * f(p0)).astype(np.float32)
+    fine = lambda ts, te: (np.exp(-((ts + te) * f(0.5) - f(4.0)) ** 2 * f(2.0)) * f(5.0)).astype(np.float32)
+    dprop = lambda ts, te, sig: (sig / f(p0), sig * f(2.0) * ((ts + te) * f(0.5) - f(p1)))
+    return prop, fine, dprop
+
+
+def _cfg3_oracle_step(O, R, p0=3.0, p1=4.0, backward=True):
+    """One cfg-3 step restated by the oracle: PropNetEstimator.sampling's level loop (ref estimators/prop_net.py:38-129), the fine
+    transmittance, compute_loss (:131-154) and its backward to the proposal density's two parameters.
+    Returns (t_starts, t_ends, loss, grad_p)."""
+    prop, fine, dprop = _cfg3_fields(p0, p1)
+    ts, te, levels, fvals = O.propnet_sampling([prop, prop], [64, 64], 16, R, 2.0, 6.0, sampling_type="uniform", stratified=False,
+                                               return_final_vals=True)
+    trans = O.batched_transmittance_from_density(ts, te, fine(ts, te))
+    if not backward:
+        return ts, te, None, None
+    loss, g_cdfs = O.propnet_loss(levels, fvals, trans)
+    gp = np.zeros(2, np.float64)
+    for (vals, _), g in zip(levels, g_cdfs):
+        t = O.transform_stot("uniform", vals, 2.0, 6.0)
+        a, b = t[..., :-1], t[..., 1:]
+        sig = prop(a, b)
+        g_sig = O.density_cdf_backward(a, b, sig, g)
+        d0, d1 = dprop(a, b, sig)
+        gp += [float((g_sig * d0).astype(np.float64).sum()), float((g_sig * d1).astype(np.float64).sum())]
+    return ts, te, loss, gp
+
+
 def _cfg3_cpu_baseline(R=1 << 17, min_seconds=4.0):
-    """cfg 3 on the host: the oracle's restatement of PropNetEstimator.sampling's level loop (2 -> 64 -> 64 -> 16, uniform;
-    ref estimators/prop_net.py:38-129, resampling = pdf.cu's kernels in C/OpenMP, the batched transmittance and the s -> t
-    map in numpy as the reference's own CPU path is torch elementwise) + the fine transmittance, on a bounded sample of
-    rays.  Forward only: the oracle restates no backward of the proposal loss."""
+    """cfg 3 on the host, forward AND backward like the GPU figure: the oracle's restatement of PropNetEstimator.sampling's level
+    loop (2 -> 64 -> 64 -> 16, uniform; ref estimators/prop_net.py:38-129, resampling = pdf.cu's kernels in C/OpenMP, the batched
+    transmittance and the s -> t map in numpy as the reference's own CPU path is torch elementwise), the fine transmittance,
+    compute_loss and its backward to the proposal parameters (oracle.propnet_loss / density_cdf_backward), on a bounded
+    sample of rays."""
     from oracle import oracle as O
     O.build()
-    prop = lambda ts, te: (np.exp(-((ts + te) * np.float32(0.5) - np.float32(4.0)) ** 2) * np.float32(3.0)).astype(np.float32)
-    fine = lambda ts, te: (np.exp(-((ts + te) * np.float32(0.5) - np.float32(4.0)) ** 2 * np.float32(2.0)) * np.float32(5.0)).astype(np.float32)
     total, reps = 0.0, 0
     while total < min_seconds and reps < 50:
         t0 = time.perf_counter()
-        ts, te, _ = O.propnet_sampling([prop, prop], [64, 64], 16, R, 2.0, 6.0, sampling_type="uniform", stratified=False)
-        O.batched_transmittance_from_density(ts, te, fine(ts, te))
+        _cfg3_oracle_step(O, R)
         total += time.perf_counter() - t0
         reps += 1
     return dict(value=R * reps / total, unit="rays/s", cores=O.max_threads(), kind="port", cpu_model=cpu_model(),
-                sample=f"{reps} passes over {R} rays (of the GPU's {1 << 20}), forward only, {total:.1f} s; C/OpenMP resampling, "
-                       f"numpy (one thread) for the elementwise s -> t map, densities and transmittance")
+                sample=f"{reps} passes over {R} rays (of the GPU's {1 << 20}), forward + proposal-loss backward, {total:.1f} s; C/OpenMP "
+                       f"resampling and searchsorted, numpy (one thread) for the elementwise s -> t map, densities, transmittance, loss")
 
 
 def extra_cfg2_testmode(dev, args, n_img=3, parity=True):
@@ -597,7 +633,35 @@ def extra_cfg3(dev, R, steps, field="native", cpu_base=True):
             cpu = _cfg3_cpu_baseline()
         except Exception as e:  # must never cost the timing
             cpu = {"error": repr(e)}
-    return {"cpu_baseline": cpu,
+    # parity of the timed configuration: one more step at the parameters training has reached, every n-th ray restated by
+    # the oracle (final samples, loss, gradient of the loss to the two proposal parameters)
+    parity = None
+    if cpu_base:
+        try:
+            from oracle import oracle as O
+            O.build()
+            p0, p1 = (float(v) for v in p.detach().cpu().tolist())
+            ts, te = est.sampling([prop, prop], [64, 64], 16, R, 2.0, 6.0, sampling_type="uniform", stratified=False, requires_grad=True)
+            trans, _ = na.render_transmittance_from_density(ts, te, fine(ts, te))
+            p.grad = None
+            g_loss = est.compute_loss(trans)
+            g_loss.backward()
+            g_grad = p.grad.detach().double().cpu().numpy()
+            n_sub = 4096
+            sub = torch.arange(0, R, max(1, R // n_sub), device=dev)[:n_sub]
+            o_ts, o_te, o_loss, o_grad = _cfg3_oracle_step(O, int(sub.numel()), p0, p1)
+            e_t = max(float(np.abs(ts[sub].detach().cpu().numpy() - o_ts).max()), float(np.abs(te[sub].detach().cpu().numpy() - o_te).max()))
+            # (every ray of this synthetic batch sees the same 1-D problem, so the subset's mean loss is the batch's; the
+            #  gradient is a sum over rays divided by the ray count inside the mean: the same)
+            e_l = abs(float(g_loss) - o_loss) / max(abs(o_loss), 1e-30)
+            e_g = float(np.abs(g_grad - o_grad).max() / max(np.abs(o_grad).max(), 1e-30))
+            parity = {"checked": True, "rays_restated": int(sub.numel()), "params": [p0, p1], "max_abs_err_t": e_t, "t_range": 4.0,
+                      "tol_t": 1e-5 * 4.0, "loss_gpu": float(g_loss), "loss_oracle": o_loss, "rel_err_loss": e_l, "tol_loss": 1e-5,
+                      "grad_gpu": g_grad.tolist(), "grad_oracle": o_grad.tolist(), "rel_err_grad": e_g, "tol_grad": 1e-4,
+                      "ok": bool(e_t <= 4e-5 and e_l <= 1e-5 and e_g <= 1e-4)}
+        except Exception as e:
+            parity = {"checked": False, "error": repr(e)}
+    return {"cpu_baseline": cpu, "parity": parity,
             "workload": f"cfg3: PropNetEstimator 2 -> 64 -> 64 -> 16, R={R}, uniform, fwd + proposal-loss bwd, {field} proposal / fine "
                         f"density callbacks",
             "ms_per_step": dt * 1e3, "rays_per_s": R / dt, "loss": float(loss),
@@ -1081,6 +1145,10 @@ def main():
             if not ok:
                 rc = 3
             del oracle_out
+        if _group_live():
+            g = w["params"].grad.detach().float().cpu().tolist()
+            out["distributed"] = dict(_DIST_INFO, backend=torch.distributed.get_backend(), world_size=torch.distributed.get_world_size(),
+                                      grad_after_allreduce=g, grad_finite=bool(all(math.isfinite(x) for x in g)))
         if not args.no_extras and world == 1:
             w.pop("last", None)
             for key, fn in (("cfg2_compacting", lambda: extra_cfg2_variant(dev, args, sigma_scale=16.0)),

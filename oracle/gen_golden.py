@@ -276,6 +276,29 @@ def pdf_fixtures():
     assert (ir == ir_t.numpy()).all()  # tests/test_pdf.py:57-62
     out.update(loss_q_vals=q_vals, loss_q_cdfs=q_cdfs, loss_k_vals=k_vals, loss_k_cdfs=k_cdfs, loss_ref=loss2, loss_inside=inside,
                loss_ids_left=il, loss_ids_right=ir)
+    # The proposal loss as a function with a backward (oracle.pdf_loss_batched / _backward, oracle.density_cdf_backward:
+    # the CPU baseline of BASELINE cfg 3 runs them): torch autograd of the reference's own expressions
+    # (prop_net.py:254-255 on the oracle's searchsorted ids; volrend.py:245-264 + prop_net.py:113 for the level step).
+    kc = T(k_cdfs.copy()).requires_grad_(True)
+    w_t = T(q_cdfs)[:, 1:] - T(q_cdfs)[:, :-1]
+    loss_t = torch.clip(w_t - (kc.gather(-1, T(ir[:, 1:])) - kc.gather(-1, T(il[:, :-1]))), min=0) ** 2 / (w_t + 1e-7)
+    gl = rng.random(loss.shape).astype(np.float32)
+    loss_t.backward(T(gl))
+    l_o, saved = O.pdf_loss_batched(q_vals, q_cdfs, k_vals, k_cdfs)
+    close(l_o, loss_t.detach().numpy(), atol=1e-7, rtol=1e-6, what="pdf_loss_batched")
+    g_o = O.pdf_loss_batched_backward(gl, saved)
+    close(g_o, kc.grad.numpy(), atol=1e-6, rtol=1e-5, what="pdf_loss_batched_backward")
+    ts_l = np.sort(rng.random((6, 13)).astype(np.float32) * 4 + 2, -1)
+    t0, t1 = ts_l[:, :-1].copy(), ts_l[:, 1:].copy()
+    sg = T((rng.random((6, 12)) * 3).astype(np.float32)).requires_grad_(True)
+    tr = rvol.render_transmittance_from_density(T(t0), T(t1), sg)[0]
+    cd = 1.0 - torch.cat([tr, torch.zeros_like(tr[:, :1])], -1)
+    gc = rng.standard_normal((6, 13)).astype(np.float32)
+    cd.backward(T(gc))
+    g_s = O.density_cdf_backward(t0, t1, sg.detach().numpy(), gc)
+    close(g_s, sg.grad.numpy(), atol=1e-6, rtol=1e-5, what="density_cdf_backward")
+    out.update(lossb_gl=gl, lossb_loss=loss_t.detach().numpy(), lossb_gk=kc.grad.numpy(), cdfb_t0=t0, cdfb_t1=t1,
+               cdfb_sig=sg.detach().numpy(), cdfb_gc=gc, cdfb_gsig=sg.grad.numpy())
     # _transform_stot (prop_net.py:215-229)
     s = rng.random((7, 9)).astype(np.float32)
     out.update(stot_s=s, stot_uniform=rprop._transform_stot("uniform", T(s), 2.0, 6.0).numpy(),

@@ -573,7 +573,7 @@ def batched_transmittance_from_density(t_starts, t_ends, sigmas):
 
 
 def propnet_sampling(prop_sigma_fns, prop_samples, num_samples, n_rays, near_plane, far_plane,
-                     sampling_type="lindisp", stratified=False, seed=0, offset=0):
+                     sampling_type="lindisp", stratified=False, seed=0, offset=0, return_final_vals=False):
     """nerfacc/estimators/prop_net.py:38-129 (PropNetEstimator.sampling) on the oracle's importance_sampling:
     the level loop  resample -> s->t -> proposal density -> transmittance -> cdfs = 1 - cat([T, 0]),  then the final
     resampling.  Returns (t_starts, t_ends, levels) with levels = [(interval edges in s, cdfs)] per proposal network
@@ -595,7 +595,62 @@ def propnet_sampling(prop_sigma_fns, prop_samples, num_samples, n_rays, near_pla
         levels.append((vals, cdfs))
     vals, _ = importance_sampling(vals, cdfs, num_samples, stratified, seed=seed, offset=offset)
     t_vals = transform_stot(sampling_type, vals, near_plane, far_plane)
+    if return_final_vals:
+        return t_vals[..., :-1], t_vals[..., 1:], levels, vals
     return t_vals[..., :-1], t_vals[..., 1:], levels
+
+
+def pdf_loss_batched(q_vals, q_cdfs, k_vals, k_cdfs, eps=1e-7):
+    """nerfacc/estimators/prop_net.py:232-256, the batched branch: per query interval  clip(w - w_outer, 0)^2 / (w + eps)  with
+    w = the query's cdf difference and w_outer = the key's cdf difference between the enclosing key edges (searchsorted).
+    Returns (loss (R, Q-1), saved) -- `saved` is what the backward needs."""
+    q_cdfs, k_cdfs = _f32(q_cdfs), _f32(k_cdfs)
+    il, ir = searchsorted(k_vals, q_vals)
+    w = (q_cdfs[..., 1:] - q_cdfs[..., :-1]).astype(np.float32)
+    il, ir = il[..., :-1], ir[..., 1:]
+    w_outer = (np.take_along_axis(k_cdfs, ir, -1) - np.take_along_axis(k_cdfs, il, -1)).astype(np.float32)
+    d = np.maximum(w - w_outer, np.float32(0.0)).astype(np.float32)
+    loss = (d * d / (w + np.float32(eps))).astype(np.float32)
+    return loss, (il, ir, w, d, k_cdfs.shape, np.float32(eps))
+
+
+def pdf_loss_batched_backward(g_loss, saved):
+    """d loss / d k_cdfs (the query side is detached, prop_net.py:147-148): -2 d / (w + eps) flows into the right key edge,
+    +2 d / (w + eps) into the left one (torch's gather backward = scatter-add)."""
+    il, ir, w, d, k_shape, eps = saved
+    gwo = (-np.float32(2.0) * d / (w + eps) * _f32(g_loss)).astype(np.float32)
+    g = np.zeros(k_shape, np.float32)
+    rows = np.broadcast_to(np.arange(k_shape[0])[:, None], il.shape)
+    np.add.at(g, (rows, ir), gwo)
+    np.add.at(g, (rows, il), -gwo)
+    return g
+
+
+def density_cdf_backward(t_starts, t_ends, sigmas, g_cdfs):
+    """Backward of PropNetEstimator.sampling's level step  cdfs = 1 - cat([T, 0]),  T = exp(-exclusive_sum(sigma * dt))
+    (prop_net.py:104-113, volrend.py:245-264, scan.py:233-242): g_T = -g_cdfs[:, :-1];  d T_k / d x_j = -T_k for j < k, so
+    g_x_j = -sum_{k > j} g_T_k T_k  (a reverse exclusive sum);  g_sigma = g_x * dt."""
+    dt = (_f32(t_ends) - _f32(t_starts)).astype(np.float32)
+    T = batched_transmittance_from_density(t_starts, t_ends, sigmas)
+    gT = (-_f32(g_cdfs)[..., :-1]).astype(np.float32)
+    a = (gT * T).astype(np.float32)
+    rev_incl = np.cumsum(a[..., ::-1], axis=-1, dtype=np.float32)[..., ::-1]
+    g_x = (-(rev_incl - a)).astype(np.float32)
+    return (g_x * dt).astype(np.float32)
+
+
+def propnet_loss(levels, final_vals, final_trans, loss_scaler=1.0):
+    """nerfacc/estimators/prop_net.py:131-154 (compute_loss): sum over the proposal levels of the MEAN of _pdf_loss(final
+    intervals, cdfs of the final transmittance (detached), level intervals, level cdfs).  Returns (loss, [d loss / d level cdfs])."""
+    final_trans = _f32(final_trans)
+    q_cdfs = (np.float32(1.0) - np.concatenate([final_trans, np.zeros_like(final_trans[:, :1])], -1)).astype(np.float32)
+    total = np.float64(0.0)
+    grads = []
+    for k_vals, k_cdfs in levels:
+        l, saved = pdf_loss_batched(final_vals, q_cdfs, k_vals, k_cdfs)
+        total += np.float64(l.astype(np.float64).mean())
+        grads.append(pdf_loss_batched_backward(np.full(l.shape, np.float32(loss_scaler / l.size), np.float32), saved))
+    return float(total * loss_scaler), grads
 
 
 # --------------------------------------------------------------------------- occupancy-grid maintenance

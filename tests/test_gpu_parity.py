@@ -2001,3 +2001,36 @@ def test_results_do_not_depend_on_the_tiling():
         assert r.returncode == 0 and "digest " in r.stdout, (tile, r.returncode, r.stdout[-300:], r.stderr[-300:])
         digests.append(r.stdout.strip().splitlines()[-1])
     assert digests[0] == digests[1] == digests[2], digests
+
+
+def test_bench_under_torchrun_exercises_rccl(dev):
+    """BASELINE cfg 4's code path in front of the driver: a fresh child process under `torch.distributed.run
+    --nproc-per-node 1` (the launcher starts before anything in the child touches the GPU) runs bench.py on the shared
+    256^3 grid -- RCCL init with device_id, the bit-packed grid broadcast from rank 0, the SUM all-reduce of the parameter
+    gradient in every step, barrier and MAX-over-ranks timing -- and prints the one JSON line."""
+    import hashlib
+    import json
+    import socket
+    import subprocess
+    import sys
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--res", "256", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extras", "--no-pipelined", "--no-kernel-timing"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "rays/s" and d["value"] > 1e6 and d["scaling"] == "weak"
+    dist = d["distributed"]
+    assert dist["backend"] == "nccl" and dist["world_size"] == 1
+    want = hashlib.sha256(np.packbits(bench.make_grid(256, "shell10").reshape(-1)).tobytes()).hexdigest()
+    assert dist["shared_grid_sha256"] == want and dist["shared_grid_bytes"] == 256 ** 3 // 8
+    assert dist["grad_finite"] and len(dist["grad_after_allreduce"]) == 2 and dist["grad_allreduces"] >= 4
+    assert any(abs(x) > 0 for x in dist["grad_after_allreduce"])

@@ -209,3 +209,14 @@ def test_threaded_bench_step_agrees_with_the_pinned_composition(oracle):
             assert abs(ri.size - kept[0].size) <= int(guard.sum())
         if scale == 16.0:
             assert kept[0].size < M          # early termination bites
+
+
+def test_proposal_loss_backward_vs_reference_autograd(oracle):
+    """oracle.pdf_loss_batched / pdf_loss_batched_backward / density_cdf_backward (the backward half of BASELINE cfg 3's CPU
+    baseline) against torch autograd of the reference's expressions (prop_net.py:254-255, :113; volrend.py:245-264),
+    recorded by oracle/gen_golden.py."""
+    g = load_golden("pdf")
+    l, saved = oracle.pdf_loss_batched(g["loss_q_vals"], g["loss_q_cdfs"], g["loss_k_vals"], g["loss_k_cdfs"])
+    assert_close(l, g["lossb_loss"], atol=1e-7, rtol=1e-6)
+    assert_close(oracle.pdf_loss_batched_backward(g["lossb_gl"], saved), g["lossb_gk"], atol=1e-6, rtol=1e-5)
+    assert_close(oracle.density_cdf_backward(g["cdfb_t0"], g["cdfb_t1"], g["cdfb_sig"], g["cdfb_gc"]), g["cdfb_gsig"], atol=1e-6, rtol=1e-5)
