@@ -224,9 +224,19 @@ int nfa_traverse_cone_runs(const nfa_traverse_args *args, int32_t *run_cnts, uin
  * nfa_traverse_runs): the same outputs, bit for bit, with the constant-step walk's DDA (packed step counters, interleaved
  * bit index, one 4-byte load per cell) -- about half the instructions per cell.  args->bricks is not read.
  * (csrc/walk.hip: cone_walk_kernel, cone_refill_kernel; ref grid.cu:68-282.) */
+/* arena (optional; NULL / 0: none): where the records go that do not fit a ray's max_runs slots, instead of sending the ray
+ * to the serial fill pass (ref grid.cu:405-471: a second full walk).  arena_capacity entries of 16 bytes {t_first:f32,
+ * k_start:31 | continues:1, ray:u32, samples:u32}, a multiple of 16, handed in ZEROED.  Such a ray keeps max_runs - 1 records
+ * and a sentinel {NaN, samples so far} in its last slot (nfa_expand_cone_runs skips the rest of its range; run_cnts = max_runs).
+ * overflow_count is int32[2]: [0] rays for the fill pass (without an arena: every ray with more records than slots; with one:
+ * only rays that found it full), [1] arena entries handed out (16 at a time; entries with samples == 0 are unused) --
+ * nfa_expand_cone_arena(arena, min(overflow_count[1], arena_capacity), ...) writes their samples. */
 int nfa_traverse_cone_walk(const nfa_traverse_args *args, const uint32_t *bits, int32_t *run_cnts, uint64_t *runs,
-                           int32_t max_runs, int32_t *overflow_count, const int32_t *ray_order, int64_t n_order,
-                           nfa_stream_t stream);
+                           int32_t max_runs, int32_t *overflow_count, uint32_t *arena, int32_t arena_capacity,
+                           const int32_t *ray_order, int64_t n_order, nfa_stream_t stream);
+int nfa_expand_cone_arena(const uint32_t *arena, int32_t n_entries, float step_size, float cone_angle,
+                          const int64_t *packed_info /*[n_rays,2]*/, float *t_starts, float *t_ends, int64_t *ray_indices,
+                          nfa_stream_t stream);
 int nfa_expand_cone_runs(int64_t n_rays, float step_size, float cone_angle, const int32_t *run_cnts,
                          const uint64_t *runs, int32_t max_runs, const int64_t *packed_info, float *t_starts,
                          float *t_ends, int64_t *ray_indices, nfa_stream_t stream);

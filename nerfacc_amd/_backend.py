@@ -69,7 +69,8 @@ _SIGS = {
     "nfa_fill_ray_indices": [_i64, _vp, _vp, _vp],
     "nfa_traverse_cone_runs": [C.POINTER(TraverseArgs), _vp, _vp, _i32, _vp, _vp, _i64, _vp],
     "nfa_alive_rays": [_vp, _vp, _i64, _f32, _i64, _vp, _vp, _vp, _vp],
-    "nfa_traverse_cone_walk": [C.POINTER(TraverseArgs), _vp, _vp, _vp, _i32, _vp, _vp, _i64, _vp],
+    "nfa_traverse_cone_walk": [C.POINTER(TraverseArgs), _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _vp],
+    "nfa_expand_cone_arena": [_vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     "nfa_bin_rays_levels": [_vp, _vp, _i64, _vp, _i32, C.POINTER(_i32), _f32, _vp, _vp, _vp, _vp],
     "nfa_expand_cone_runs": [_i64, _f32, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "nfa_expand_intervals": [_i64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],

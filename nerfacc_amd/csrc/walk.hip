@@ -928,6 +928,14 @@ struct ConeParams {
     const int32_t *order;        // lane -> ray assignment or NULL
     int64_t n_order;
     int32_t chunk, min_busy;     // cone_refill_kernel: entries of the ray list per wave; lanes that keep the cell loop going
+    // Records that do not fit the ray's max_runs slots go to an ARENA instead of sending the ray to the serial fill pass (a
+    // second full walk: 1.2 ms per step on cfg 5 for 0.1 % of the rays): the ray keeps max_runs - 1 records, its last slot
+    // holds a sentinel {NaN, samples so far} that makes the expansion skip the rest of its range, and the others are
+    // appended to arena[] as {t_first, k_start | continues << 31, ray, samples}, CONE_ARENA_BLOCK at a time (one atomic per
+    // block); nfa_expand_cone_arena writes their samples.  NULL: no arena (rays with too many records overflow as before).
+    uint4 *arena;                // [arena_cap], zeroed by the caller (samples == 0: unused entry)
+    int32_t arena_cap;
+    int32_t *arena_count;        // [1] entries handed out (whole blocks), zeroed by the call
 #ifdef NFA_CONE_PROFILE
     unsigned long long *profile; // [8] debugging aid: cycles outside / inside the cell loop, trips, lane-trips, rounds
 #endif
@@ -938,6 +946,9 @@ struct ConeParams {
 #ifndef NFA_CONE_REFILL_SPLIT
 #define NFA_CONE_REFILL_SPLIT 1
 #endif
+constexpr uint32_t CONE_ARENA_BLOCK = 16u;          // arena entries a ray takes per atomic (a power of two)
+constexpr uint32_t CONE_ARENA_NONE = 0xFFFFFFFFu;    // the lane's arena state: the arena was full when this ray asked
+constexpr uint32_t CONE_ARENA_FRESH = 0xFFFFFFFEu;   //                         no entry yet
 constexpr int CONE_WALK_RUN_CAP = 64;   // = grid.hip's CONE_RUN_CAP: the expansion iterates the recurrence at most this often
 struct ConeRay {
     float t_last;
@@ -958,7 +969,7 @@ __device__ __forceinline__ void cone_span_begin(const nfa_traverse_args &a, cons
 // One cell (grid.cu:184-272); true when the span is over (the step left its last cell, or the sample budget is spent).
 template <bool SPLIT>
 __device__ __forceinline__ bool cone_cell(const nfa_traverse_args &a, const ConeParams &p, int64_t tid, float this_tmax, WalkSpan &sp,
-                                          unsigned long long &w_cur, uint32_t &i_cur, ConeRay &st)
+                                          unsigned long long &w_cur, uint32_t &i_cur, ConeRay &st, uint32_t *arena_slot /* LDS, this lane's */)
 {
     const float step_size = a.step_size, cone = a.cone_angle;
     const int32_t limit = a.traverse_steps_limit;
@@ -980,10 +991,28 @@ __device__ __forceinline__ bool cone_cell(const nfa_traverse_args &a, const Cone
     auto emit = [&](float t_next) {
         const bool cut = !st.continuous || st.run_len == CONE_WALK_RUN_CAP;
         if (cut) {
-            if (st.n_runs < p.max_runs)
-                p.runs[(int64_t)st.n_runs * a.n_rays + tid] =
-                    (unsigned long long)f32_bits(st.t_last) |
-                    ((unsigned long long)((uint32_t)st.n_samples | (st.continuous ? 0x80000000u : 0u)) << 32);
+            const uint32_t kc = (uint32_t)st.n_samples | (st.continuous ? 0x80000000u : 0u);
+            const int32_t inl = p.arena ? p.max_runs - 1 : p.max_runs;   // records the ray keeps in its own slots
+            if (st.n_runs < inl) {
+                p.runs[(int64_t)st.n_runs * a.n_rays + tid] = (unsigned long long)f32_bits(st.t_last) | ((unsigned long long)kc << 32);
+            } else if (p.arena) {
+                uint32_t e = *arena_slot;                                // the ray's previous arena entry (CONE_ARENA_NONE: gave up)
+                if (st.n_runs == inl) {
+                    p.runs[(int64_t)inl * a.n_rays + tid] = 0x7FC00000ull | ((unsigned long long)(uint32_t)st.n_samples << 32);
+                    e = CONE_ARENA_FRESH;
+                } else if (e < CONE_ARENA_NONE) {
+                    reinterpret_cast<uint32_t *>(p.arena + e)[3] = (uint32_t)st.run_len;   // the previous entry is complete: its samples
+                }
+                if (e != CONE_ARENA_NONE) {
+                    e = (e == CONE_ARENA_FRESH || ((e + 1u) & (CONE_ARENA_BLOCK - 1u)) == 0u) ? (uint32_t)atomicAdd(p.arena_count, (int32_t)CONE_ARENA_BLOCK)
+                                                                                             : e + 1u;
+                    if (e + CONE_ARENA_BLOCK <= (uint32_t)p.arena_cap || (e & (CONE_ARENA_BLOCK - 1u)) != 0u)
+                        p.arena[e] = make_uint4(f32_bits(st.t_last), kc, (uint32_t)tid, 0u);
+                    else
+                        e = CONE_ARENA_NONE;                             // the arena is full: this ray goes to the serial fill pass
+                }
+                *arena_slot = e;
+            }
             st.n_runs++;
         }
         st.run_len = cut ? 1 : st.run_len + 1;
@@ -1157,12 +1186,18 @@ __device__ __forceinline__ bool cone_next_span_staged(const nfa_traverse_args &a
     return false;
 }
 
-__device__ __forceinline__ void cone_ray_out(const nfa_traverse_args &a, const ConeParams &p, int64_t tid, const ConeRay &st)
+__device__ __forceinline__ void cone_ray_out(const nfa_traverse_args &a, const ConeParams &p, int64_t tid, const ConeRay &st,
+                                             const uint32_t *arena_slot)
 {
     if (a.terminate_planes) a.terminate_planes[tid] = st.t_last;
     a.sm_cnts[tid] = st.n_samples;
     // rays with > 2^21 samples go to the serial fill (the expansion packs a 27-bit batch offset)
     int32_t n_runs = st.n_runs;
+    if (p.arena && n_runs >= p.max_runs) {   // the ray's last records are in the arena: its slots hold max_runs - 1 of them + the sentinel
+        const uint32_t e = *arena_slot;
+        if (e < CONE_ARENA_FRESH) { reinterpret_cast<uint32_t *>(p.arena + e)[3] = (uint32_t)st.run_len; n_runs = p.max_runs; }
+        else n_runs = p.max_runs + 1;
+    }
     if (st.n_samples > (1 << 21) && n_runs <= p.max_runs) n_runs = p.max_runs + 1;
     p.run_cnts[tid] = n_runs;
     if (n_runs > p.max_runs) atomicAdd(p.overflow, 1);
@@ -1186,6 +1221,8 @@ template <bool FUSED>
 __attribute__((amdgpu_waves_per_eu(NFA_CONE_WALK_WAVES, NFA_CONE_WALK_WAVES)))
 __global__ __launch_bounds__(256) void cone_walk_kernel(const nfa_traverse_args a, const ConeParams p)
 {
+    __shared__ uint32_t s_arena[256];                 // per lane: the ray's current arena entry (cone_cell: emit)
+    uint32_t *const arena_slot = s_arena + threadIdx.x;
     const int64_t n_walk = p.order ? p.n_order : a.n_rays;
     const int32_t limit = a.traverse_steps_limit;
     for (int64_t slot_i = xcd_fair_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; slot_i < n_walk;
@@ -1205,12 +1242,12 @@ __global__ __launch_bounds__(256) void cone_walk_kernel(const nfa_traverse_args 
         unsigned long long w_cur = 0ull;
         uint32_t i_cur = 0u;
         while (cone_next_span<FUSED>(a, p, tid, o, d, near_plane, far_plane, ev, st, sp, span_tmax, w_cur, i_cur)) {
-            while (!cone_cell<NFA_CONE_WALK_SPLIT != 0>(a, p, tid, span_tmax, sp, w_cur, i_cur, st)) {}
+            while (!cone_cell<NFA_CONE_WALK_SPLIT != 0>(a, p, tid, span_tmax, sp, w_cur, i_cur, st, arena_slot)) {}
             // The budget is spent: the last thing that happened was a sample (continuous), so the spans still to come would
             // change nothing (grid.cu:151,185: no fast-forward, no cell visited).
             if (limit > 0 && st.n_samples >= limit) break;
         }
-        cone_ray_out(a, p, tid, st);
+        cone_ray_out(a, p, tid, st, arena_slot);
     }
 }
 
@@ -1229,6 +1266,8 @@ __global__ __launch_bounds__(256) void cone_refill_kernel(const nfa_traverse_arg
 {
     static_assert(!(FUSED && STAGED), "a fused walk has no event list");
     __shared__ float ts_lds[STAGED ? CONE_EV_MAX * 256 : 1];
+    __shared__ uint32_t s_arena[256];                 // per lane: the ray's current arena entry (cone_cell: emit)
+    uint32_t *const arena_slot = s_arena + threadIdx.x;
     float *const ts_col = ts_lds + (STAGED ? threadIdx.x : 0);
     uint32_t ti_pack = 0u, hit_mask = 0u;
     enum { IDLE = 0, SPAN = 1, WALK = 2, FINISH = 3 };
@@ -1266,7 +1305,7 @@ __global__ __launch_bounds__(256) void cone_refill_kernel(const nfa_traverse_arg
                 phase = found ? WALK : FINISH;
             }
             if (phase == FINISH) {
-                cone_ray_out(a, p, tid, st);
+                cone_ray_out(a, p, tid, st, arena_slot);
                 phase = IDLE;
             }
             if (pass == 1) break;
@@ -1307,7 +1346,7 @@ __global__ __launch_bounds__(256) void cone_refill_kernel(const nfa_traverse_arg
             pf_trips++; pf_lanes += __popcll(__ballot(phase == WALK));
 #endif
             if (phase == WALK) {
-                if (cone_cell<NFA_CONE_REFILL_SPLIT != 0>(a, p, tid, span_tmax, sp, w_cur, i_cur, st))
+                if (cone_cell<NFA_CONE_REFILL_SPLIT != 0>(a, p, tid, span_tmax, sp, w_cur, i_cur, st, arena_slot))
                     phase = (limit > 0 && st.n_samples >= limit) ? FINISH : SPAN;  // budget spent: nothing after it changes the ray
             }
         } while (__popcll(__ballot(phase == WALK)) >= need);
@@ -1419,15 +1458,51 @@ int nfa_traverse_runs(const nfa_traverse_args *pa, const uint32_t *bits, int32_t
     return NFA_OK;
 }
 
+// nfa_expand_cone_arena: the samples of the arena's entries (ConeParams::arena): one wave per entry, lane i re-runs i steps of
+// the recurrence t <- t + max(step, t * cone) from the entry's first distance (grid.cu:213-216, as expand_runs_kernel<EXP_CONE>
+// does for the records a ray keeps in its own slots) and writes sample k_start + i of the entry's ray
+__global__ __launch_bounds__(256) void expand_cone_arena_kernel(const uint4 *__restrict__ arena, int32_t n_entries, float step, float cone,
+                                                                const longlong2 *__restrict__ packed_info, float *__restrict__ t_starts,
+                                                                float *__restrict__ t_ends, int64_t *__restrict__ ray_indices)
+{
+    const int32_t e = (int32_t)(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (e >= n_entries) return;
+    const uint4 rec = arena[e];
+    const uint32_t i = threadIdx.x & 63u;
+    if (i >= rec.w) return;                                   // (rec.w == 0: an unused entry of a ray's block)
+    float t = bits_f32(rec.x);
+    for (uint32_t k = 0; k < i; ++k) t = t + calc_dt(t, cone, step);
+    const int64_t at = packed_info[rec.z].x + (int64_t)(rec.y & 0x7FFFFFFFu) + i;
+    t_starts[at] = t;
+    t_ends[at] = t + calc_dt(t, cone, step);
+    ray_indices[at] = (int64_t)rec.z;
+}
+
+int nfa_expand_cone_arena(const uint32_t *arena, int32_t n_entries, float step_size, float cone_angle, const int64_t *packed_info,
+                          float *t_starts, float *t_ends, int64_t *ray_indices, nfa_stream_t stream)
+{
+    NFA_REQUIRE(n_entries >= 0, "expand_cone_arena: negative n_entries");
+    if (n_entries == 0) return NFA_OK;
+    NFA_REQUIRE(arena && packed_info && t_starts && t_ends && ray_indices, "expand_cone_arena: null pointer");
+    NFA_REQUIRE(step_size > 0.0f && cone_angle > 0.0f, "expand_cone_arena: step_size and cone_angle must be > 0");
+    hipLaunchKernelGGL(expand_cone_arena_kernel, dim3((unsigned)((n_entries + 3) / 4)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const uint4 *>(arena), n_entries, step_size, cone_angle, reinterpret_cast<const longlong2 *>(packed_info),
+                       t_starts, t_ends, ray_indices);
+    NFA_CHECK_LAUNCH("expand_cone_arena");
+    return NFA_OK;
+}
+
 int nfa_traverse_cone_walk(const nfa_traverse_args *pa, const uint32_t *bits, int32_t *run_cnts, uint64_t *runs, int32_t max_runs,
-                           int32_t *overflow_count, const int32_t *ray_order, int64_t n_order, nfa_stream_t stream)
+                           int32_t *overflow_count, uint32_t *arena, int32_t arena_capacity, const int32_t *ray_order, int64_t n_order,
+                           nfa_stream_t stream)
 {
     NFA_REQUIRE(pa != nullptr, "traverse_cone_walk: null args");
     const nfa_traverse_args &a = *pa;
     NFA_REQUIRE(a.n_rays >= 0 && a.n_rays < (int64_t)1 << 31, "traverse_cone_walk: n_rays out of range");
     NFA_REQUIRE(overflow_count, "traverse_cone_walk: overflow_count is null");
     hipStream_t s = as_stream(stream);
-    if (hipMemsetAsync(overflow_count, 0, sizeof(int32_t), s) != hipSuccess) { set_error("traverse_cone_walk: memset failed"); return NFA_EHIP; }
+    if (hipMemsetAsync(overflow_count, 0, 2 * sizeof(int32_t), s) != hipSuccess) { set_error("traverse_cone_walk: memset failed"); return NFA_EHIP; }
+    NFA_REQUIRE(arena_capacity >= 0 && (arena == nullptr || arena_capacity % (int32_t)CONE_ARENA_BLOCK == 0), "traverse_cone_walk: arena_capacity must be a multiple of 16");
     if (a.n_rays == 0) return NFA_OK;
     NFA_REQUIRE(a.step_size > 0.0f && a.cone_angle > 0.0f, "traverse_cone_walk: needs step_size > 0 and cone_angle > 0");
     NFA_REQUIRE(a.mode == 0 || a.mode == 2, "traverse_cone_walk: mode must be 0 (all rays) or 2 (rays_mask + traverse_steps_limit)");
@@ -1450,6 +1525,9 @@ int nfa_traverse_cone_walk(const nfa_traverse_args *pa, const uint32_t *bits, in
     p.runs = reinterpret_cast<unsigned long long *>(runs);
     p.max_runs = max_runs;
     p.overflow = overflow_count;
+    p.arena = (arena && arena_capacity > 0 && max_runs >= 2) ? reinterpret_cast<uint4 *>(arena) : nullptr;
+    p.arena_cap = arena_capacity;
+    p.arena_count = overflow_count + 1;
     p.order = ray_order;
     p.n_order = ray_order ? n_order : a.n_rays;
     NFA_REQUIRE(!ray_order || (n_order >= 0 && n_order <= a.n_rays), "traverse_cone_walk: n_order out of range");

@@ -201,7 +201,7 @@ def traverse_grids(
                 iv_packed = _cumsum_packed(iv_cnts, meta[0:1])
                 sm_packed = _cumsum_packed(sm_cnts, meta[1:2])
                 n_iv, n_sm, n_overflow = (int(v) for v in meta.tolist())  # the one device->host read
-                n_overflow, off_lattice = n_overflow & 0xFFFFFFFF, n_overflow >> 32
+                n_overflow, off_lattice = n_overflow & 0xFFFFFFFF, n_overflow >> 32   # (nfa_traverse_runs: [1] = off the lattice)
                 if not off_lattice or near_hint is None:
                     break
                 near_hint = None   # rays that are not on the lattice of near_hint (csrc/walk.hip): the per-ray marcher
@@ -344,6 +344,8 @@ def _pinned_meta(dev) -> Tensor:
 CONE_RUNS = os.environ.get("NERFACC_AMD_CONE_RUNS", "1") != "0"   # 0: the serial count + fill passes (A/B testing)
 ALIVE_LIST_FRACTION = float(os.environ.get("NERFACC_AMD_ALIVE_FRACTION", "0.75"))   # test-mode loop: below this share of alive rays only they are walked
 CONE_WALK = os.environ.get("NERFACC_AMD_CONE_WALK", "1") != "0"   # 0: the count pass over the brick-packed grid (grid.hip) instead of walk.hip's DDA (A/B testing)
+CONE_ARENA = os.environ.get("NERFACC_AMD_CONE_ARENA", "1") != "0"   # 0: rays with more than MAX_RUNS records go to the serial fill pass (A/B testing)
+CONE_ARENA_MIN = 4096   # smallest arena (entries; a multiple of 16)
 CONE_BIN_THRESHOLD = 1.25   # cone-angle walk: bin the rays when a wave of 64 neighbours crosses this many times its mean ray's cells
 
 
@@ -426,6 +428,7 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
                    0 if order is None else order.numel(), B.stream())
         elif use_cone_runs:
             _get_bricks(binaries)
+            arena, arena_cap = None, 0
             run_cnts = (torch.zeros if alive is not None else torch.empty)(n_rays, dtype=torch.int32, device=dev)
             runs = torch.empty((MAX_RUNS, n_rays), dtype=torch.int64, device=dev)
             order = alive
@@ -445,8 +448,11 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
                     order = None
             if CONE_WALK and _walk_supported(binaries) and min(binaries.shape[1:]) >= 4:
                 # the constant-step walk's DDA over the 1-bit grid copy (csrc/walk.hip: cone_walk_kernel / cone_refill_kernel)
+                # records beyond a ray's MAX_RUNS slots go to an arena (16 bytes each) instead of a second walk of the ray
+                arena_cap = CONE_ARENA and max(CONE_ARENA_MIN, (n_rays // 8 + 15) // 16 * 16)
+                arena = torch.zeros(2 * arena_cap, dtype=torch.int64, device=dev) if arena_cap else None
                 B.call("nfa_traverse_cone_walk", C.byref(a), B.ptr(_get_walk_bits(binaries)), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS,
-                       B.ptr(meta[3:4]), B.ptr(order), 0 if order is None else order.numel(), B.stream())
+                       B.ptr(meta[3:4]), B.ptr(arena), arena_cap, B.ptr(order), 0 if order is None else order.numel(), B.stream())
             else:
                 B.call("nfa_traverse_cone_runs", C.byref(a), B.ptr(run_cnts), B.ptr(runs), MAX_RUNS, B.ptr(meta[3:4]), B.ptr(order),
                        0 if order is None else order.numel(), B.stream())
@@ -478,7 +484,10 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
             n_sm, s_max, s_sum, n_overflow, c_max, c_sum = (int(v) for v in host[:6].tolist())
         else:
             n_sm, s_max, s_sum, n_overflow, c_max, c_sum = (int(v) for v in meta.tolist())  # the one device->host read of the traversal
-        n_overflow, off_lattice = n_overflow & 0xFFFFFFFF, n_overflow >> 32
+        n_overflow, off_lattice = n_overflow & 0xFFFFFFFF, n_overflow >> 32   # (nfa_traverse_runs: [1] = off the lattice)
+        n_arena = 0
+        if use_cone_runs and arena is not None:
+            n_arena, off_lattice = min(off_lattice, arena_cap), 0                 # (nfa_traverse_cone_walk: [1] = arena entries)
         if off_lattice and use_runs and near_hint is not None:
             # rays that are not on the lattice of near_hint (a near plane that differs from it, a march beyond the tabulated
             # sequence: csrc/walk.hip): the same traversal with the per-ray marcher
@@ -526,6 +535,9 @@ def _traverse_samples(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, 
             elif use_cone_runs:
                 B.call("nfa_expand_cone_runs", n_rays, float(step_size), float(cone_angle), B.ptr(run_cnts), B.ptr(runs),
                        MAX_RUNS, B.ptr(packed_info), B.ptr(t_starts), B.ptr(t_ends), B.ptr(ray_indices), B.stream())
+                if n_arena > 0:
+                    B.call("nfa_expand_cone_arena", B.ptr(arena), n_arena, float(step_size), float(cone_angle), B.ptr(packed_info),
+                           B.ptr(t_starts), B.ptr(t_ends), B.ptr(ray_indices), B.stream())
             if joined is not None:
                 main.wait_event(joined)
             if not (use_runs or use_cone_runs):

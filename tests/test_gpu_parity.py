@@ -2034,3 +2034,56 @@ def test_bench_under_torchrun_exercises_rccl(dev):
     assert dist["shared_grid_sha256"] == want and dist["shared_grid_bytes"] == 256 ** 3 // 8
     assert dist["grad_finite"] and len(dist["grad_after_allreduce"]) == 2 and dist["grad_allreduces"] >= 4
     assert any(abs(x) > 0 for x in dist["grad_after_allreduce"])
+
+
+def test_cone_walk_record_arena(dev, oracle):
+    """Rays with more run records than their MAX_RUNS slots keep MAX_RUNS - 1 of them and a sentinel, the others go to the
+    arena and are expanded from there (csrc/walk.hip: ConeParams::arena, nfa_expand_cone_arena) -- no second walk.  With 4
+    slots per ray nearly every ray uses the arena; with a 16-entry arena most rays find it full and take the serial fill
+    pass after all; results: the oracle's, bit for bit, in every combination, and the form without an arena."""
+    from nerfacc_amd import grid as G
+    rng = np.random.default_rng(11)
+    saved = (G.MAX_RUNS, G.CONE_ARENA, G.CONE_ARENA_MIN)
+    try:
+        for levels, res, occ, R, step, cone, limit in ((2, 32, 0.3, 6000, 6e-3, 0.01, None), (1, 48, 0.5, 3000, 3e-3, 0.004, None),
+                                                        (3, 24, 0.2, 4000, 5e-3, 0.02, 30)):
+            est = na.OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=res, levels=levels).to(dev)
+            b = rng.random((levels, res, res, res)) < occ
+            o = (rng.random((R, 3)).astype(np.float32) - 0.5) * 1.5
+            d = rng.standard_normal((R, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+            near = np.full(R, 0.05, np.float32); far = np.full(R, 1e10, np.float32)
+            mask = (rng.random(R) < 0.7) if limit else None
+            kw = dict(rays_mask=None if mask is None else T(mask, dev), traverse_steps_limit=limit, near_hint=0.05)
+            args = (T(o, dev), T(d, dev), T(b, dev), est.aabbs, T(near, dev), T(far, dev), step, cone)
+            outs = {}
+            for name, (max_runs, arena, amin) in {"32 slots": (32, True, 4096), "4 slots + arena": (4, True, 1 << 20),
+                                                  "4 slots, arena of 16": (4, True, 16), "4 slots, no arena": (4, False, 4096),
+                                                  "2 slots + arena": (2, True, 1 << 20)}.items():
+                G.MAX_RUNS, G.CONE_ARENA, G.CONE_ARENA_MIN = max_runs, arena, amin
+                calls = []
+                orig = G.B.call
+                G.B.call = lambda n, *a, **k: (calls.append(n), orig(n, *a, **k))[1]
+                try:
+                    outs[name] = G._traverse_samples(*args, **kw)
+                finally:
+                    G.B.call = orig
+                if name == "4 slots + arena":
+                    assert "nfa_expand_cone_arena" in calls and "nfa_traverse_grids" not in calls, calls
+                if name == "4 slots, no arena":
+                    assert "nfa_expand_cone_arena" not in calls and "nfa_traverse_grids" in calls, calls
+            ref = outs["32 slots"]
+            assert ref[0].numel() > 2000
+            for name, got in outs.items():
+                assert all(torch.equal(x, y) for x, y in zip(ref, got)), (name, levels, res)
+            ab = est.aabbs.cpu().numpy()
+            if limit is None:
+                riv, rsm, _ = oracle.traverse_grids(o, d, b, ab, near_planes=near, far_planes=far, step_size=step, cone_angle=cone)
+                keep = np.ones(rsm["ray_indices"].shape[0], bool)
+            else:
+                riv, rsm, _ = oracle.traverse_grids(o, d, b, ab, near_planes=near, far_planes=far, step_size=step, cone_angle=cone,
+                                                    traverse_steps_limit=limit, over_allocate=True, rays_mask=mask)
+                keep = rsm["is_valid"]
+            assert (ref[0].cpu().numpy() == rsm["ray_indices"][keep]).all()
+            assert (ref[1].cpu().numpy() == riv["vals"][riv["is_left"]]).all() and (ref[2].cpu().numpy() == riv["vals"][riv["is_right"]]).all()
+    finally:
+        G.MAX_RUNS, G.CONE_ARENA, G.CONE_ARENA_MIN = saved
