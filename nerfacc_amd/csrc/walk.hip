@@ -624,6 +624,15 @@ __device__ __forceinline__ float dda_step_lds(const char *lds, uint32_t ax /* th
     return m;
 }
 
+// the lane's three rows of the table, from the span's DDA state
+__device__ __forceinline__ void dda_table_write(char *tab_lds, const WalkSpan &sp)
+{
+    char *row = tab_lds + 16u * threadIdx.x;
+    *reinterpret_cast<nfa_v4f *>(row) = nfa_v4f{sp.dx, 0.0f, 0.0f, bits_f32(sp.mx)};
+    *reinterpret_cast<nfa_v4f *>(row + WK_TAB_AXIS) = nfa_v4f{0.0f, sp.dy, 0.0f, bits_f32(sp.my)};
+    *reinterpret_cast<nfa_v4f *>(row + 2 * WK_TAB_AXIS) = nfa_v4f{0.0f, 0.0f, sp.dz, bits_f32(sp.mz)};
+}
+
 // One cell of the walk.  (w_cur, i_cur): the word of the grid copy that holds the occupancy bit of the cell the ray is in
 // and the bit's index -- requested when the ray entered the cell, one cell's worth of instructions ago; `open`: the kind of
 // the ray's open list entry.  Steps the DDA, looks at the current cell's bit, requests the next cell's word into the same
@@ -795,12 +804,7 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
                 *reinterpret_cast<float *>(col + ((kk + 1u) << WK_LG)) = this_tmax;
                 ev_span |= 1u << kk;
                 walk_span_setup(a, p.lay, o, d, level, this_tmin, this_tmax, sp);
-                {   // the span's per-axis constants: the lane's three rows of the table (dda_step_lds)
-                    char *row = tab_lds + 16u * threadIdx.x;
-                    *reinterpret_cast<nfa_v4f *>(row) = nfa_v4f{sp.dx, 0.0f, 0.0f, bits_f32(sp.mx)};
-                    *reinterpret_cast<nfa_v4f *>(row + WK_TAB_AXIS) = nfa_v4f{0.0f, sp.dy, 0.0f, bits_f32(sp.my)};
-                    *reinterpret_cast<nfa_v4f *>(row + 2 * WK_TAB_AXIS) = nfa_v4f{0.0f, 0.0f, sp.dz, bits_f32(sp.mz)};
-                }
+                dda_table_write(tab_lds, sp);   // the span's per-axis constants (dda_step_lds)
                 const uint32_t idx0 = sp.widx ^ sp.flip;
                 w_cur = bits[idx0 >> 5]; i_cur = idx0;
                 open_type = (int32_t)((w_cur >> (idx0 & 31u)) & 1u);
@@ -933,6 +937,7 @@ struct ConeParams {
     // holds a sentinel {NaN, samples so far} that makes the expansion skip the rest of its range, and the others are
     // appended to arena[] as {t_first, k_start | continues << 31, ray, samples}, CONE_ARENA_BLOCK at a time (one atomic per
     // block); nfa_expand_cone_arena writes their samples.  NULL: no arena (rays with too many records overflow as before).
+    char *tab_lds;               // (set by the kernels) LDS: [3][256] rows of the DDA's per-axis constants (dda_step_lds)
     uint4 *arena;                // [arena_cap], zeroed by the caller (samples == 0: unused entry)
     int32_t arena_cap;
     int32_t *arena_count;        // [1] entries handed out (whole blocks), zeroed by the call
@@ -962,6 +967,7 @@ __device__ __forceinline__ void cone_span_begin(const nfa_traverse_args &a, cons
 {
     if (!st.continuous) st.t_last = fast_forward(st.t_last, this_tmin, a.step_size, a.cone_angle);  // grid.cu:151-163
     walk_span_setup(a, p.lay, o, d, level, this_tmin, this_tmax, sp);
+    dda_table_write(p.tab_lds, sp);
     i_cur = sp.widx ^ sp.flip;
     w_cur = reinterpret_cast<const unsigned long long *>(p.bits)[i_cur >> 6];
 }
@@ -975,7 +981,8 @@ __device__ __forceinline__ bool cone_cell(const nfa_traverse_args &a, const Cone
     const int32_t limit = a.traverse_steps_limit;
     const uint32_t w_half = (i_cur & 32u) ? (uint32_t)(w_cur >> 32) : (uint32_t)w_cur;
     const bool occupied = __builtin_amdgcn_ubfe(w_half, i_cur, 1u) != 0u;   // bit (i_cur & 31) of the half
-    const float m = dda_step(sp.dx, sp.dy, sp.dz, sp.mx, sp.my, sp.mz, sp.tx, sp.ty, sp.tz, sp.rem, sp.widx);
+    const uint32_t tab_x = 16u * threadIdx.x;
+    const float m = dda_step_lds(p.tab_lds, tab_x, tab_x + 2u * WK_TAB_AXIS, sp.tx, sp.ty, sp.tz, sp.rem, sp.widx);
     const float t_traverse = vmin_f32(m, this_tmax);
     const bool done = (sp.rem & WK_GUARD) != WK_GUARD;
     // The next cell's bit: the low six index bits are two of each coordinate, so an aligned 64-bit word of the copy is a
@@ -1219,8 +1226,11 @@ __device__ __forceinline__ bool cone_ray_masked(const nfa_traverse_args &a, cons
 #endif
 template <bool FUSED>
 __attribute__((amdgpu_waves_per_eu(NFA_CONE_WALK_WAVES, NFA_CONE_WALK_WAVES)))
-__global__ __launch_bounds__(256) void cone_walk_kernel(const nfa_traverse_args a, const ConeParams p)
+__global__ __launch_bounds__(256) void cone_walk_kernel(const nfa_traverse_args a, const ConeParams p_in)
 {
+    __shared__ __attribute__((aligned(16))) char s_tab[3 * WK_TAB_AXIS];
+    ConeParams p = p_in;
+    p.tab_lds = s_tab;
     __shared__ uint32_t s_arena[256];                 // per lane: the ray's current arena entry (cone_cell: emit)
     uint32_t *const arena_slot = s_arena + threadIdx.x;
     const int64_t n_walk = p.order ? p.n_order : a.n_rays;
@@ -1262,9 +1272,13 @@ template <bool FUSED, bool STAGED /* the event list travels with the lane (n_gri
 #ifdef NFA_CONE_REFILL_WAVES
 __attribute__((amdgpu_waves_per_eu(NFA_CONE_REFILL_WAVES, NFA_CONE_REFILL_WAVES)))
 #endif
-__global__ __launch_bounds__(256) void cone_refill_kernel(const nfa_traverse_args a, const ConeParams p)
+__global__ __launch_bounds__(256) void cone_refill_kernel(const nfa_traverse_args a, const ConeParams p_in)
 {
     static_assert(!(FUSED && STAGED), "a fused walk has no event list");
+    static_assert(WK_THREADS == 256, "the cone kernels share the walk's table layout");
+    __shared__ __attribute__((aligned(16))) char s_tab[3 * WK_TAB_AXIS];
+    ConeParams p = p_in;
+    p.tab_lds = s_tab;
     __shared__ float ts_lds[STAGED ? CONE_EV_MAX * 256 : 1];
     __shared__ uint32_t s_arena[256];                 // per lane: the ray's current arena entry (cone_cell: emit)
     uint32_t *const arena_slot = s_arena + threadIdx.x;
