@@ -133,6 +133,16 @@ typedef struct nfa_traverse_args {
      * results are identical. */
     const uint64_t *bricks;
     const uint32_t *coarse;
+    /* Optional DEVICE-side controls, for loops that must not wait for the host (the test-mode loop captured into a hipGraph):
+     *   steps_limit_dev  (nfa_traverse_runs, mode 2) the step limit of this call, read from the device instead of
+     *                    traverse_steps_limit (which must still be > 0: it selects the kernel); 0 = nothing to do, the
+     *                    call leaves every output as it is;
+     *   n_listed_dev     (nfa_traverse_runs with ray_order) the number of entries of ray_order to walk (<= n_order);
+     *   run_if_nonzero   (nfa_traverse_grids) the launch does nothing when *run_if_nonzero == 0 (the fill pass for rays
+     *                    with too many run records, whose count the host has not seen). */
+    const int32_t *steps_limit_dev;
+    const int64_t *n_listed_dev;
+    const int32_t *run_if_nonzero;
 } nfa_traverse_args;
 int nfa_traverse_grids(const nfa_traverse_args *args, nfa_stream_t stream);
 
@@ -182,6 +192,25 @@ int nfa_bin_rays(const float *rays_o, const float *rays_d, int64_t n_rays, const
  * nfa_traverse_runs / nfa_traverse_cone_walk with n_order = *count), *count = their number.  One launch. */
 int nfa_alive_rays(const float *opacity, const int64_t *packed_info /*[n_rays,2]*/, int64_t n_samples, float opacity_max,
                    int64_t n_rays, uint8_t *mask, int32_t *alive, int64_t *count, nfa_stream_t stream);
+/* The test-mode loop without the host in it (ref examples/utils.py:330-414; nerfacc_amd/marching.py, padded form): the
+ * iteration schedule lives in state[8] (int32, zeroed before the first iteration):
+ *   state[0] samples per ray of the CURRENT iteration, 0 = the loop is over (no ray alive, or max_samples handed out),
+ *   state[1] samples per ray handed out so far, state[2] iterations that did something, state[4..5] (one int64) samples
+ *   that entered the accumulation so far.
+ * alive_count is int64[2]: [0] the alive rays (written by nfa_testmode_alive, n_rays before the first iteration), [1] its
+ * value at the start of the current iteration (the walk's n_listed_dev).
+ * nfa_testmode_begin   starts an iteration: state[0] = max(min(n_rays / alive_count[0], 64), min_samples) while rays are alive
+ *                      and state[1] < max_samples (then state[1] += state[0]), else 0; alive_count[1] = alive_count[0],
+ *                      alive_count[0] = 0; zeroes sm_cnts[n_rays], run_cnts[n_rays] and zero_words[n_zero] (int64: the
+ *                      caller's counters of the iteration, e.g. nfa_traverse_runs' overflow_count -- a call with
+ *                      steps_limit_dev set does not zero it itself, so that the iteration has no memset node);
+ * nfa_testmode_alive   ends it: nfa_alive_rays with n_samples = state[0] (state[0] == 0: nothing happens, count[0] stays 0)
+ *                      into count = alive_count, and state[4..5] += the iteration's samples (the last row of packed_info)
+ *                      when count_samples != 0. */
+int nfa_testmode_begin(int64_t *alive_count, int32_t *state, int64_t n_rays, int32_t min_samples, int32_t max_samples,
+                       int64_t *sm_cnts, int32_t *run_cnts, int64_t *zero_words, int32_t n_zero, nfa_stream_t stream);
+int nfa_testmode_alive(const float *opacity, const int64_t *packed_info, int32_t *state, float opacity_max, int64_t n_rays,
+                       uint8_t *mask, int32_t *alive, int64_t *count, int32_t count_samples, nfa_stream_t stream);
 /* The same for nested levels (aabbs[n_grids][6], finest first; e.g. rays that start inside the finest box): the key is the
  * number of cell boundaries the ray crosses from near_plane on, summed over the levels (the length inside level l but
  * outside level l - 1, times sum_k |d_k| res_k / extent_k).  ray_order of nfa_traverse_cone_runs / nfa_traverse_runs. */

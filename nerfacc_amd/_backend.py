@@ -38,6 +38,7 @@ class TraverseArgs(C.Structure):
         ("terminate_planes", _vp),
         ("ray_filter", _vp), ("ray_filter_min", _i32),
         ("bricks", _vp), ("coarse", _vp),
+        ("steps_limit_dev", _vp), ("n_listed_dev", _vp), ("run_if_nonzero", _vp),
     ]
 
 
@@ -69,6 +70,8 @@ _SIGS = {
     "nfa_fill_ray_indices": [_i64, _vp, _vp, _vp],
     "nfa_traverse_cone_runs": [C.POINTER(TraverseArgs), _vp, _vp, _i32, _vp, _vp, _i64, _vp],
     "nfa_alive_rays": [_vp, _vp, _i64, _f32, _i64, _vp, _vp, _vp, _vp],
+    "nfa_testmode_begin": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp],
+    "nfa_testmode_alive": [_vp, _vp, _vp, _f32, _i64, _vp, _vp, _vp, _i32, _vp],
     "nfa_traverse_cone_walk": [C.POINTER(TraverseArgs), _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _vp],
     "nfa_expand_cone_arena": [_vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     "nfa_bin_rays_levels": [_vp, _vp, _i64, _vp, _i32, C.POINTER(_i32), _f32, _vp, _vp, _vp, _vp],

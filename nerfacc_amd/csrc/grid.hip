@@ -354,8 +354,14 @@ template <int EMIT, bool HAS_IV, bool HAS_SM, bool FUSED>
 #ifdef NFA_TRAVERSE_WAVES
 __attribute__((amdgpu_waves_per_eu(NFA_TRAVERSE_WAVES, 8)))
 #endif
-__global__ __launch_bounds__(256) void traverse_kernel(const nfa_traverse_args a, const RunOut ro)
+__global__ __launch_bounds__(256) void traverse_kernel(const nfa_traverse_args a_in, const RunOut ro)
 {
+    if (a_in.run_if_nonzero && *a_in.run_if_nonzero == 0) return;   // (a fill pass launched without the host knowing whether it is needed)
+    nfa_traverse_args a = a_in;
+    if (a.steps_limit_dev) {   // the step limit of a loop that does not wait for the host (0: this iteration does nothing)
+        a.traverse_steps_limit = *a.steps_limit_dev;
+        if (a.traverse_steps_limit <= 0) return;
+    }
     const int64_t n_walk = (EMIT == EMIT_RUNS && ro.order) ? ro.n_order : a.n_rays;
     for (int64_t slot_i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; slot_i < n_walk;
          slot_i += (int64_t)blockDim.x * gridDim.x) {

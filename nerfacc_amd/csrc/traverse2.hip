@@ -624,12 +624,23 @@ __global__ __launch_bounds__(64 * EXP_WPB) void expand_intervals_kernel(int64_t 
 // ascending inside a workgroup's stretch and the stretches come in the order the workgroups finish (the walk's results do not
 // depend on the list's order).
 constexpr int ALIVE_THREADS = 1024, ALIVE_PER_THREAD = 8, ALIVE_PER_WG = ALIVE_THREADS * ALIVE_PER_THREAD;
+// state (optional): the device-side schedule of the test-mode loop (include/nerfacc_hip.h: nfa_testmode_begin); n_samples is
+// then state[0], and nothing happens when that is 0 (*count stays 0: the host zeroed it)
 __global__ __launch_bounds__(ALIVE_THREADS) void alive_rays_kernel(const float *__restrict__ opacity, const longlong2 *__restrict__ packed_info,
-                                                                  int64_t n_samples, float thre, int64_t n_rays, uint8_t *__restrict__ mask,
-                                                                  int32_t *__restrict__ alive, unsigned long long *__restrict__ count)
+                                                                  int64_t n_samples_arg, float thre, int64_t n_rays, uint8_t *__restrict__ mask,
+                                                                  int32_t *__restrict__ alive, unsigned long long *__restrict__ count,
+                                                                  int32_t *__restrict__ state, int32_t count_samples)
 {
     __shared__ int32_t s_wave[ALIVE_THREADS / 64];
     __shared__ unsigned long long s_base;
+    const int64_t n_samples = state ? (int64_t)state[0] : n_samples_arg;
+    if (state) {
+        if (n_samples == 0) return;
+        if (count_samples && blockIdx.x == 0 && threadIdx.x == 0 && n_rays > 0) {
+            const longlong2 last = packed_info[n_rays - 1];
+            *reinterpret_cast<long long *>(state + 4) += last.x + last.y;
+        }
+    }
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * ALIVE_PER_WG + (int64_t)threadIdx.x * ALIVE_PER_THREAD;
     uint32_t bits = 0u;
@@ -666,11 +677,60 @@ __global__ __launch_bounds__(ALIVE_THREADS) void alive_rays_kernel(const float *
         if ((bits >> k) & 1u) alive[o++] = (int32_t)(r0 + k);
 }
 
+// nfa_testmode_begin: the schedule of one iteration (thread 0) and the zeroing of what the iteration accumulates into
+__global__ __launch_bounds__(256) void testmode_begin_kernel(int64_t *__restrict__ alive_count, int32_t *__restrict__ state, int64_t n_rays,
+                                                            int32_t min_samples, int32_t max_samples, int64_t *__restrict__ sm_cnts,
+                                                            int32_t *__restrict__ run_cnts, int64_t *__restrict__ zero_words, int32_t n_zero)
+{
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)blockDim.x * gridDim.x;
+    for (int64_t i = i0; i < n_rays; i += stride) { sm_cnts[i] = 0; run_cnts[i] = 0; }
+    for (int64_t i = i0; i < n_zero; i += stride) zero_words[i] = 0;
+    if (i0 == 0) {   // examples/utils.py:330-340
+        const int64_t n_alive = alive_count[0];
+        alive_count[1] = n_alive;    // what this iteration's walk lists (n_listed_dev)
+        alive_count[0] = 0;          // nfa_testmode_alive counts into it
+        int32_t n = 0;
+        if (n_alive > 0 && state[1] < max_samples) {
+            const int64_t q = n_rays / n_alive;
+            n = (int32_t)(q < 64 ? q : 64);
+            n = n > min_samples ? n : min_samples;
+            state[1] += n;
+            state[2] += 1;
+        }
+        state[0] = n;
+    }
+}
+
 }  // namespace nfa
 
 using namespace nfa;
 
 extern "C" {
+
+int nfa_testmode_begin(int64_t *alive_count, int32_t *state, int64_t n_rays, int32_t min_samples, int32_t max_samples,
+                       int64_t *sm_cnts, int32_t *run_cnts, int64_t *zero_words, int32_t n_zero, nfa_stream_t stream)
+{
+    NFA_REQUIRE(alive_count && state && n_rays >= 0 && min_samples >= 1 && max_samples >= 1 && (n_rays == 0 || (sm_cnts && run_cnts)) &&
+                n_zero >= 0 && (n_zero == 0 || zero_words), "testmode_begin: bad arguments");
+    hipLaunchKernelGGL(testmode_begin_kernel, dim3(grid_1d(n_rays > 0 ? n_rays : 1, 256, 2048)), dim3(256), 0, as_stream(stream), alive_count,
+                       state, n_rays, min_samples, max_samples, sm_cnts, run_cnts, zero_words, n_zero);
+    NFA_CHECK_LAUNCH("testmode_begin");
+    return NFA_OK;
+}
+
+int nfa_testmode_alive(const float *opacity, const int64_t *packed_info, int32_t *state, float opacity_max, int64_t n_rays,
+                       uint8_t *mask, int32_t *alive, int64_t *count, int32_t count_samples, nfa_stream_t stream)
+{
+    NFA_REQUIRE(n_rays >= 0 && n_rays < ((int64_t)1 << 31) && count && state, "testmode_alive: bad arguments");
+    hipStream_t s = as_stream(stream);
+    if (n_rays == 0) return NFA_OK;      // (*count was zeroed by nfa_testmode_begin: no memset node in the iteration's graph)
+    NFA_REQUIRE(opacity && packed_info && mask && alive, "testmode_alive: null pointer");
+    const unsigned grid = (unsigned)((n_rays + ALIVE_PER_WG - 1) / ALIVE_PER_WG);
+    hipLaunchKernelGGL(alive_rays_kernel, dim3(grid), dim3(ALIVE_THREADS), 0, s, opacity, reinterpret_cast<const longlong2 *>(packed_info),
+                       (int64_t)0, opacity_max, n_rays, mask, alive, reinterpret_cast<unsigned long long *>(count), state, count_samples);
+    NFA_CHECK_LAUNCH("testmode_alive");
+    return NFA_OK;
+}
 
 int64_t nfa_bricks_words(int32_t n_grids, const int32_t *res)
 {
@@ -725,7 +785,7 @@ int nfa_alive_rays(const float *opacity, const int64_t *packed_info, int64_t n_s
     NFA_REQUIRE(opacity && packed_info && mask && alive, "alive_rays: null pointer");
     const unsigned grid = (unsigned)((n_rays + ALIVE_PER_WG - 1) / ALIVE_PER_WG);
     hipLaunchKernelGGL(alive_rays_kernel, dim3(grid), dim3(ALIVE_THREADS), 0, s, opacity, reinterpret_cast<const longlong2 *>(packed_info),
-                       n_samples, opacity_max, n_rays, mask, alive, reinterpret_cast<unsigned long long *>(count));
+                       n_samples, opacity_max, n_rays, mask, alive, reinterpret_cast<unsigned long long *>(count), nullptr, 0);
     NFA_CHECK_LAUNCH("alive_rays");
     return NFA_OK;
 }

@@ -705,13 +705,13 @@ struct WalkOut {
 };
 template <bool FUSED, bool HAS_LIMIT, bool LATTICE>
 __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkParams &p, int64_t tid, char *ev_lds, char *tab_lds,
-                                         uint32_t lane_off, const ApproachLds &tb, const LatticeLds &lt, WalkOut &out)
+                                         uint32_t lane_off, const ApproachLds &tb, const LatticeLds &lt, int32_t steps_limit, WalkOut &out)
 {
     Marcher s;
     LatState ls;
     char *const col = ev_lds + lane_off;
     const float dt = a.step_size;
-    const int32_t limit = HAS_LIMIT ? a.traverse_steps_limit : 0;
+    const int32_t limit = HAS_LIMIT ? steps_limit : 0;
     const uint32_t *__restrict__ bits = p.bits;
     const float near_plane = a.near_planes[tid], far_plane = a.far_planes[tid];
     const float o[3] = {a.rays_o[3 * tid], a.rays_o[3 * tid + 1], a.rays_o[3 * tid + 2]};
@@ -868,7 +868,11 @@ __device__ __forceinline__ void walk_body(const nfa_traverse_args &a, const Walk
     else approach_to_lds(tb, p);
     __syncthreads();
     const uint32_t lane_off = 4u * threadIdx.x;
-    const int64_t n_walk = p.order ? p.n_order : a.n_rays;
+    // device-side controls (include/nerfacc_hip.h: steps_limit_dev, n_listed_dev): a loop that does not wait for the host
+    const int32_t steps_limit = (HAS_LIMIT && a.steps_limit_dev) ? *a.steps_limit_dev : a.traverse_steps_limit;
+    if (HAS_LIMIT && steps_limit <= 0) return;
+    int64_t n_walk = p.order ? p.n_order : a.n_rays;
+    if (p.order && a.n_listed_dev) n_walk = min(n_walk, *a.n_listed_dev);
 #ifdef NFA_WALK_STAMPS
     const int64_t bid = p.tile_order ? (int64_t)p.tile_order[blockIdx.x] : xcd_fair_block(blockIdx.x, gridDim.x);
 #else
@@ -885,7 +889,7 @@ __device__ __forceinline__ void walk_body(const nfa_traverse_args &a, const Walk
             continue;
         }
         WalkOut s;
-        walk_ray<FUSED, HAS_LIMIT, LATTICE>(a, p, tid, ev_lds, tab_lds, lane_off, tb, lt, s);
+        walk_ray<FUSED, HAS_LIMIT, LATTICE>(a, p, tid, ev_lds, tab_lds, lane_off, tb, lt, steps_limit, s);
         if (a.terminate_planes) a.terminate_planes[tid] = s.t_last;
         a.sm_cnts[tid] = s.n_samples;
         if (a.iv_cnts) a.iv_cnts[tid] = s.n_samples + s.n_chains;  // edges = samples + one leading edge per chain
@@ -1411,7 +1415,8 @@ int nfa_traverse_runs(const nfa_traverse_args *pa, const uint32_t *bits, int32_t
     NFA_REQUIRE(a.n_rays >= 0 && a.n_rays < (int64_t)1 << 31, "traverse_runs: n_rays out of range");
     NFA_REQUIRE(overflow_count, "traverse_runs: overflow_count is null");
     hipStream_t s = as_stream(stream);
-    if (hipMemsetAsync(overflow_count, 0, 2 * sizeof(int32_t), s) != hipSuccess) { set_error("traverse_runs: memset failed"); return NFA_EHIP; }
+    // (device-driven calls -- steps_limit_dev set -- come with overflow_count zeroed by nfa_testmode_begin: no memset node in their graph)
+    if (!a.steps_limit_dev && hipMemsetAsync(overflow_count, 0, 2 * sizeof(int32_t), s) != hipSuccess) { set_error("traverse_runs: memset failed"); return NFA_EHIP; }
     if (a.n_rays == 0) return NFA_OK;
     NFA_REQUIRE(a.step_size > 0.0f && a.cone_angle == 0.0f, "traverse_runs: needs step_size > 0 and cone_angle == 0");
     NFA_REQUIRE(a.mode == 0 || a.mode == 2, "traverse_runs: mode must be 0 (all rays) or 2 (rays_mask + limit)");

@@ -2087,3 +2087,38 @@ def test_cone_walk_record_arena(dev, oracle):
             assert (ref[1].cpu().numpy() == riv["vals"][riv["is_left"]]).all() and (ref[2].cpu().numpy() == riv["vals"][riv["is_right"]]).all()
     finally:
         G.MAX_RUNS, G.CONE_ARENA, G.CONE_ARENA_MIN = saved
+
+
+@pytest.mark.parametrize("levels,alpha_thre,graph", [(1, 0.0, True), (2, 0.0, True), (1, 2e-3, True), (1, 0.0, False)])
+def test_padded_test_mode_loop_equals_the_exact_one(dev, levels, alpha_thre, graph):
+    """nerfacc_amd.marching.PaddedTestModeLoop -- the test-mode loop with fixed shapes, the schedule on the device and one
+    iteration replayed as a hipGraph, no host read inside -- gives the image and the sample count of the exact-shape loop
+    (same kernels on the same values: bit for bit), on one and two levels, with an alpha threshold, and replayed a second time."""
+    from nerfacc_amd.marching import render_rays_test_mode, PaddedTestModeLoop
+    rng = np.random.default_rng(23)
+    n, res, step = 6000, 48, 6e-3
+    o = (rng.random((n, 3)).astype(np.float32) - 0.5) * 3.0
+    d = rng.standard_normal((n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    b = rng.random((levels, res, res, res)) < 0.25
+    est = na.OccGridEstimator([-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=res, levels=levels).to(dev)
+    est.binaries = T(b, dev)
+    bk = T(np.array([0.2, 0.4, 0.6], np.float32), dev)
+
+    def field_t(ts, te, ri):
+        tm = (ts + te) * 0.5
+        return (torch.stack([0.5 + 0.5 * torch.cos(tm), (ri % 7).float() / 7.0, torch.full_like(tm, 0.3)], -1),
+                25.0 * (0.5 + 0.5 * torch.sin(9.0 * tm)))
+
+    kw = dict(near_plane=0.05, far_plane=1e10, render_step_size=step, alpha_thre=alpha_thre, early_stop_eps=1e-3)
+    want = render_rays_test_mode(600, field_t, est, T(o, dev), T(d, dev), render_bkgd=bk, **kw)
+    loop = PaddedTestModeLoop(600, field_t, est, T(o, dev), T(d, dev), kw["near_plane"], kw["far_plane"], step, alpha_thre, 1e-3,
+                              use_graph=graph)
+    for rep in range(2):
+        got = loop.render(bk)
+        assert got[3] == want[3] and want[3] > 20000, (rep, got[3], want[3])
+        for a, w in zip(got[:3], want[:3]):
+            assert torch.equal(a, w), rep
+        assert loop.iterations_run >= 10 and loop.iterations_queued <= loop.iterations_run + 3 * loop.check_every
+    if graph:   # the public switch
+        got = render_rays_test_mode(600, field_t, est, T(o, dev), T(d, dev), render_bkgd=bk, padded=True, **kw)
+        assert got[3] == want[3] and all(torch.equal(a, w) for a, w in zip(got[:3], want[:3]))
