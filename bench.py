@@ -572,7 +572,33 @@ def extra_cfg2_testmode(dev, args, n_img=3, parity=True):
     R = w["n_rays"]
     out = {"workload": f"render_rays_test_mode, cfg 2's scene: {R} image rays, {args.res}^3 {args.grid}, step {step:.6f}, cone 0, "
                        f"max_samples 1024, early_stop_eps 1e-4",
-           "ms_per_image": dt * 1e3, "rays_per_s": R / dt, "total_samples": int(total)}
+           "ms_per_image": dt * 1e3, "rays_per_s": R / dt, "total_samples": int(total),
+           "note": "ms_per_image: the exact-shape loop (two host reads per iteration: host-bound); padded: the same loop with fixed "
+                   "shapes, the schedule on the device and one iteration replayed as a hipGraph (no host read inside)"}
+    try:   # the loop without the host in it (nerfacc_amd/marching.py: PaddedTestModeLoop): wall time and GPU-busy time
+        from nerfacc_amd.marching import PaddedTestModeLoop
+        with torch.no_grad():
+            loop = PaddedTestModeLoop(1024, w["rgb_sigma_fn"], est, w["rays_o"], w["rays_d"], 0.0, 1e10, step, 0.0, 1e-4)
+            p_rgb, p_opa, p_dep, p_total = loop.render(None)                                             # warm-up + capture
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(n_img):
+                p_rgb, p_opa, p_dep, p_total = loop.render(None)
+            e1.record()
+            torch.cuda.synchronize()
+            dtp = (time.perf_counter() - t0) / n_img
+        out["padded"] = {"ms_per_image": dtp * 1e3, "rays_per_s": R / dtp, "gpu_busy_ms_per_image": e0.elapsed_time(e1) / n_img,
+                         "iterations_run": loop.iterations_run, "iterations_queued": loop.iterations_queued,
+                         "total_samples": int(p_total),
+                         "identical_to_exact_loop": bool(int(p_total) == int(total) and torch.equal(p_rgb, rgb) and torch.equal(p_opa, opa)
+                                                         and torch.equal(p_dep, dep)),
+                         "gpu_busy_note": "HIP events around the images' replays on the stream they run on; the host queues "
+                                          "iterations ahead of the GPU, so the stream has no idle gaps between them"}
+        del loop
+    except Exception as e:
+        out["padded"] = {"error": repr(e)}
     if parity:
         try:
             from oracle import oracle as O
