@@ -418,19 +418,32 @@ __device__ __forceinline__ void lattice_run(LatState &s, char *col /* LDS column
     const uint32_t n_rows = p.lat.n_rows;
     const int32_t e_lo = (int32_t)p.lat.e_lo, b_hi = (int32_t)p.lat.n_binades - 1;
     const float near_f = bits_f32(p.lat.near_bits);
-    // ---- pass A: thresholds -> lattice positions
+    // ---- pass A: thresholds -> lattice positions.  lattice_J_fast (march.h) without a branch, in the instructions that issue
+    // at the full rate (common.hip.h): conditions are lane masks from the sign of a difference, selects are v_bitop3.
     uint32_t failed = 0u;
+    const float near_half = near_f + half;
     for (int32_t k = 0; k < cnt; ++k) {
         float *slot = reinterpret_cast<float *>(col + (k << WK_LG));
         const float v = *slot;
-        int32_t b = ((int32_t)f32_bits(v - half) >> 23) - e_lo;     // (a negative value: below every row)
+        const float c = v - half;
+        int32_t b = ((int32_t)f32_bits(c) >> 23) - e_lo;            // (a negative value: below every row)
         b = max(0, min(b, b_hi));
-        const uint4 ra = lt.main_a[b];
-        const uint2 rb = lt.main_b[b];
-        uint32_t w = lattice_J_fast(ra.x, ra.y, ra.z, ra.w, bits_f32(rb.x), rb.y, v, half);
-        w = (near_f + half < v) ? w : lattice_pack(0u, 0u);          // no step at all: the ray stays on the near plane
-        failed |= (w == LATTICE_FAIL ? 1u : 0u) << k;
-        *reinterpret_cast<uint32_t *>(slot) = w == LATTICE_FAIL ? f32_bits(v) : w;
+        const uint4 ra = lt.main_a[b];                              // {A, jA, q, n}
+        const uint2 rb = lt.main_b[b];                              // {1 / (q ulp), row}
+        const float est = (c - bits_f32(ra.x)) * bits_f32(rb.x);
+        const uint32_t a = (uint32_t)__builtin_amdgcn_fmed3f(est, 0.0f, 4194304.0f) - 1u;   // floor(est) - 1 (est < 1, NaN: wraps, declined below)
+        // the three points a, a + 1, a + 2 exist: a <= n - 3 as unsigned numbers (n < 3: n - 3 wraps, so test n too)
+        const uint32_t in_row = ~(uint32_t)((int32_t)((ra.w - 3u - a) | a | (ra.w - 3u)) >> 31);
+        const uint32_t b0 = mad_u24(a, ra.z, ra.x), b1 = b0 + ra.z, b2 = b1 + ra.z;   // (a q < 2^23 when the row is right: a < n)
+        const uint32_t m0 = mask_less(bits_f32(b0) + half, v), m1 = mask_less(bits_f32(b1) + half, v), m2 = mask_less(bits_f32(b2) + half, v);
+        const uint32_t ok = in_row & m0 & ~m2;                      // the condition holds at a, fails at a + 2: the answer is a + 1 or a + 2
+        const uint32_t j = ra.y + a + 1u - m1;                      // (m1 is 0 or -1)
+        const uint32_t w_ok = (j << LATTICE_ROW_BITS) | rb.y;
+        const uint32_t stays = ~mask_less(near_half, v);            // no step at all: the ray stays on the near plane, position (0, row 0)
+        const uint32_t served = ok | stays;
+        const uint32_t w = sel_mask(stays, 0u, w_ok);
+        failed |= (~served & 1u) << k;
+        *reinterpret_cast<uint32_t *>(slot) = sel_mask(served, w, f32_bits(v));
     }
     if (failed != 0u) {
         const LatticeRowsLds rows{lt, n_rows};

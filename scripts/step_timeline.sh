@@ -3,16 +3,16 @@
 mkdir -p gpurun_out
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-rm -rf gpurun_out/r03_tl
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r03_tl -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-pipelined --no-extras > gpurun_out/r03_tl.log 2>&1
+rm -rf gpurun_out/r04_tl
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r04_tl -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-pipelined --no-extras > gpurun_out/r04_tl.log 2>&1
 echo rc=$?
-f=$(find gpurun_out/r03_tl -name "*kernel_trace.csv" | head -1)
+f=$(find gpurun_out/r04_tl -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # last full step: from the last walk kernel
-idx = [i for i, r in enumerate(rows) if "walk_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if ("walk_kernel" in r["Kernel_Name"] or "walk_lattice_kernel" in r["Kernel_Name"])]
 a, b = idx[-2], idx[-1]
 t0 = int(rows[a]["Start_Timestamp"]); prev_end = None
 busy = 0
