@@ -497,6 +497,7 @@ struct WalkSpan {
     uint32_t mx, my, mz;      // bits of each axis in the interleaved cell index (0: the ray does not move along the axis)
     uint32_t rem;             // steps left per axis (9 bits + guard each)
     uint32_t widx;            // interleaved index of the current cell, every axis counted in the ray's direction of travel
+    uint32_t end;             // the same for the coordinates (per axis) at which the span is over: start + steps, modulo the axis' range
     uint32_t flip;            // widx ^ flip = bit index in the grid copy (axes walked downwards reflected, level bits)
 };
 
@@ -544,17 +545,23 @@ __device__ __forceinline__ void walk_span_setup(const nfa_traverse_args &a, cons
     sp.dx = delta[0]; sp.dy = delta[1]; sp.dz = delta[2];
     sp.rem = (uint32_t)(nst[0] - 1) | ((uint32_t)(nst[1] - 1) << 10) | ((uint32_t)(nst[2] - 1) << 20) | WK_GUARD;
     // an axis walked downwards counts its reflected coordinate (2^nb - 1 - c = c ^ (2^nb - 1)) upwards: every step is "+1"
-    uint32_t widx = 0u, flip = (uint32_t)level << lay.bits, mk[3];
+    uint32_t widx = 0u, flip = (uint32_t)level << lay.bits, mk[3], end = 0u;
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
         const uint32_t M = lay.mask[ax];
         const uint32_t dep = bit_deposit((uint32_t)cur[ax], M);
-        widx |= stepi[ax] < 0 ? (dep ^ M) : dep;
+        const uint32_t w_ax = stepi[ax] < 0 ? (dep ^ M) : dep;
+        widx |= w_ax;
         flip |= stepi[ax] < 0 ? M : 0u;
         mk[ax] = stepi[ax] != 0 ? M : 0u;
+        // the coordinate nst steps of +1 further, modulo the axis' range (dda_step_lds_end; nst <= 2^bits, so the first time
+        // the axis' bits agree with these is after exactly nst steps; the deposit drops the bits beyond the mask's)
+        const uint32_t c_max = (1u << __builtin_popcount(M)) - 1u;
+        const uint32_t c_ref = stepi[ax] < 0 ? c_max - (uint32_t)cur[ax] : (uint32_t)cur[ax];
+        end |= bit_deposit(c_ref + (uint32_t)nst[ax], M);
     }
     sp.mx = mk[0]; sp.my = mk[1]; sp.mz = mk[2];
-    sp.widx = widx; sp.flip = flip;
+    sp.widx = widx; sp.flip = flip; sp.end = end;
 }
 
 // single_traversal (include/utils_grid.cuh:116-142) on the walk's state; returns the exit distance m of the cell the ray
@@ -600,7 +607,7 @@ __device__ __forceinline__ float dda_step(float dx, float dy, float dz, uint32_t
     const uint32_t M = sel_mask(kz, sel_mask(ky, mx, my), mz);
     uint32_t filled;
     asm("v_bitop3_b32 %0, %1, %2, %2 bitop3:0xcf" : "=v"(filled) : "v"(M), "v"(widx));   // (M & widx) | ~M
-    filled += M & 7u;
+    filled += 1u;                                                                       // (the bits below the axis' lowest one are ones: the carry runs up to it)
     widx = sel_mask(M, filled, widx);                                                   // (M & sum) | (~M & widx)
     return m;
 }
@@ -632,8 +639,34 @@ __device__ __forceinline__ float dda_step_lds(const char *lds, uint32_t ax /* th
     const uint32_t M = f32_bits(row.w);
     uint32_t filled;
     asm("v_bitop3_b32 %0, %1, %2, %2 bitop3:0xcf" : "=v"(filled) : "v"(M), "v"(widx));   // (M & widx) | ~M
-    filled += M & 7u;
+    filled += 1u;
     widx = sel_mask(M, filled, widx);                                                   // (M & sum) | (~M & widx)
+    return m;
+}
+
+// The constant-step walk's form of the same step: no step counters.  The span is over when the coordinate of the axis just
+// stepped reaches the one behind the span's last cell (utils_grid.cuh:138: `cur == final + step`); with every axis counted
+// in the direction of travel that is "the axis' bits of widx equal those of `end`" (walk_span_setup), one v_bitop3 on the
+// mask the row holds anyway: `over` = 0 when the span has ended (an axis that cannot move has no bits: the first step
+// along it ends the span, as a counter of one step did).  3 full-rate instructions less than counters + guard bits.
+__device__ __forceinline__ float dda_step_lds_end(const char *lds, uint32_t ax /* the lane's x row */, uint32_t az /* its z row */, float &tx,
+                                                  float &ty, float &tz, uint32_t end, uint32_t &widx, uint32_t &over)
+{
+    const float m = min3_f32(tx, ty, tz);
+    const uint32_t kz = mask_less(m, tz), ky = mask_less(m, ty);   // ~0: that axis is NOT the minimum
+    uint32_t addr;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xce" : "=v"(addr) : "v"(ky), "v"(ax), "s"(WK_TAB_AXIS));   // ky ? x row : y row  (b | (~a & c))
+    addr = sel_mask(kz, addr, az);
+    const nfa_v4f row = *reinterpret_cast<const nfa_v4f *>(lds + addr);
+    asm("v_add_f32 %0, %0, %1" : "+v"(tx) : "v"(row.x));
+    asm("v_add_f32 %0, %0, %1" : "+v"(ty) : "v"(row.y));
+    asm("v_add_f32 %0, %0, %1" : "+v"(tz) : "v"(row.z));
+    const uint32_t M = f32_bits(row.w);
+    uint32_t filled;
+    asm("v_bitop3_b32 %0, %1, %2, %2 bitop3:0xcf" : "=v"(filled) : "v"(M), "v"(widx));   // (M & widx) | ~M
+    filled += 1u;
+    widx = sel_mask(M, filled, widx);                                                   // (M & sum) | (~M & widx)
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x28" : "=v"(over) : "v"(widx), "v"(end), "v"(M));   // (widx ^ end) & M
     return m;
 }
 
@@ -651,10 +684,16 @@ __device__ __forceinline__ void dda_table_write(char *tab_lds, const WalkSpan &s
 // the ray's open list entry.  Steps the DDA, looks at the current cell's bit, requests the next cell's word into the same
 // registers, closes the open entry when the occupancy flips and records the cell's exit distance in the open entry's slot.
 __device__ __forceinline__ void walk_cell(const char *tab_lds, uint32_t ax, uint32_t az, uint32_t flip, float &tx,
-                                          float &ty, float &tz, uint32_t &rem, uint32_t &widx, uint32_t &ev_addr, float &m_out,
+                                          float &ty, float &tz, uint32_t end, uint32_t &over, uint32_t &widx, uint32_t &ev_addr, float &m_out,
                                           uint32_t &w_cur, uint32_t &i_cur, int32_t &open, const uint32_t *__restrict__ bits, char *ev_lds)
 {
-    const float m = dda_step_lds(tab_lds, ax, az, tx, ty, tz, rem, widx);   // exit distance of this cell (clamped to this_tmax by phase 2)
+#ifdef NFA_WALK_REM_COUNTERS   /* A/B: the step counters with guard bits (`end` holds them) */
+    uint32_t rem = over;
+    const float m = dda_step_lds(tab_lds, ax, az, tx, ty, tz, rem, widx);
+    over = rem;
+#else
+    const float m = dda_step_lds_end(tab_lds, ax, az, tx, ty, tz, end, widx, over);   // exit distance of this cell (clamped to this_tmax by phase 2)
+#endif
     const uint32_t changed = __builtin_amdgcn_ubfe(w_cur, i_cur, 1u) ^ (uint32_t)open;   // bit (i_cur & 31) of the current cell's word
     i_cur = widx ^ flip;
 #if defined(NFA_WALK_EXP) && NFA_WALK_EXP == 1   /* timing experiment: no load at all */
@@ -669,10 +708,14 @@ __device__ __forceinline__ void walk_cell(const char *tab_lds, uint32_t ax, uint
     *reinterpret_cast<float *>(ev_lds + ev_addr) = m;
     m_out = m;
 }
-// stop when a step counter has run out (a guard bit is gone: the span ends) or the open entry sits in the last slot
-__device__ __forceinline__ bool walk_stop(uint32_t rem, uint32_t ev_addr)
+// stop when the span is over (dda_step_lds_end) or the open entry sits in the last slot
+__device__ __forceinline__ bool walk_stop(uint32_t over, uint32_t ev_addr)
 {
-    return ((rem & WK_GUARD) | (ev_addr & WK_FULL)) != WK_GUARD;
+#ifdef NFA_WALK_REM_COUNTERS
+    return ((over & WK_GUARD) | (ev_addr & WK_FULL)) != WK_GUARD;
+#else
+    return (over == 0u) | (ev_addr >= WK_FULL);
+#endif
 }
 
 // The approach table of the launch, read from the kernel-argument segment as memory (indexed by thread: as an argument in
@@ -770,7 +813,7 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
     }
 
     WalkSpan sp;
-    sp.tx = sp.ty = sp.tz = sp.dx = sp.dy = sp.dz = 0.f; sp.mx = sp.my = sp.mz = 0u; sp.rem = 0u; sp.widx = 0u; sp.flip = 0u;
+    sp.tx = sp.ty = sp.tz = sp.dx = sp.dy = sp.dz = 0.f; sp.mx = sp.my = sp.mz = 0u; sp.rem = 0u; sp.widx = 0u; sp.flip = 0u; sp.end = 0u;
     int32_t in_span = 0, has_open = 0, open_type = 0;
     uint32_t w_cur = 0u, i_cur = 0u;   // the word of the grid copy with the current cell's bit, and the bit's index
     uint32_t ev_addr = lane_off;  // byte offset of the open entry's slot: slot << 10 | lane offset
@@ -829,8 +872,15 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
             // the reference's cell loop (grid.cu:184-272) reduced to the DDA
             float tx = sp.tx, ty = sp.ty, tz = sp.tz;
             const uint32_t flip = sp.flip;
-            const uint32_t ax = 16u * threadIdx.x, az = ax + 2u * WK_TAB_AXIS;
-            uint32_t rem = sp.rem;
+            const uint32_t ax = 16u * threadIdx.x;
+            uint32_t az = ax + 2u * WK_TAB_AXIS;
+            asm volatile("" : "+v"(az));   // (kept in a register: left alone, the compiler forms it again in every cell)
+            const uint32_t end = sp.end;
+#ifdef NFA_WALK_REM_COUNTERS
+            uint32_t over = sp.rem;
+#else
+            uint32_t over = 1u;
+#endif
             uint32_t widx = sp.widx;
             // Nothing in the cell loop reads LDS or scalar memory.  Without this the compiler's wait-count pass, which
             // merges the loop header's state with the preheader's, puts an `s_waitcnt lgkmcnt(0)` INSIDE the loop whenever
@@ -838,14 +888,19 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
             // then waited for its own ds_write, the walk took 3x as long).  lgkmcnt(0), vmcnt / expcnt untouched:
             __builtin_amdgcn_s_waitcnt(0xC07F);
 #if defined(NFA_WALK_EXP) && NFA_WALK_EXP == 5   /* timing experiment: everything but the cell loop */
-            rem = 0u;
+            over = 0u;
 #else
             do {
-                walk_cell(tab_lds, ax, az, flip, tx, ty, tz, rem, widx, ev_addr, m_last, w_cur, i_cur, open_type, bits, ev_lds);
-            } while (!walk_stop(rem, ev_addr));
+                walk_cell(tab_lds, ax, az, flip, tx, ty, tz, end, over, widx, ev_addr, m_last, w_cur, i_cur, open_type, bits, ev_lds);
+            } while (!walk_stop(over, ev_addr));
 #endif
-            sp.tx = tx; sp.ty = ty; sp.tz = tz; sp.rem = rem; sp.widx = widx;
-            if ((rem & WK_GUARD) != WK_GUARD) in_span = 0;
+            sp.tx = tx; sp.ty = ty; sp.tz = tz; sp.widx = widx;
+#ifdef NFA_WALK_REM_COUNTERS
+            sp.rem = over;
+            over = ((over & WK_GUARD) != WK_GUARD) ? 0u : 1u;
+#endif
+            asm volatile("" : "+v"(over));   // (otherwise `over == 0` is tracked as a second lane mask inside the cell loop)
+            if (over == 0u) in_span = 0;
             else break;  // list full
         }
         // ---------------- phase 2
@@ -1317,7 +1372,7 @@ __global__ __launch_bounds__(256) void cone_refill_kernel(const nfa_traverse_arg
     ConeRay st;
     st.t_last = 0.0f; st.continuous = 0; st.n_samples = 0; st.n_runs = 0; st.run_len = 0;
     WalkSpan sp;
-    sp.tx = sp.ty = sp.tz = sp.dx = sp.dy = sp.dz = 0.f; sp.mx = sp.my = sp.mz = 0u; sp.rem = 0u; sp.widx = 0u; sp.flip = 0u;
+    sp.tx = sp.ty = sp.tz = sp.dx = sp.dy = sp.dz = 0.f; sp.mx = sp.my = sp.mz = 0u; sp.rem = 0u; sp.widx = 0u; sp.flip = 0u; sp.end = 0u;
     unsigned long long w_cur = 0ull;
     uint32_t i_cur = 0u;
 
