@@ -29,7 +29,7 @@ namespace nfa {
 #ifndef NFA_WK_EV
 #define NFA_WK_EV 16
 #endif
-constexpr int WK_EV = NFA_WK_EV;           // list slots per ray: 16 KiB of LDS per 256 rays -> 8 workgroups per CU
+constexpr int WK_EV = NFA_WK_EV;           // list slots per ray: 17 x 4 bytes of LDS per lane
 #ifndef NFA_WALK_WAVES
 #define NFA_WALK_WAVES 5   /* 100 -> 95 registers (one 8-byte spill outside the loops): 5 waves per SIMD instead of 4 fill a part of the
                               time a slot waits for its next workgroup (scripts/walk_timeline.py): 168 -> 160 us on cfg 2, 384 -> 351 at 256^3 */
@@ -41,7 +41,10 @@ constexpr int WK_EV = NFA_WK_EV;           // list slots per ray: 16 KiB of LDS 
 #endif
 static_assert(NFA_WK_EV == 16 || NFA_WK_EV == 8, "the list-full test is one bit of the slot address: a power of two");
 #ifndef NFA_WALK_LG
-#define NFA_WALK_LG 10   /* log2 of the bytes of one list slot = 4 bytes x threads per workgroup: 10 = 256 threads */
+#define NFA_WALK_LG 8    /* log2 of the bytes of one list slot = 4 bytes x threads per workgroup: 8 = 64 threads, one wave.  A workgroup's
+                            wave slots and LDS are handed on when its LAST wave is done; the waves of a 256-thread workgroup differ by
+                            tens of microseconds (wave time stamps, scripts/walk_timeline.py).  256 / 128 / 64 threads: 146.9 / 144.7 /
+                            142.0 us on cfg 2, 286.5 / 285.0 / 273.4 at 256^3 (one box) */
 #endif
 constexpr int WK_LG = NFA_WALK_LG;
 constexpr int WK_THREADS = 1 << (WK_LG - 2);
@@ -498,6 +501,7 @@ struct WalkSpan {
     uint32_t rem;             // steps left per axis (9 bits + guard each)
     uint32_t widx;            // interleaved index of the current cell, every axis counted in the ray's direction of travel
     uint32_t end;             // the same for the coordinates (per axis) at which the span is over: start + steps, modulo the axis' range
+    uint32_t over;            // 0: the DDA has left the span's last cell (dda_step_lds_end)
     uint32_t flip;            // widx ^ flip = bit index in the grid copy (axes walked downwards reflected, level bits)
 };
 
@@ -618,7 +622,7 @@ __device__ __forceinline__ float dda_step(float dx, float dy, float dz, uint32_t
 // 5 half-rate + 22 full-rate instructions and one 16-byte LDS read per cell (registers: 5 + 27, and six registers more).
 // Rows of 16 bytes, lanes 16 bytes apart, axes 4096 bytes apart: a quad of lanes reads four different bank groups
 // whichever rows its lanes pick.
-constexpr uint32_t WK_TAB_AXIS = WK_THREADS * 16;
+constexpr uint32_t WK_TAB_AXIS = 256 * 16;   // (the cone kernels' workgroups: 256 lanes, whatever the constant-step walk's are)
 static_assert((WK_TAB_AXIS & (WK_TAB_AXIS - 1)) == 0, "the row address is formed by OR-ing the axis offset into the lane's");
 __device__ __forceinline__ float dda_step_lds(const char *lds, uint32_t ax /* the lane's x row */, uint32_t az /* its z row */, float &tx,
                                               float &ty, float &tz, uint32_t &rem, uint32_t &widx)
@@ -653,20 +657,39 @@ __device__ __forceinline__ float dda_step_lds_end(const char *lds, uint32_t ax /
                                                   float &ty, float &tz, uint32_t end, uint32_t &widx, uint32_t &over)
 {
     const float m = min3_f32(tx, ty, tz);
-    const uint32_t kz = mask_less(m, tz), ky = mask_less(m, ty);   // ~0: that axis is NOT the minimum
-    uint32_t addr;
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xce" : "=v"(addr) : "v"(ky), "v"(ax), "s"(WK_TAB_AXIS));   // ky ? x row : y row  (b | (~a & c))
-    addr = sel_mask(kz, addr, az);
+    const uint32_t kz = (uint32_t)((int32_t)f32_bits(m - tz) >> 31), ky = (uint32_t)((int32_t)f32_bits(m - ty) >> 31);   // ~0: that axis is NOT the minimum
+    const uint32_t addr = __builtin_amdgcn_bitop3_b32(kz, __builtin_amdgcn_bitop3_b32(ky, ax, WK_TAB_AXIS, 0xce), az, 0xca);   // kz ? (ky ? x row : y row) : z row
     const nfa_v4f row = *reinterpret_cast<const nfa_v4f *>(lds + addr);
     asm("v_add_f32 %0, %0, %1" : "+v"(tx) : "v"(row.x));
     asm("v_add_f32 %0, %0, %1" : "+v"(ty) : "v"(row.y));
     asm("v_add_f32 %0, %0, %1" : "+v"(tz) : "v"(row.z));
     const uint32_t M = f32_bits(row.w);
-    uint32_t filled;
-    asm("v_bitop3_b32 %0, %1, %2, %2 bitop3:0xcf" : "=v"(filled) : "v"(M), "v"(widx));   // (M & widx) | ~M
-    filled += 1u;
-    widx = sel_mask(M, filled, widx);                                                   // (M & sum) | (~M & widx)
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x28" : "=v"(over) : "v"(widx), "v"(end), "v"(M));   // (widx ^ end) & M
+    const uint32_t filled = __builtin_amdgcn_bitop3_b32(M, widx, widx, 0xcf) + 1u;   // ((M & widx) | ~M) + 1
+    widx = __builtin_amdgcn_bitop3_b32(M, filled, widx, 0xca);                       // (M & sum) | (~M & widx)
+    over = __builtin_amdgcn_bitop3_b32(widx, end, M, 0x28);                          // (widx ^ end) & M
+    return m;
+}
+
+// The same step with the per-axis constants in registers and no table: the distances are updated as t += delta & mask, so no
+// LDS read stands between one cell's minimum and the next one's (26 vector instructions instead of 23 and a read).
+__device__ __forceinline__ float dda_step_reg_end(float dx, float dy, float dz, uint32_t mx, uint32_t my, uint32_t mz, float &tx, float &ty,
+                                                  float &tz, uint32_t end, uint32_t &widx, uint32_t &over)
+{
+    // (compiler builtins where there is one: between two `asm` statements the compiler puts an s_nop whenever the second reads
+    //  what the first wrote -- it cannot know that the first is no transcendental -- and seven of those per cell cost as much
+    //  as seven instructions at this occupancy)
+    const float m = min3_f32(tx, ty, tz);
+    const uint32_t kz = (uint32_t)((int32_t)f32_bits(m - tz) >> 31), ky = (uint32_t)((int32_t)f32_bits(m - ty) >> 31);   // ~0: that axis is NOT the minimum
+    const float ix = bits_f32(__builtin_amdgcn_bitop3_b32(f32_bits(dx), kz, ky, 0x80));   // dx & kz & ky
+    const float iy = bits_f32(__builtin_amdgcn_bitop3_b32(f32_bits(dy), kz, ky, 0x40));   // dy & kz & ~ky
+    const float iz = bits_f32(__builtin_amdgcn_bitop3_b32(f32_bits(dz), kz, kz, 0x30));   // dz & ~kz
+    asm("v_add_f32 %0, %0, %1" : "+v"(tx) : "v"(ix));   // (t + 0 = t exactly: the distances are never -0; plain adds would be paired into a half-rate v_pk_add_f32)
+    asm("v_add_f32 %0, %0, %1" : "+v"(ty) : "v"(iy));
+    asm("v_add_f32 %0, %0, %1" : "+v"(tz) : "v"(iz));
+    const uint32_t M = __builtin_amdgcn_bitop3_b32(kz, __builtin_amdgcn_bitop3_b32(ky, mx, my, 0xca), mz, 0xca);
+    const uint32_t filled = __builtin_amdgcn_bitop3_b32(M, widx, widx, 0xcf) + 1u;   // ((M & widx) | ~M) + 1: the carry runs up to the axis' lowest bit
+    widx = __builtin_amdgcn_bitop3_b32(M, filled, widx, 0xca);
+    over = __builtin_amdgcn_bitop3_b32(widx, end, M, 0x28);                          // (widx ^ end) & M
     return m;
 }
 
@@ -679,43 +702,44 @@ __device__ __forceinline__ void dda_table_write(char *tab_lds, const WalkSpan &s
     *reinterpret_cast<nfa_v4f *>(row + 2 * WK_TAB_AXIS) = nfa_v4f{0.0f, 0.0f, sp.dz, bits_f32(sp.mz)};
 }
 
-// One cell of the walk.  (w_cur, i_cur): the word of the grid copy that holds the occupancy bit of the cell the ray is in
-// and the bit's index -- requested when the ray entered the cell, one cell's worth of instructions ago; `open`: the kind of
-// the ray's open list entry.  Steps the DDA, looks at the current cell's bit, requests the next cell's word into the same
-// registers, closes the open entry when the occupancy flips and records the cell's exit distance in the open entry's slot.
-__device__ __forceinline__ void walk_cell(const char *tab_lds, uint32_t ax, uint32_t az, uint32_t flip, float &tx,
-                                          float &ty, float &tz, uint32_t end, uint32_t &over, uint32_t &widx, uint32_t &ev_addr, float &m_out,
-                                          uint32_t &w_cur, uint32_t &i_cur, int32_t &open, const uint32_t *__restrict__ bits, char *ev_lds)
+// One cell of the walk in three pieces, because they run one cell apart (walk_ray's cell loop):
+//   dda_step_lds_end  steps the DDA out of the cell the ray is in and returns that cell's exit distance;
+//   walk_request      requests the word of the grid copy that holds the occupancy bit of the cell the ray is in now
+//                     ((i, w): the bit's index and the word);
+//   walk_record       looks at a cell's bit once its word has arrived, closes the ray's open list entry when the occupancy
+//                     flips and records the cell's exit distance in the open entry's slot (`open`: the kind of the open entry).
+// The cell sequence does not depend on the occupancy, so the DDA may run ahead: a word is requested TWO steps before it is
+// looked at (the request used to be one cell old and the wave waited for it in every cell: 43 % of a wave's life was spent in
+// s_waitcnt, SQ_WAIT_ANY).
+// The request is written as an instruction the compiler does not track and is waited for by hand (walk_arrived): its own
+// wait-count pass has to assume that a wave may go from the loop's first half straight to the next trip (the lanes leave the
+// loop one by one, so the structured loop has that edge) and would wait for EVERY request at the first use of a word, the one
+// made half a trip ago included.  Requests return in order: "at most one in flight" means the older word has arrived.
+__device__ __forceinline__ void walk_request(uint32_t widx, uint32_t flip, const uint32_t *__restrict__ bits, uint32_t &i, uint32_t &w)
 {
-#ifdef NFA_WALK_REM_COUNTERS   /* A/B: the step counters with guard bits (`end` holds them) */
-    uint32_t rem = over;
-    const float m = dda_step_lds(tab_lds, ax, az, tx, ty, tz, rem, widx);
-    over = rem;
+    i = widx ^ flip;
+#if defined(NFA_WALK_EXP) && NFA_WALK_EXP == 2  /* timing experiment: every load hits one 128-byte line */
+    const uint32_t off = ((i >> 5) & 31u) << 2;
 #else
-    const float m = dda_step_lds_end(tab_lds, ax, az, tx, ty, tz, end, widx, over);   // exit distance of this cell (clamped to this_tmax by phase 2)
+    const uint32_t off = (i >> 5) << 2;
 #endif
-    const uint32_t changed = __builtin_amdgcn_ubfe(w_cur, i_cur, 1u) ^ (uint32_t)open;   // bit (i_cur & 31) of the current cell's word
-    i_cur = widx ^ flip;
-#if defined(NFA_WALK_EXP) && NFA_WALK_EXP == 1   /* timing experiment: no load at all */
-    w_cur = i_cur >> 2;
-#elif defined(NFA_WALK_EXP) && NFA_WALK_EXP == 2  /* timing experiment: every load hits one 128-byte line */
-    w_cur = bits[(i_cur >> 5) & 31u];
-#else
-    w_cur = bits[i_cur >> 5];
-#endif
-    open ^= (int32_t)changed;                 // = the current cell's occupancy
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(w) : "v"(off), "s"(bits) : "memory");
+}
+// the older of the two words in flight has arrived / both have
+// (`after`: a value the wait is to follow in the instruction order -- left alone it is scheduled to the top of the cell)
+__device__ __forceinline__ void walk_arrived(uint32_t &w, uint32_t after) { asm volatile("s_waitcnt vmcnt(1)" : "+v"(w) : "v"(after) : "memory"); }
+__device__ __forceinline__ void walk_arrived_all(uint32_t &w0, uint32_t &w1) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1) : : "memory"); }
+__device__ __forceinline__ void walk_record(float m, uint32_t w, uint32_t i, int32_t &open, uint32_t &ev_addr, char *ev_lds)
+{
+    const uint32_t changed = __builtin_amdgcn_ubfe(w, i, 1u) ^ (uint32_t)open;   // bit (i & 31) of the cell's word
+    open ^= (int32_t)changed;                    // = the cell's occupancy
     ev_addr += changed << WK_LG;                 // the open entry is complete when the occupancy flips
     *reinterpret_cast<float *>(ev_lds + ev_addr) = m;
-    m_out = m;
 }
 // stop when the span is over (dda_step_lds_end) or the open entry sits in the last slot
 __device__ __forceinline__ bool walk_stop(uint32_t over, uint32_t ev_addr)
 {
-#ifdef NFA_WALK_REM_COUNTERS
-    return ((over & WK_GUARD) | (ev_addr & WK_FULL)) != WK_GUARD;
-#else
     return (over == 0u) | (ev_addr >= WK_FULL);
-#endif
 }
 
 // The approach table of the launch, read from the kernel-argument segment as memory (indexed by thread: as an argument in
@@ -759,6 +783,11 @@ struct WalkOut {
     float t_last;
     int32_t n_samples, n_chains, n_runs;
 };
+#if defined(NFA_WALK_TABLE)   /* A/B: the step's constants from the LDS table */
+#define WALK_DDA(tx_, ty_, tz_, widx_, over_) dda_step_lds_end(tab_lds, 16u * threadIdx.x, walk_az, tx_, ty_, tz_, sp.end, widx_, over_)
+#else
+#define WALK_DDA(tx_, ty_, tz_, widx_, over_) dda_step_reg_end(sp.dx, sp.dy, sp.dz, sp.mx, sp.my, sp.mz, tx_, ty_, tz_, sp.end, widx_, over_)
+#endif
 template <bool FUSED, bool HAS_LIMIT, bool LATTICE>
 __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkParams &p, int64_t tid, char *ev_lds, char *tab_lds,
                                          uint32_t lane_off, const ApproachLds &tb, const LatticeLds &lt, int32_t steps_limit, WalkOut &out)
@@ -813,9 +842,13 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
     }
 
     WalkSpan sp;
-    sp.tx = sp.ty = sp.tz = sp.dx = sp.dy = sp.dz = 0.f; sp.mx = sp.my = sp.mz = 0u; sp.rem = 0u; sp.widx = 0u; sp.flip = 0u; sp.end = 0u;
+    sp.tx = sp.ty = sp.tz = sp.dx = sp.dy = sp.dz = 0.f; sp.mx = sp.my = sp.mz = 0u; sp.rem = 0u; sp.widx = 0u; sp.flip = 0u; sp.end = 0u; sp.over = 0u;
     int32_t in_span = 0, has_open = 0, open_type = 0;
-    uint32_t w_cur = 0u, i_cur = 0u;   // the word of the grid copy with the current cell's bit, and the bit's index
+    // the two cells in flight (see the cell loop): P has been stepped out of (exit distance m_p) and waits for its word, Q is
+    // the cell the ray is in; (i, w): the index of a cell's occupancy bit and the word of the grid copy that holds it
+    float m_p = 0.f, m_q = 0.f;
+    uint32_t i_p = 0u, w_p = 0u, i_q = 0u, w_q = 0u;
+    int32_t par = 0;              // 1: the roles of P and Q are exchanged (the cell loop was left after its first half)
     uint32_t ev_addr = lane_off;  // byte offset of the open entry's slot: slot << 10 | lane offset
     uint32_t ev_span = 0u;
     float m_last = 0.f;
@@ -860,48 +893,81 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
                 *reinterpret_cast<float *>(col + ((kk + 1u) << WK_LG)) = this_tmax;
                 ev_span |= 1u << kk;
                 walk_span_setup(a, p.lay, o, d, level, this_tmin, this_tmax, sp);
+#if defined(NFA_WALK_TABLE)
                 dda_table_write(tab_lds, sp);   // the span's per-axis constants (dda_step_lds)
+                uint32_t walk_az = 16u * threadIdx.x + 2u * WK_TAB_AXIS;
+#endif
                 const uint32_t idx0 = sp.widx ^ sp.flip;
-                w_cur = bits[idx0 >> 5]; i_cur = idx0;
-                open_type = (int32_t)((w_cur >> (idx0 & 31u)) & 1u);
+                w_p = bits[idx0 >> 5]; i_p = idx0;
+                open_type = (int32_t)((w_p >> (idx0 & 31u)) & 1u);
                 ev_span |= (uint32_t)open_type << (16u + kk);
                 ev_addr = ((kk + 2u) << WK_LG) | lane_off;
                 has_open = 1;
                 in_span = 1;
+                // the first cell's step: its exit distance, the request for the second cell's word
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                m_p = WALK_DDA(sp.tx, sp.ty, sp.tz, sp.widx, sp.over);
+                walk_request(sp.widx, sp.flip, bits, i_q, w_q);
+                par = 0;
             }
-            // the reference's cell loop (grid.cu:184-272) reduced to the DDA
+            // The reference's cell loop (grid.cu:184-272) reduced to the DDA.  At its head: cell P (m_p, i_p, w_p) has been
+            // stepped out of but not recorded, cell Q (i_q, w_q) is the one the ray is in, its word requested.  Two cells per
+            // trip, P's and Q's registers trading roles, so that nothing is moved from one to the other.
             float tx = sp.tx, ty = sp.ty, tz = sp.tz;
             const uint32_t flip = sp.flip;
-            const uint32_t ax = 16u * threadIdx.x;
-            uint32_t az = ax + 2u * WK_TAB_AXIS;
-            asm volatile("" : "+v"(az));   // (kept in a register: left alone, the compiler forms it again in every cell)
-            const uint32_t end = sp.end;
-#ifdef NFA_WALK_REM_COUNTERS
-            uint32_t over = sp.rem;
-#else
-            uint32_t over = 1u;
+#if defined(NFA_WALK_TABLE)
+            uint32_t walk_az = 16u * threadIdx.x + 2u * WK_TAB_AXIS;
+            asm volatile("" : "+v"(walk_az));   // (kept in a register: left alone, the compiler forms it again in every cell)
 #endif
+            uint32_t over = sp.over;
             uint32_t widx = sp.widx;
-            // Nothing in the cell loop reads LDS or scalar memory.  Without this the compiler's wait-count pass, which
-            // merges the loop header's state with the preheader's, puts an `s_waitcnt lgkmcnt(0)` INSIDE the loop whenever
-            // some path into it leaves an LDS read or a kernel-argument load in flight (in the single-launch forms of the one-pass traversal: every cell
-            // then waited for its own ds_write, the walk took 3x as long).  lgkmcnt(0), vmcnt / expcnt untouched:
-            __builtin_amdgcn_s_waitcnt(0xC07F);
+            // Nothing in the cell loop but the table read uses LDS results or scalar memory.  Without this the compiler's wait-count
+            // pass, which merges the loop header's state with the preheader's, puts an `s_waitcnt lgkmcnt(0)` in front of every
+            // ds_write whenever some path into the loop leaves an LDS read or a kernel-argument load in flight.
+            // The same pass decides how many requests may stay in flight at the loop's first use of a word from ALL the paths into
+            // the loop (behind phase 2 its stores are in flight too) and settles for "none": the request made half a trip ago
+            // would be waited for.  With nothing in flight at the loop's head it finds vmcnt(1) in both halves.
+            // vmcnt(0) lgkmcnt(0), expcnt untouched:
+            __builtin_amdgcn_s_waitcnt(0x0070);
 #if defined(NFA_WALK_EXP) && NFA_WALK_EXP == 5   /* timing experiment: everything but the cell loop */
             over = 0u;
 #else
-            do {
-                walk_cell(tab_lds, ax, az, flip, tx, ty, tz, end, over, widx, ev_addr, m_last, w_cur, i_cur, open_type, bits, ev_lds);
-            } while (!walk_stop(over, ev_addr));
+            if (over != 0u) {
+                // (`par`: whose registers hold the unrecorded cell when the loop is left -- the lanes leave it one by one and
+                //  nothing is moved on the way out: a move of a register with a request in flight waits for the request.  A lane
+                //  that left after the first half resumes with the second.)
+                bool go = true;
+                if (par) {
+                    m_p = WALK_DDA(tx, ty, tz, widx, over);
+                    walk_arrived(w_q, over);
+                    walk_record(m_q, w_q, i_q, open_type, ev_addr, ev_lds);
+                    walk_request(widx, flip, bits, i_q, w_q);
+                    par = 0;
+                    go = !walk_stop(over, ev_addr);
+                }
+                if (go) for (;;) {
+                    m_q = WALK_DDA(tx, ty, tz, widx, over);   // out of Q
+                    walk_arrived(w_p, over);
+                    walk_record(m_p, w_p, i_p, open_type, ev_addr, ev_lds);
+                    walk_request(widx, flip, bits, i_p, w_p);                               // P's registers: the cell behind Q
+                    if (walk_stop(over, ev_addr)) { par = 1; break; }
+                    m_p = WALK_DDA(tx, ty, tz, widx, over);   // out of the cell in P's registers
+                    walk_arrived(w_q, over);
+                    walk_record(m_q, w_q, i_q, open_type, ev_addr, ev_lds);
+                    walk_request(widx, flip, bits, i_q, w_q);
+                    if (walk_stop(over, ev_addr)) break;
+                }
+                asm volatile("" : "+v"(par));   // (otherwise "the cell recorded last" is tracked with a move in every cell)
+                m_last = par ? m_p : m_q;   // the cell recorded last
+            }
 #endif
-            sp.tx = tx; sp.ty = ty; sp.tz = tz; sp.widx = widx;
-#ifdef NFA_WALK_REM_COUNTERS
-            sp.rem = over;
-            over = ((over & WK_GUARD) != WK_GUARD) ? 0u : 1u;
-#endif
-            asm volatile("" : "+v"(over));   // (otherwise `over == 0` is tracked as a second lane mask inside the cell loop)
-            if (over == 0u) in_span = 0;
-            else break;  // list full
+            walk_arrived_all(w_p, w_q);
+            sp.tx = tx; sp.ty = ty; sp.tz = tz; sp.widx = widx; sp.over = over;
+            if (ev_addr >= WK_FULL) break;   // list full: phase 2 first (the unrecorded cell stays so)
+            // the span's DDA is over: its last cell is recorded, and the next span (or the end) follows
+            m_last = par ? m_q : m_p;
+            walk_record(m_last, par ? w_q : w_p, par ? i_q : i_p, open_type, ev_addr, ev_lds);
+            in_span = 0;
         }
         // ---------------- phase 2
         int32_t cnt = (int32_t)(ev_addr >> WK_LG);
@@ -926,7 +992,12 @@ template <bool FUSED, bool HAS_LIMIT, bool LATTICE>
 __device__ __forceinline__ void walk_body(const nfa_traverse_args &a, const WalkParams &p)
 {
     __shared__ __attribute__((aligned(16))) char ev_lds[(WK_EV + 1) << WK_LG];   // [WK_EV + 1][256] floats
+#if defined(NFA_WALK_TABLE)
+    static_assert(WK_THREADS == 256, "the table's rows are laid out for 256 lanes");
     __shared__ __attribute__((aligned(16))) char tab_lds[3 * WK_TAB_AXIS];         // [3][256] rows of the DDA's per-axis constants
+#else
+    char *const tab_lds = nullptr;   // (the step's constants stay in registers: dda_step_reg_end)
+#endif
     __shared__ ApproachLds tb;
     __shared__ LatticeLds lt;
 #ifdef NFA_WALK_STAMPS
@@ -1347,7 +1418,6 @@ __attribute__((amdgpu_waves_per_eu(NFA_CONE_REFILL_WAVES, NFA_CONE_REFILL_WAVES)
 __global__ __launch_bounds__(256) void cone_refill_kernel(const nfa_traverse_args a, const ConeParams p_in)
 {
     static_assert(!(FUSED && STAGED), "a fused walk has no event list");
-    static_assert(WK_THREADS == 256, "the cone kernels share the walk's table layout");
     __shared__ __attribute__((aligned(16))) char s_tab[3 * WK_TAB_AXIS];
     ConeParams p = p_in;
     p.tab_lds = s_tab;
@@ -1372,7 +1442,7 @@ __global__ __launch_bounds__(256) void cone_refill_kernel(const nfa_traverse_arg
     ConeRay st;
     st.t_last = 0.0f; st.continuous = 0; st.n_samples = 0; st.n_runs = 0; st.run_len = 0;
     WalkSpan sp;
-    sp.tx = sp.ty = sp.tz = sp.dx = sp.dy = sp.dz = 0.f; sp.mx = sp.my = sp.mz = 0u; sp.rem = 0u; sp.widx = 0u; sp.flip = 0u; sp.end = 0u;
+    sp.tx = sp.ty = sp.tz = sp.dx = sp.dy = sp.dz = 0.f; sp.mx = sp.my = sp.mz = 0u; sp.rem = 0u; sp.widx = 0u; sp.flip = 0u; sp.end = 0u; sp.over = 0u;
     unsigned long long w_cur = 0ull;
     uint32_t i_cur = 0u;
 
