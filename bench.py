@@ -439,18 +439,28 @@ def kernel_table(ksum, ab):
     return kernels
 
 
-def timed_steps(fn, steps, warmup, with_kernels=True):
+def timed_steps(fn, steps, warmup, with_kernels=True, per_step=None):
     """(seconds per step, per-native-call HIP-event table) of `fn` -- used for the secondary configurations; the headline
-    loop in main() is timed without the per-call events."""
+    loop in main() is timed without the per-call events.  `per_step` (a list): every step is timed by itself (a
+    synchronisation after each: for steps of many milliseconds), the list receives the times and the MEDIAN is returned -- a
+    configuration that is given three steps must not report one allocator stall as half of its figure."""
     for _ in range(warmup):
         out = fn()
     gc.collect(); gc.disable()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        out = fn()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    if per_step is not None:
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            out = fn()
+            torch.cuda.synchronize()
+            per_step.append(time.perf_counter() - t0)
+        dt = float(np.median(per_step))
+    else:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
     gc.enable()
     ks = {}
     if with_kernels:
@@ -732,13 +742,15 @@ def extra_cfg5(dev, R, steps, res=512, G=4, parity=True, train=True):
     out = {"workload": f"cfg5: {G} nested {res}^3 levels, R={R} rays from inside, step 1e-3, cone 0.004, near 0.2, "
                        f"alpha_thre 1e-2, sampling + rendering fwd + bwd"}
     if train:
-        dt, ks, m = timed_steps(step, steps, 2)
+        step_s: list = []
+        dt, ks, m = timed_steps(step, max(steps, 5), 3, per_step=step_s)
         ri, ts, te, pi = na.grid._traverse_samples(rays_o, rays_d, est.binaries, est.aabbs, torch.full((R,), 0.2, device=dev),
                                                    torch.full((R,), 1e10, device=dev), 1e-3, 0.004)
         M = int(ri.numel())
         del ri, ts, te, pi
         kernels = kernel_table(ks, algorithmic_bytes(R, M, int(m), res, G))
-        out.update({"ms_per_step": dt * 1e3, "rays_per_s": R / dt, "samples_before_compaction": M, "samples_after_compaction": int(m),
+        out.update({"ms_per_step": dt * 1e3, "ms_per_step_is": "median of the steps timed one by one", "ms_each_step": [round(x * 1e3, 2) for x in step_s],
+                    "rays_per_s": R / dt, "samples_before_compaction": M, "samples_after_compaction": int(m),
                     "native_ms_per_step": sum(v["ms_per_step"] for v in ks.values()),
                     "kernels": {k: {kk: vv for kk, vv in v.items() if kk != "launches_per_step"} for k, v in kernels.items()}})
     # ---- the a12 test-mode loop on the same scene (SURVEY 8d cfg 5: "run both sampling (train) and the test-mode loop")

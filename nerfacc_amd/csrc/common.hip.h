@@ -137,26 +137,20 @@ __device__ __forceinline__ int64_t xcd_fair_block(uint32_t b, uint32_t n_blocks)
 // table: a select whose condition is a lane MASK in a register ((k & x) | (~k & y)) is one v_bitop3 at the full rate where
 // v_cndmask / v_bfi run at half of it, and "x is the minimum m of the values" is the sign of m - x (two full-rate
 // instructions for a mask that serves any number of selects) instead of a compare plus a select each.
+// (The compiler's builtin where there is one: between two `asm` statements it puts an s_nop whenever the second reads what the
+// first wrote -- it cannot know that the first is no transcendental -- and an s_nop costs an issue slot like an instruction.)
 __device__ __forceinline__ uint32_t sel_mask(uint32_t k, uint32_t x, uint32_t y)   // k ? x : y, bit by bit
 {
-    uint32_t r;
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca" : "=v"(r) : "v"(k), "v"(x), "v"(y));
-    return r;
+    return __builtin_amdgcn_bitop3_b32(k, x, y, 0xca);
 }
 __device__ __forceinline__ float sel_mask(uint32_t k, float x, float y)
 {
-    float r;
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca" : "=v"(r) : "v"(k), "v"(x), "v"(y));
-    return r;
+    return __builtin_bit_cast(float, __builtin_amdgcn_bitop3_b32(k, __builtin_bit_cast(uint32_t, x), __builtin_bit_cast(uint32_t, y), 0xca));
 }
 // ~0 where a - b is negative (a < b for finite a, b; a == b gives +0: no bits), else 0
 __device__ __forceinline__ uint32_t mask_less(float a, float b)
 {
-    float d;
-    int32_t k;
-    asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(k) : "v"(d));
-    return (uint32_t)k;
+    return (uint32_t)(__builtin_bit_cast(int32_t, a - b) >> 31);   // v_sub_f32, v_ashrrev_i32 (checked in the generated code)
 }
 __device__ __forceinline__ float min3_f32(float a, float b, float c)
 {
