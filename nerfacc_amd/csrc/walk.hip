@@ -1125,9 +1125,18 @@ __device__ __forceinline__ bool cone_cell(const nfa_traverse_args &a, const Cone
     const uint32_t w_half = (i_cur & 32u) ? (uint32_t)(w_cur >> 32) : (uint32_t)w_cur;
     const bool occupied = __builtin_amdgcn_ubfe(w_half, i_cur, 1u) != 0u;   // bit (i_cur & 31) of the half
     const uint32_t tab_x = 16u * threadIdx.x;
-    const float m = dda_step_lds(p.tab_lds, tab_x, tab_x + 2u * WK_TAB_AXIS, sp.tx, sp.ty, sp.tz, sp.rem, sp.widx);
+    // (the end of the span: by the cell index in the one-ray-per-lane kernel -- cfg 5's count pass 7.30 -> 7.20 ms --, by the
+    //  step counters in the refilling one, where the index form measured 2 % slower per image: 100.6 -> 102.6 ms)
+    float m;
+    bool done;
+    if constexpr (SPLIT) {
+        m = dda_step_lds(p.tab_lds, tab_x, tab_x + 2u * WK_TAB_AXIS, sp.tx, sp.ty, sp.tz, sp.rem, sp.widx);
+        done = (sp.rem & WK_GUARD) != WK_GUARD;
+    } else {
+        m = dda_step_lds_end(p.tab_lds, tab_x, tab_x + 2u * WK_TAB_AXIS, sp.tx, sp.ty, sp.tz, sp.end, sp.widx, sp.over);
+        done = sp.over == 0u;
+    }
     const float t_traverse = vmin_f32(m, this_tmax);
-    const bool done = (sp.rem & WK_GUARD) != WK_GUARD;
     // The next cell's bit: the low six index bits are two of each coordinate, so an aligned 64-bit word of the copy is a
     // 4 x 4 x 4 brick; it stays in registers while the ray is inside it (with unrelated rays every load of a wave is 64
     // cache lines: one load per cell instead of one per brick cost the unlimited walk of cfg 5 2 ms of 12) and the load,
