@@ -3,20 +3,22 @@
 //
 // Reference semantics: cuda/csrc/grid.cu:68-282 (kernel), include/utils_grid.cuh:58-142 (setup_traversal,
 // single_traversal); the reference walks every ray twice (count + fill) with one scattered 1-byte grid load, a
-// per-sample loop and three-way divergence per cell.  The walk is bound by instruction issue, not by memory, so it
-// is built around the instruction count per cell:
+// per-sample loop and three-way divergence per cell.  The walk moves almost no memory; what it costs is a wave's time
+// per cell (instructions of every kind, and the round trips it waits for), so it is built around those:
 //
-//   phase 1  the cell loop does ONLY the DDA: the three boundary distances, a packed step counter that ends the span
-//            (three 10-bit fields with a guard bit each: the step that would leave the span's last cell clears a guard),
-//            a linear bit index that moves by a per-axis stride, one 4-byte load per cell from the 1-bit-per-cell copy of
-//            the grid (issued for the NEXT cell: the cell sequence does not depend on occupancy), and one LDS store: the
-//            exit distance of the current cell goes to the slot of the ray's open list entry, and the slot index moves
-//            on when the occupancy flips.  No marching, no branches besides the loop's own.  ~25 vector instructions.
+//   phase 1  the cell loop does ONLY the DDA: the three boundary distances (one v_min3, lane masks from sign bits,
+//            t += delta & mask), an interleaved cell index that moves by a masked increment and ends the span when the
+//            stepped axis' bits reach the end cell's, one 4-byte load per cell from the 1-bit-per-cell copy of the grid --
+//            requested TWO steps before it is looked at: the cell sequence does not depend on occupancy --, and one LDS
+//            store: the exit distance of a cell goes to the slot of the ray's open list entry, and the slot index moves
+//            on when the occupancy flips.  No marching, no branches besides the loop's own.  26 vector instructions.
 //   phase 2  a ray's list is a handful of thresholds of alternating kind (skip to / emit to).  Inside one binade every
-//            step of the serial accumulation t += dt adds the same number q of ulps (march.h), so the march to a
-//            threshold is "the smallest J with fl(t + J q ulp + dt/2) >= thr": an fp32 estimate and four exact probes,
-//            straight-line code, no loop.  Events that leave the binade (or stand on the near plane, or meet an exact
-//            tie) are left for a general path that the whole wave runs together once the lock-step loop has drained.
+//            step of the serial accumulation t += dt adds the same number q of ulps (march.h).  With ONE near plane for
+//            the launch every ray stands on one lattice of sample positions and an entry is the index J(thr) of a lattice
+//            point (lattice_run: no state, no branches in the conversion; samples are index differences); with per-ray near
+//            planes the march to a threshold is "the smallest J with fl(t + J q ulp + dt/2) >= thr": an fp32 estimate and
+//            four exact probes, straight-line code (marcher_run).  Events that leave the binade (or stand on the near plane,
+//            or meet an exact tie) are left for a general path that the whole wave runs together.
 //
 // Results are bit-identical to the serial accumulation (oracle/nerfacc_oracle.c; tests/test_march_cpu.py checks
 // the same marching code against the serial loop on the CPU).
@@ -568,54 +570,14 @@ __device__ __forceinline__ void walk_span_setup(const nfa_traverse_args &a, cons
     sp.widx = widx; sp.flip = flip; sp.end = end;
 }
 
-// single_traversal (include/utils_grid.cuh:116-142) on the walk's state; returns the exit distance m of the cell the ray
-// leaves.  The reference steps x if tx < ty && tx < tz, else y if ty < tz, else z: that is "z if tz is the minimum, else y
-// if ty is, else x" (ties go z over y over x either way), and the chosen axis' distance IS m, so its update is m + delta.
-// Written against the issue rates of common.hip.h: ONE half-rate instruction (v_min3); "is the minimum" comes from the sign
-// of m - t, every select is a v_bitop3 on those masks (the first form -- two v_min, two v_cmp, ten v_cndmask, two v_bfi --
-// was 15 half-rate + 15 full-rate instructions per cell, this one is 5 + 27).  The distances are never -0 (walk_span_setup
-// adds +0), so m - t is +0 exactly for the minimum.
-__device__ __forceinline__ float dda_step(float dx, float dy, float dz, uint32_t mx, uint32_t my, uint32_t mz, float &tx, float &ty,
-                                          float &tz, uint32_t &rem, uint32_t &widx)
-{
-#if defined(NFA_DDA_FORM) && NFA_DDA_FORM == 0   /* A/B: the first form (compares + v_cndmask) */
-    const float n = vmin_f32(ty, tz);
-    const float m0 = vmin_f32(tx, n);
-    const bool s0 = tx < n;
-    const bool s1 = ty < tz;
-    const float dsel = s0 ? dx : (s1 ? dy : dz);
-    const float nm0 = m0 + dsel;
-    const float ty1 = s1 ? nm0 : ty, tz1 = s1 ? tz : nm0;
-    tx = s0 ? nm0 : tx;
-    ty = s0 ? ty : ty1;
-    tz = s0 ? tz : tz1;
-    rem -= s0 ? 1u : (s1 ? (1u << 10) : (1u << 20));
-    const uint32_t M0 = s0 ? mx : (s1 ? my : mz);
-    uint32_t filled0;
-    asm("v_bfi_b32 %0, %1, %2, -1" : "=v"(filled0) : "v"(M0), "v"(widx));
-    filled0 += M0 & 7u;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(widx) : "v"(M0), "v"(filled0), "v"(widx));
-    return m0;
-#endif
-    const float m = min3_f32(tx, ty, tz);
-    const uint32_t kz = mask_less(m, tz), ky = mask_less(m, ty);   // ~0: that axis is NOT the minimum
-    const uint32_t go_x = kz & ky, go_y = kz & ~ky;                // ~0: the step goes along x / along y (else z: ~kz)
-    const float nm = m + sel_mask(kz, sel_mask(ky, dx, dy), dz);
-    tx = sel_mask(go_x, nm, tx);
-    ty = sel_mask(go_y, nm, ty);
-    tz = sel_mask(kz, tz, nm);
-    rem -= sel_mask(kz, sel_mask(ky, 1u, 1u << 10), 1u << 20);
-    // +1 on the chosen axis' bits of the interleaved index: fill the other bits with ones so that the carry runs through
-    // them, add the axis' lowest bit, keep the axis' bits of the sum (a carry out of the top bit is dropped: one step
-    // outside the grid wraps to a valid cell, which is never used)
-    const uint32_t M = sel_mask(kz, sel_mask(ky, mx, my), mz);
-    uint32_t filled;
-    asm("v_bitop3_b32 %0, %1, %2, %2 bitop3:0xcf" : "=v"(filled) : "v"(M), "v"(widx));   // (M & widx) | ~M
-    filled += 1u;                                                                       // (the bits below the axis' lowest one are ones: the carry runs up to it)
-    widx = sel_mask(M, filled, widx);                                                   // (M & sum) | (~M & widx)
-    return m;
-}
-
+// single_traversal (include/utils_grid.cuh:116-142) on the walk's state; the step functions below return the exit distance m
+// of the cell the ray leaves.  The reference steps x if tx < ty && tx < tz, else y if ty < tz, else z: that is "z if tz is
+// the minimum, else y if ty is, else x" (ties go z over y over x either way), and the chosen axis' distance IS m, so its
+// update is m + delta.  Written against the issue rates of common.hip.h: ONE half-rate instruction (v_min3); "is the
+// minimum" comes from the sign of m - t, every select is a v_bitop3 on those masks (the first form -- two v_min, two v_cmp,
+// ten v_cndmask, two v_bfi -- was 15 half-rate + 15 full-rate instructions per cell).  The distances are never -0
+// (walk_span_setup adds +0), so m - t is +0 exactly for the minimum.
+//
 // The same step with the per-axis constants in LDS (the constant-step walk's cell loop): row a of the lane's table holds
 // {axis a's delta in component a, +0 in the others; the axis' bits of the interleaved index}, so the chosen axis' row IS the
 // update of the three distances (t + 0 = t exactly: the distances are never -0) and no constant is selected in registers:
@@ -783,13 +745,9 @@ struct WalkOut {
     float t_last;
     int32_t n_samples, n_chains, n_runs;
 };
-#if defined(NFA_WALK_TABLE)   /* A/B: the step's constants from the LDS table */
-#define WALK_DDA(tx_, ty_, tz_, widx_, over_) dda_step_lds_end(tab_lds, 16u * threadIdx.x, walk_az, tx_, ty_, tz_, sp.end, widx_, over_)
-#else
 #define WALK_DDA(tx_, ty_, tz_, widx_, over_) dda_step_reg_end(sp.dx, sp.dy, sp.dz, sp.mx, sp.my, sp.mz, tx_, ty_, tz_, sp.end, widx_, over_)
-#endif
 template <bool FUSED, bool HAS_LIMIT, bool LATTICE>
-__device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkParams &p, int64_t tid, char *ev_lds, char *tab_lds,
+__device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkParams &p, int64_t tid, char *ev_lds,
                                          uint32_t lane_off, const ApproachLds &tb, const LatticeLds &lt, int32_t steps_limit, WalkOut &out)
 {
     Marcher s;
@@ -893,10 +851,6 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
                 *reinterpret_cast<float *>(col + ((kk + 1u) << WK_LG)) = this_tmax;
                 ev_span |= 1u << kk;
                 walk_span_setup(a, p.lay, o, d, level, this_tmin, this_tmax, sp);
-#if defined(NFA_WALK_TABLE)
-                dda_table_write(tab_lds, sp);   // the span's per-axis constants (dda_step_lds)
-                uint32_t walk_az = 16u * threadIdx.x + 2u * WK_TAB_AXIS;
-#endif
                 const uint32_t idx0 = sp.widx ^ sp.flip;
                 w_p = bits[idx0 >> 5]; i_p = idx0;
                 open_type = (int32_t)((w_p >> (idx0 & 31u)) & 1u);
@@ -915,10 +869,6 @@ __device__ __forceinline__ void walk_ray(const nfa_traverse_args &a, const WalkP
             // trip, P's and Q's registers trading roles, so that nothing is moved from one to the other.
             float tx = sp.tx, ty = sp.ty, tz = sp.tz;
             const uint32_t flip = sp.flip;
-#if defined(NFA_WALK_TABLE)
-            uint32_t walk_az = 16u * threadIdx.x + 2u * WK_TAB_AXIS;
-            asm volatile("" : "+v"(walk_az));   // (kept in a register: left alone, the compiler forms it again in every cell)
-#endif
             uint32_t over = sp.over;
             uint32_t widx = sp.widx;
             // Nothing in the cell loop but the table read uses LDS results or scalar memory.  Without this the compiler's wait-count
@@ -992,12 +942,6 @@ template <bool FUSED, bool HAS_LIMIT, bool LATTICE>
 __device__ __forceinline__ void walk_body(const nfa_traverse_args &a, const WalkParams &p)
 {
     __shared__ __attribute__((aligned(16))) char ev_lds[(WK_EV + 1) << WK_LG];   // [WK_EV + 1][256] floats
-#if defined(NFA_WALK_TABLE)
-    static_assert(WK_THREADS == 256, "the table's rows are laid out for 256 lanes");
-    __shared__ __attribute__((aligned(16))) char tab_lds[3 * WK_TAB_AXIS];         // [3][256] rows of the DDA's per-axis constants
-#else
-    char *const tab_lds = nullptr;   // (the step's constants stay in registers: dda_step_reg_end)
-#endif
     __shared__ ApproachLds tb;
     __shared__ LatticeLds lt;
 #ifdef NFA_WALK_STAMPS
@@ -1028,7 +972,7 @@ __device__ __forceinline__ void walk_body(const nfa_traverse_args &a, const Walk
             continue;
         }
         WalkOut s;
-        walk_ray<FUSED, HAS_LIMIT, LATTICE>(a, p, tid, ev_lds, tab_lds, lane_off, tb, lt, steps_limit, s);
+        walk_ray<FUSED, HAS_LIMIT, LATTICE>(a, p, tid, ev_lds, lane_off, tb, lt, steps_limit, s);
         if (a.terminate_planes) a.terminate_planes[tid] = s.t_last;
         a.sm_cnts[tid] = s.n_samples;
         if (a.iv_cnts) a.iv_cnts[tid] = s.n_samples + s.n_chains;  // edges = samples + one leading edge per chain
