@@ -40,7 +40,7 @@ typedef void *nfa_stream_t; /* hipStream_t */
 const char *nfa_last_error(void);
 /* The version of THIS header.  Bumped whenever an entry point changes its arguments or what it expects of them; a caller
  * built against another value must not call the library (nerfacc_amd/_backend.py refuses to load it). */
-#define NFA_VERSION 400
+#define NFA_VERSION 401
 int nfa_version(void);          /* NFA_VERSION of the header the library was built from */
 /* Knobs of the A/B tests and measurement scripts (which of two equivalent kernels a call takes, tile sizes); value NULL
  * or "" unsets.  Names: NFA_REFILL, NFA_REFILL_ALL, NFA_CONE_STAGED, NFA_SEG_TILE, NFA_WALK_NO_LATTICE.  Results never
@@ -82,6 +82,15 @@ int nfa_ray_aabb_intersect(const float *rays_o, const float *rays_d, int64_t n_r
                            const float *aabbs, int32_t n_aabbs, float near_plane, float far_plane,
                            float miss_value, float *t_mins, float *t_maxs, uint8_t *hits,
                            nfa_stream_t stream);
+
+/* The sorted enter / exit events of every ray against the n_aabbs nested boxes, as the reference's Python forms them
+ * (grid.py:156-162: ray_aabb_intersect(rays_o, rays_d, aabbs) with near = -inf, far = +inf, miss = +inf, then
+ * torch.sort(torch.cat([t_mins, t_maxs], -1), -1)) in one pass: t_sorted f32 [n_rays, 2 n_aabbs], t_indices int64
+ * [n_rays, 2 n_aabbs] (k < n_aabbs: entering box k, else leaving box k - n_aabbs), hits bool [n_rays, n_aabbs].
+ * Stable: ties keep the order of the concatenation (the reference leaves it unspecified).  n_aabbs <= NFA_MAX_EVENT_LEVELS. */
+#define NFA_MAX_EVENT_LEVELS 8
+int nfa_ray_events(const float *rays_o, const float *rays_d, int64_t n_rays, const float *aabbs, int32_t n_aabbs,
+                   float *t_sorted, int64_t *t_indices, uint8_t *hits, nfa_stream_t stream);
 
 /* One launch of the traversal, ref: cuda/csrc/grid.cu:68-282 + host :320-474.
  *

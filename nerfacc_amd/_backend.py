@@ -55,6 +55,7 @@ _SIGS = {
     "nfa_pdf_loss_mean_bwd": [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _vp, _vp],
     "nfa_pack_bits": [_vp, _i64, _vp, _vp],
     "nfa_ray_aabb_intersect": [_vp, _vp, _i64, _vp, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
+    "nfa_ray_events": [_vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp],
     "nfa_traverse_grids": [C.POINTER(TraverseArgs), _vp],
     "nfa_bricks_words": [_i32, C.POINTER(_i32)],
     "nfa_pack_bricks": [_vp, _i32, C.POINTER(_i32), _vp, _vp, _vp],
@@ -145,7 +146,7 @@ def load() -> C.CDLL:
     return _lib
 
 
-ABI_VERSION = 400   # include/nerfacc_hip.h: NFA_VERSION
+ABI_VERSION = 401   # include/nerfacc_hip.h: NFA_VERSION
 
 
 def set_tuning(name: str, value: Optional[str]) -> None:

@@ -88,6 +88,31 @@ def _cumsum_packed(cnts: Tensor, total_out: Tensor, stats: bool = False) -> Tens
     return packed
 
 
+MAX_EVENT_LEVELS = 8   # include/nerfacc_hip.h: NFA_MAX_EVENT_LEVELS
+
+
+def ray_events(rays_o: Tensor, rays_d: Tensor, aabbs: Tensor):
+    """``(t_sorted, t_indices, hits)`` of the reference's ``traverse_grids`` preamble (grid.py:156-162:
+    ``ray_aabb_intersect`` with its defaults, then ``torch.sort(torch.cat([t_mins, t_maxs], -1), -1)``) in one native
+    pass (``nfa_ray_events``: intersection and a stable sort of the 2 G distances in registers) for up to 8 nested boxes;
+    more than that: the reference's composition on the native intersection."""
+    G = aabbs.shape[0]
+    if G > MAX_EVENT_LEVELS or not rays_o.is_cuda:
+        t_mins, t_maxs, hits = ray_aabb_intersect(rays_o, rays_d, aabbs)
+        t_sorted, t_indices = torch.sort(torch.cat([t_mins, t_maxs], dim=-1), dim=-1)
+        return t_sorted, t_indices, hits
+    dev = B.require_device(rays_o, rays_d, aabbs)
+    rays_o, rays_d, aabbs = rays_o.float().contiguous(), rays_d.float().contiguous(), aabbs.float().contiguous()
+    n = rays_o.shape[0]
+    t_sorted = torch.empty((n, 2 * G), dtype=torch.float32, device=dev)
+    t_indices = torch.empty((n, 2 * G), dtype=torch.int64, device=dev)
+    hits = torch.empty((n, G), dtype=torch.bool, device=dev)
+    with torch.cuda.device(dev):
+        B.call("nfa_ray_events", B.ptr(rays_o), B.ptr(rays_d), n, B.ptr(aabbs), G, B.ptr(t_sorted), B.ptr(t_indices),
+               B.ptr(hits), B.stream())
+    return t_sorted, t_indices, hits
+
+
 def _prepare(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, rays_mask, t_sorted, t_indices, hits,
              allow_fused: bool):
     dev = B.require_device(rays_o, rays_d, binaries, aabbs)
@@ -107,8 +132,7 @@ def _prepare(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, rays_mask
         if allow_fused and binaries.shape[0] == 1:
             t_sorted = t_indices = hits = None  # intersected inside the traversal kernel
         else:  # grid.py:156-162
-            t_mins, t_maxs, hits = ray_aabb_intersect(rays_o, rays_d, aabbs)
-            t_sorted, t_indices = torch.sort(torch.cat([t_mins, t_maxs], dim=-1), dim=-1)
+            t_sorted, t_indices, hits = ray_events(rays_o, rays_d, aabbs)
     if t_sorted is not None:
         t_sorted = t_sorted.float().contiguous()
         t_indices = t_indices.to(torch.int64).contiguous()

@@ -88,8 +88,7 @@ def render_rays_test_mode(
     n_grids = estimator.binaries.size(0)
     t_sorted = t_indices = hits = None
     if n_grids > 1:  # intersections are computed once (:317-327); one grid is intersected in-kernel
-        t_mins, t_maxs, hits = ray_aabb_intersect(rays_o, rays_d, estimator.aabbs)
-        t_sorted, t_indices = torch.sort(torch.cat([t_mins, t_maxs], -1), -1)
+        t_sorted, t_indices, hits = G.ray_events(rays_o, rays_d, estimator.aabbs)
     opc_thre = 1 - early_stop_eps
     n_visible = None  # device counter of the samples that pass alpha_thre on the fused path
 
@@ -203,8 +202,7 @@ class PaddedTestModeLoop:
         with torch.cuda.device(dev):
             self.t_sorted = self.t_indices = self.hits = None
             if self.binaries.size(0) > 1:
-                t_mins, t_maxs, hits = ray_aabb_intersect(self.rays_o, self.rays_d, self.aabbs)
-                self.t_sorted, self.t_indices = torch.sort(torch.cat([t_mins, t_maxs], -1), -1)
+                self.t_sorted, self.t_indices, hits = G.ray_events(self.rays_o, self.rays_d, self.aabbs)
                 self.hits = hits.contiguous()
             self.bits = G._get_walk_bits(self.binaries)
             self.planes = torch.empty(R, **f32)                      # near planes in, termination planes out (per ray, in place)

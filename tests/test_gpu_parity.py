@@ -658,6 +658,46 @@ def test_ray_aabb_intersect(dev, oracle):
     assert (inside == hit).all()
 
 
+def test_ray_events_equal_intersection_plus_stable_sort(dev, oracle):
+    """nfa_ray_events (intersection + sort of the 2 G distances in registers) against the reference's composition
+    (grid.py:156-162) on the native intersection, with a STABLE torch.sort: same values, same indices -- ties included
+    (the +inf pairs of missed boxes) --, same hits; rays from inside, from outside, axis-parallel, missing every box."""
+    from nerfacc_amd.grid import ray_events
+    rng = np.random.default_rng(11)
+    for G in (1, 2, 3, 4, 8):
+        n = 5000
+        o = rng.standard_normal((n, 3)).astype(np.float32) * 1.5
+        d = rng.standard_normal((n, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=-1, keepdims=True)
+        o[:500] *= 0.1                                   # inside the innermost box
+        d[500:600, 1] = 0.0; d[600:650, :2] = 0.0; d[600:650, 2] = 1.0   # axis-parallel (1 / d = inf)
+        o[650:700] = 50.0                                # far away, most boxes missed
+        base = np.array([-1, -1, -1, 1, 1, 1], dtype=np.float32)
+        aabbs = np.stack([base * 2.0 ** k for k in range(G)]).astype(np.float32)
+        ro, rd, ab = T(o, dev), T(d, dev), T(aabbs, dev)
+        ts, ti, hits = ray_events(ro, rd, ab)
+        t_mins, t_maxs, h_ref = na.ray_aabb_intersect(ro, rd, ab)
+        cat = torch.cat([t_mins, t_maxs], -1)
+        ts_ref, ti_ref = torch.sort(cat, dim=-1, stable=True)
+        assert ts.dtype == torch.float32 and ti.dtype == torch.int64 and hits.dtype == torch.bool
+        assert ts.shape == (n, 2 * G) and ti.shape == (n, 2 * G) and hits.shape == (n, G)
+        assert torch.equal(hits, h_ref), G
+        assert torch.equal(ts.view(torch.int32), ts_ref.view(torch.int32)), G      # bit for bit (inf included)
+        assert torch.equal(ti, ti_ref), G
+        om, oM, oh = oracle.ray_aabb_intersect(o, d, aabbs, -np.inf, np.inf, np.inf)
+        ocat = np.concatenate([om, oM], -1)
+        oi = np.argsort(ocat, axis=-1, kind="stable")
+        assert (ti.cpu().numpy() == oi).all() and (ts.cpu().numpy() == np.take_along_axis(ocat, oi, -1)).all(), G
+    # more boxes than the native pass takes: the composition
+    G = 9
+    aabbs = np.stack([base * 1.5 ** k for k in range(G)]).astype(np.float32)
+    ts, ti, hits = ray_events(ro, rd, T(aabbs, dev))
+    assert ts.shape == (n, 2 * G) and (ts[:, 1:] >= ts[:, :-1]).all()
+    # an empty batch
+    ts, ti, hits = ray_events(ro[:0], rd[:0], ab)
+    assert ts.shape == (0, 2 * ab.shape[0]) and ti.shape == ts.shape and hits.shape == (0, ab.shape[0])
+
+
 def _cmp_traversal(res, ref):
     iv, sm, term = res
     riv, rsm, rterm = ref
