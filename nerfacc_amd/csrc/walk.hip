@@ -584,7 +584,13 @@ __device__ __forceinline__ void walk_span_setup(const nfa_traverse_args &a, cons
 // 5 half-rate + 22 full-rate instructions and one 16-byte LDS read per cell (registers: 5 + 27, and six registers more).
 // Rows of 16 bytes, lanes 16 bytes apart, axes 4096 bytes apart: a quad of lanes reads four different bank groups
 // whichever rows its lanes pick.
-constexpr uint32_t WK_TAB_AXIS = 256 * 16;   // (the cone kernels' workgroups: 256 lanes, whatever the constant-step walk's are)
+#ifndef NFA_CONE_THREADS
+#define NFA_CONE_THREADS 256   /* lanes per workgroup of the cone-angle kernels (their LDS tables are laid out for that many).  Unlike the
+                                  constant-step walk they gain nothing from smaller workgroups (their rays are binned by length, their waves own
+                                  chunks): 256 / 128 / 64 lanes: cfg 5's count pass 7.20 / 7.23 / 7.26 ms, its test-mode image 98.8 / 101.4 / 100.8 ms */
+#endif
+constexpr int CONE_THREADS = NFA_CONE_THREADS;
+constexpr uint32_t WK_TAB_AXIS = CONE_THREADS * 16;   // (the cone kernels' workgroups, whatever the constant-step walk's are)
 static_assert((WK_TAB_AXIS & (WK_TAB_AXIS - 1)) == 0, "the row address is formed by OR-ing the axis offset into the lane's");
 __device__ __forceinline__ float dda_step_lds(const char *lds, uint32_t ax /* the lane's x row */, uint32_t az /* its z row */, float &tx,
                                               float &ty, float &tz, uint32_t &rem, uint32_t &widx)
@@ -1254,7 +1260,7 @@ __device__ __forceinline__ void cone_stage_events(const nfa_traverse_args &a, in
         if (i < 2 * G) {
             const int64_t v = ti[i];
             pk |= ((uint64_t)v < (uint64_t)(2 * G) ? (uint32_t)v : 15u) << (4 * i);   // (out of range: 15, a level nobody hits)
-            ts_col[i * 256] = ts[i];
+            ts_col[i * CONE_THREADS] = ts[i];
         }
 #pragma unroll
     for (int g = 0; g < CONE_EV_MAX / 2; ++g)
@@ -1278,8 +1284,8 @@ __device__ __forceinline__ bool cone_next_span_staged(const nfa_traverse_args &a
             level = nidx >= G ? nidx - G : nidx;
             ok = nidx >= G && level < G && ((hit_mask >> level) & 1u) != 0u;
         }
-        const float this_tmin = fmaxf(ts_col[i * 256], near_plane);
-        const float this_tmax = fminf(ts_col[(i + 1) * 256], far_plane);
+        const float this_tmin = fmaxf(ts_col[i * CONE_THREADS], near_plane);
+        const float this_tmax = fminf(ts_col[(i + 1) * CONE_THREADS], far_plane);
         if (ok && this_tmin < this_tmax) {
             span_tmax = this_tmax;
             cone_span_begin(a, p, o, d, level, this_tmin, this_tmax, st, sp, w_cur, i_cur);
@@ -1322,12 +1328,12 @@ __device__ __forceinline__ bool cone_ray_masked(const nfa_traverse_args &a, cons
 #endif
 template <bool FUSED>
 __attribute__((amdgpu_waves_per_eu(NFA_CONE_WALK_WAVES, NFA_CONE_WALK_WAVES)))
-__global__ __launch_bounds__(256) void cone_walk_kernel(const nfa_traverse_args a, const ConeParams p_in)
+__global__ __launch_bounds__(CONE_THREADS) void cone_walk_kernel(const nfa_traverse_args a, const ConeParams p_in)
 {
     __shared__ __attribute__((aligned(16))) char s_tab[3 * WK_TAB_AXIS];
     ConeParams p = p_in;
     p.tab_lds = s_tab;
-    __shared__ uint32_t s_arena[256];                 // per lane: the ray's current arena entry (cone_cell: emit)
+    __shared__ uint32_t s_arena[CONE_THREADS];        // per lane: the ray's current arena entry (cone_cell: emit)
     uint32_t *const arena_slot = s_arena + threadIdx.x;
     const int64_t n_walk = p.order ? p.n_order : a.n_rays;
     const int32_t limit = a.traverse_steps_limit;
@@ -1368,14 +1374,14 @@ template <bool FUSED, bool STAGED /* the event list travels with the lane (n_gri
 #ifdef NFA_CONE_REFILL_WAVES
 __attribute__((amdgpu_waves_per_eu(NFA_CONE_REFILL_WAVES, NFA_CONE_REFILL_WAVES)))
 #endif
-__global__ __launch_bounds__(256) void cone_refill_kernel(const nfa_traverse_args a, const ConeParams p_in)
+__global__ __launch_bounds__(CONE_THREADS) void cone_refill_kernel(const nfa_traverse_args a, const ConeParams p_in)
 {
     static_assert(!(FUSED && STAGED), "a fused walk has no event list");
     __shared__ __attribute__((aligned(16))) char s_tab[3 * WK_TAB_AXIS];
     ConeParams p = p_in;
     p.tab_lds = s_tab;
-    __shared__ float ts_lds[STAGED ? CONE_EV_MAX * 256 : 1];
-    __shared__ uint32_t s_arena[256];                 // per lane: the ray's current arena entry (cone_cell: emit)
+    __shared__ float ts_lds[STAGED ? CONE_EV_MAX * CONE_THREADS : 1];
+    __shared__ uint32_t s_arena[CONE_THREADS];        // per lane: the ray's current arena entry (cone_cell: emit)
     uint32_t *const arena_slot = s_arena + threadIdx.x;
     float *const ts_col = ts_lds + (STAGED ? threadIdx.x : 0);
     uint32_t ti_pack = 0u, hit_mask = 0u;
@@ -1658,17 +1664,18 @@ int nfa_traverse_cone_walk(const nfa_traverse_args *pa, const uint32_t *bits, in
         if (refill_env) { long c = 0; int m = 0; if (sscanf(refill_env, "%ld,%d", &c, &m) == 2 && c >= 64 && m >= 1 && m <= 64) { chunk = c / 64 * 64; min_busy = m; } }
         p.chunk = (int32_t)chunk; p.min_busy = min_busy;
         const int64_t n_waves = (p.n_order + chunk - 1) / chunk;
-        const unsigned grid = (unsigned)((n_waves + 3) / 4);
+        constexpr int wpb = CONE_THREADS / 64;
+        const unsigned grid = (unsigned)((n_waves + wpb - 1) / wpb);
         const char *staged_env = tuning_env("NFA_CONE_STAGED");   // "0": event lists read from memory (A/B)
         const bool staged = !fused && 2 * a.n_grids <= CONE_EV_MAX && !(staged_env && staged_env[0] == '0');
-        if (fused)       hipLaunchKernelGGL((cone_refill_kernel<true, false>), dim3(grid), dim3(256), 0, s, a, p);
-        else if (staged) hipLaunchKernelGGL((cone_refill_kernel<false, true>), dim3(grid), dim3(256), 0, s, a, p);
-        else             hipLaunchKernelGGL((cone_refill_kernel<false, false>), dim3(grid), dim3(256), 0, s, a, p);
+        if (fused)       hipLaunchKernelGGL((cone_refill_kernel<true, false>), dim3(grid), dim3(CONE_THREADS), 0, s, a, p);
+        else if (staged) hipLaunchKernelGGL((cone_refill_kernel<false, true>), dim3(grid), dim3(CONE_THREADS), 0, s, a, p);
+        else             hipLaunchKernelGGL((cone_refill_kernel<false, false>), dim3(grid), dim3(CONE_THREADS), 0, s, a, p);
     } else {
         p.chunk = 64; p.min_busy = 64;
-        const unsigned grid = grid_1d(p.n_order, 256, 1 << 20);
-        if (fused) hipLaunchKernelGGL((cone_walk_kernel<true>), dim3(grid), dim3(256), 0, s, a, p);
-        else       hipLaunchKernelGGL((cone_walk_kernel<false>), dim3(grid), dim3(256), 0, s, a, p);
+        const unsigned grid = grid_1d(p.n_order, CONE_THREADS, 1 << 20);
+        if (fused) hipLaunchKernelGGL((cone_walk_kernel<true>), dim3(grid), dim3(CONE_THREADS), 0, s, a, p);
+        else       hipLaunchKernelGGL((cone_walk_kernel<false>), dim3(grid), dim3(CONE_THREADS), 0, s, a, p);
     }
     NFA_CHECK_LAUNCH("traverse_cone_walk");
     return NFA_OK;
