@@ -954,7 +954,11 @@ def main():
                     help="estimator.bin_rays: auto = decided from the previous batch's coherence (the default of the library)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--no-pipelined", action="store_true", help="skip the second (software-pipelined) timed loop")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="also time the K steps with the next batch's traversal prefetched on a second stream (OccGridEstimator."
+                         "prefetch_traversal); off by default since round 4: with that round's walk it measures like the sequential "
+                         "step (1.39-1.45 ms against 1.40-1.44) -- DESIGN.md 6")
+    ap.add_argument("--no-pipelined", action="store_true", help="(accepted for older scripts: the pipelined loop is off unless --pipelined)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary configurations (cfg2 variants, cfg3, cfg5)")
     ap.add_argument("--only", default="", choices=["", "cfg2_compacting", "cfg2_random", "cfg2_testmode", "cfg4_per_rank", "cfg3", "cfg5", "cfg5_testmode"],
                     help="run ONE secondary configuration alone and print its object (for rocprofv3 passes: profiles/<round>_<cfg>_*)")
@@ -1035,7 +1039,7 @@ def main():
     # runs on a side stream under the HBM-bound rendering / backward of batch i).  Reported beside `value`,
     # which stays the strictly sequential step the per-kernel numbers and the rocprof summaries refer to.
     dt_pipe, pipe_error = None, None
-    if not args.no_pipelined:
+    if args.pipelined and not args.no_pipelined:
         try:
             handle = w["estimator"].prefetch_traversal(w["rays_o"], w["rays_d"], render_step_size=w["step"],
                                                        wait_for_inputs=False)
