@@ -552,10 +552,12 @@ __device__ __forceinline__ void walk_span_setup(const nfa_traverse_args &a, cons
     sp.rem = (uint32_t)(nst[0] - 1) | ((uint32_t)(nst[1] - 1) << 10) | ((uint32_t)(nst[2] - 1) << 20) | WK_GUARD;
     // an axis walked downwards counts its reflected coordinate (2^nb - 1 - c = c ^ (2^nb - 1)) upwards: every step is "+1"
     uint32_t widx = 0u, flip = (uint32_t)level << lay.bits, mk[3], end = 0u;
+    const bool regular = walk_layout_regular(lay);   // (wave-uniform: the layout is a kernel argument)
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
         const uint32_t M = lay.mask[ax];
-        const uint32_t dep = bit_deposit((uint32_t)cur[ax], M);
+        // (regular: the three masks are the plain rotation z, x, y -- walk_layout.h -- and axis ax sits at bit (ax + 1) % 3)
+        const uint32_t dep = regular ? (spread_by_3((uint32_t)cur[ax]) << ((ax + 1) % 3)) : bit_deposit((uint32_t)cur[ax], M);
         const uint32_t w_ax = stepi[ax] < 0 ? (dep ^ M) : dep;
         widx |= w_ax;
         flip |= stepi[ax] < 0 ? M : 0u;
@@ -564,7 +566,8 @@ __device__ __forceinline__ void walk_span_setup(const nfa_traverse_args &a, cons
         // the axis' bits agree with these is after exactly nst steps; the deposit drops the bits beyond the mask's)
         const uint32_t c_max = (1u << __builtin_popcount(M)) - 1u;
         const uint32_t c_ref = stepi[ax] < 0 ? c_max - (uint32_t)cur[ax] : (uint32_t)cur[ax];
-        end |= bit_deposit(c_ref + (uint32_t)nst[ax], M);
+        const uint32_t c_end = (c_ref + (uint32_t)nst[ax]) & c_max;
+        end |= regular ? (spread_by_3(c_end) << ((ax + 1) % 3)) : bit_deposit(c_end, M);
     }
     sp.mx = mk[0]; sp.my = mk[1]; sp.mz = mk[2];
     sp.widx = widx; sp.flip = flip; sp.end = end;

@@ -44,6 +44,26 @@ __host__ __device__ inline uint32_t bit_deposit(uint32_t v, uint32_t mask)
     for (uint32_t m = mask; m != 0u; m &= m - 1u, v >>= 1) out |= (v & 1u) ? (m & (0u - m)) : 0u;
     return out;
 }
+// When the three axes have the same number of index bits (any cubic grid) the masks are the regular rotation z, x, y:
+// mask[2] = 0b...001001, mask[0] = mask[2] << 1, mask[1] = mask[2] << 2, and a deposit is the classic "one bit in three"
+// spread (8 instructions) shifted by the axis' position instead of a loop over the mask's bits (~4 instructions per bit).
+__host__ __device__ inline bool walk_layout_regular(const WalkLayout &L)
+{
+    const uint32_t mz = L.mask[2];
+    uint32_t nb = 0;
+    for (uint32_t m = mz; m != 0u; m &= m - 1u) ++nb;
+    const uint32_t want = nb >= 11u ? 0u : (0x09249249u & ((1u << (3u * nb)) - 1u));
+    return nb >= 1u && mz == want && L.mask[0] == (mz << 1) && L.mask[1] == (mz << 2);
+}
+__host__ __device__ inline uint32_t spread_by_3(uint32_t x)   // bit k of x (k < 10) -> bit 3k
+{
+    x &= 0x3FFu;
+    x = (x | (x << 16)) & 0x030000FFu;
+    x = (x | (x << 8)) & 0x0300F00Fu;
+    x = (x | (x << 4)) & 0x030C30C3u;
+    x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
 __host__ __device__ inline uint32_t bit_extract(uint32_t v, uint32_t mask)
 {
     uint32_t out = 0u, k = 0u;

@@ -356,3 +356,39 @@ def test_lattice_table_and_J_match_the_serial_loop(tmp_path):
         assert n > 3000
         total += n; fast += bad[2]
     assert fast > 0.5 * total      # the fast form serves most thresholds
+
+
+LAYOUT_HARNESS = r'''
+#define __host__
+#define __device__
+#include "walk_layout.h"
+using namespace nfa;
+extern "C" int layout_check()
+{
+    int bad = 0;
+    for (int nb = 1; nb <= 9; ++nb) {
+        // the three axes need the same number of index bits, not the same size
+        int32_t res[3] = {1 << nb, (1 << nb) - (nb > 2 ? 3 : 0), 1 << nb};
+        const WalkLayout L = walk_layout(res);
+        if (!walk_layout_regular(L)) { bad += 1000; continue; }
+        for (int ax = 0; ax < 3; ++ax)
+            for (uint32_t v = 0; v < (1u << nb); ++v)
+                if (bit_deposit(v, L.mask[ax]) != (spread_by_3(v) << ((ax + 1) % 3))) ++bad;
+    }
+    int32_t r2[3] = {128, 64, 128}, r3[3] = {1, 1, 1}, r4[3] = {100, 200, 100};
+    if (walk_layout_regular(walk_layout(r2)) || walk_layout_regular(walk_layout(r3)) || walk_layout_regular(walk_layout(r4))) bad += 100000;
+    return bad;
+}
+'''
+
+
+def test_regular_layout_deposit_equals_the_generic_one(tmp_path):
+    """walk.hip's span setup deposits coordinates with the 'one bit in three' spread when the layout is the plain rotation
+    (walk_layout.h: walk_layout_regular, spread_by_3): the same bits as the generic deposit for every coordinate, and layouts
+    with unequal bit counts are not taken for regular."""
+    src = tmp_path / "layout.cpp"
+    src.write_text(LAYOUT_HARNESS)
+    so = tmp_path / "liblayout_test.so"
+    subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-std=c++17", "-I", os.path.join(ROOT, "nerfacc_amd", "csrc"), str(src),
+                    "-o", str(so)], check=True)
+    assert C.CDLL(str(so)).layout_check() == 0
