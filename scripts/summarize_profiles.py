@@ -21,7 +21,7 @@ os.makedirs(dst, exist_ok=True)
 def one(pattern):
     f = glob.glob(os.path.join(src, pattern))
     assert f, pattern
-    return f[0]
+    return max(f, key=os.path.getmtime)   # gpurun merges a call's files into the directory: earlier collections' files stay
 
 
 def short(name):
@@ -71,7 +71,7 @@ for cfg in ("cfg2_compacting", "cfg2_random", "cfg3", "cfg5", "cfg4_256"):
     f = glob.glob(os.path.join(src, f"{tag}_{cfg}_trace/*/*_kernel_stats.csv"))
     if not f:
         continue
-    rows = list(csv.DictReader(open(f[0])))
+    rows = list(csv.DictReader(open(max(f, key=os.path.getmtime))))
     with open(os.path.join(dst, f"{tag}_{cfg}_kernel_stats.csv"), "w", newline="") as fo:
         w = csv.writer(fo)
         w.writerow(["kernel", "calls", "avg_us", "min_us", "max_us", "total_ms", "percent"])
