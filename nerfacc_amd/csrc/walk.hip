@@ -139,7 +139,9 @@ __device__ __forceinline__ void marcher_refresh(Marcher &s, float dt)
 // for the expansion)
 __device__ __forceinline__ void store_run(const WalkParams &p, int32_t slot, int64_t tid, unsigned long long rec)
 {
-    if (slot < p.max_runs) (p.runs + tid)[(int64_t)slot * p.n_rays] = rec;
+    // (slot < 2^5 and n_rays < 2^31, checked on the host: one v_mad_u64_u32 instead of a 64 x 64-bit product -- two quarter-rate
+    //  multiplies and an add3 more per record)
+    if (slot < p.max_runs) (p.runs + tid)[(uint64_t)(uint32_t)slot * (uint64_t)(uint32_t)p.n_rays] = rec;
 }
 
 // n samples t0, t0 + inc, ... join the ray's run list; a run record {t_first : f32 | k_start : 31, continues_previous : 1}
@@ -464,6 +466,9 @@ __device__ __forceinline__ void lattice_run(LatState &s, char *col /* LDS column
             *reinterpret_cast<uint32_t *>(slot) = w;
         } while (failed != 0u);
     }
+#ifdef NFA_WALK_NO_PASSB   /* timing experiment: thresholds converted, nothing emitted (wrong results) */
+    return;
+#endif
     // ---- pass B: the list, in integers (grid.cu:153-163 span start, :193-206 empty cells, :207-262 occupied cells)
     int32_t k = 0;
     while (k < cnt) {
