@@ -583,7 +583,7 @@ def extra_cfg2_testmode(dev, args, n_img=3, parity=True):
     out = {"workload": f"render_rays_test_mode, cfg 2's scene: {R} image rays, {args.res}^3 {args.grid}, step {step:.6f}, cone 0, "
                        f"max_samples 1024, early_stop_eps 1e-4",
            "ms_per_image": dt * 1e3, "rays_per_s": R / dt, "total_samples": int(total),
-           "note": "ms_per_image: the exact-shape loop (two host reads per iteration: host-bound); padded: the same loop with fixed "
+           "note": "ms_per_image: the exact-shape loop (the callback sees exactly the iteration's samples; one host read per iteration since round 4, two before); padded: the same loop with fixed "
                    "shapes, the schedule on the device and one iteration replayed as a hipGraph (no host read inside)"}
     try:   # the loop without the host in it (nerfacc_amd/marching.py: PaddedTestModeLoop): wall time and GPU-busy time
         from nerfacc_amd.marching import PaddedTestModeLoop

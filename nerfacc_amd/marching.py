@@ -15,7 +15,9 @@ The reference implements one iteration as an over-allocated ``traverse_grids`` (
 occupy a thread and n_alive * n_samples * 3 zero-filled slots), three boolean-index compactions
 (three device syncs) and a ``pack_info``.  Here the ray mask and the step limit are honoured inside
 the run-length traversal, which emits the compact ``(ray_indices, t_starts, t_ends, packed_info)``
-directly: two host reads per iteration (number of alive rays, number of samples).
+directly: two host reads per iteration (number of alive rays, number of samples); with a constant step ONE -- the schedule
+is computed on the device and the host only waits for the sample count it needs to shape the arrays
+(PaddedTestModeLoop.render_exact) -- or none (padded=True).
 """
 from __future__ import annotations
 
@@ -34,6 +36,7 @@ from .volrend import accumulate_along_rays_, render_weight_from_density
 
 
 _VISIBLE_SLOTS = 1024  # include/nerfacc_hip.h: NFA_VISIBLE_SLOTS
+ONE_READ = True        # constant step: the exact-shape loop with the schedule on the device (PaddedTestModeLoop.render_exact); False: rounds 1-3's loop
 
 
 def _render_step_native(seg, t_starts, t_ends, sigmas, rgbs, alpha_thre, rgb, opacity, depth, n_visible) -> None:
@@ -70,10 +73,10 @@ def render_rays_test_mode(
     callback then receives arrays of a FIXED length (the iteration's capacity) whose tail beyond the iteration's samples
     holds earlier, finite values; it must be elementwise in the samples and must not synchronise with the host.
     """
-    if padded and cone_angle == 0.0 and rays_o.is_cuda and G._walk_supported(estimator.binaries):
+    if cone_angle == 0.0 and rays_o.is_cuda and rays_o.shape[0] > 0 and G._walk_supported(estimator.binaries) and (padded or ONE_READ):
         loop = PaddedTestModeLoop(max_samples, rgb_sigma_fn, estimator, rays_o, rays_d, near_plane, far_plane, render_step_size,
                                   alpha_thre, early_stop_eps)
-        return loop.render(render_bkgd)
+        return loop.render(render_bkgd) if padded else loop.render_exact(render_bkgd)
     num_rays = rays_o.shape[0]
     device = rays_o.device
     opacity = torch.zeros(num_rays, 1, device=device)
@@ -274,6 +277,67 @@ class PaddedTestModeLoop:
                B.ptr(self.rgb), B.ptr(self.opacity), B.ptr(self.depth), B.ptr(self.n_visible), s())
         B.call("nfa_testmode_alive", B.ptr(self.opacity), B.ptr(self.packed_info), B.ptr(self.state), self.opc_thre, R,
                B.ptr(self.ray_mask), B.ptr(self.alive), B.ptr(self.alive_count), 0 if self.alpha_thre > 0 else 1, s())
+
+    @torch.no_grad()
+    def render_exact(self, render_bkgd: Optional[Tensor] = None):
+        """The same loop with EXACT shapes for the callback (the reference's contract: ``rgb_sigma_fn`` sees the iteration's
+        samples and nothing else) and ONE host read per iteration instead of two: the schedule still lives on the device
+        (the walk reads its step limit and the length of the alive list there), so the host only waits for the iteration's
+        sample count -- which it needs to shape the arrays -- and learns the step limit with it.  The exact-shape loop of
+        rounds 1-3 waited for the alive count before the walk and for the sample count behind it; on a slow host that was
+        29 ms per 1 M-ray image for 4 ms of kernels."""
+        R, s = self.R, B.stream
+        i64, f32 = dict(dtype=torch.int64, device=self.dev), dict(dtype=torch.float32, device=self.dev)
+        with torch.cuda.device(self.dev):
+            self._reset()
+            if getattr(self, "host_n", None) is None:
+                self.host_n = torch.empty(1, dtype=torch.int64, pin_memory=True)
+                self.host_s = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            budget = -(-self.max_samples // self.min_samples)
+            f = self.fill_args
+            self.iterations_run = 0
+            while budget > 0:
+                budget -= 1
+                B.call("nfa_testmode_begin", B.ptr(self.alive_count), B.ptr(self.state), R, self.min_samples, self.max_samples,
+                       B.ptr(self.sm_cnts), B.ptr(self.run_cnts), B.ptr(self.meta), self.meta.numel(), s())
+                self.planes_in.copy_(self.planes)
+                B.call("nfa_traverse_runs", C.byref(self.args), B.ptr(self.bits), B.ptr(self.run_cnts), B.ptr(self.runs), G.MAX_RUNS,
+                       B.ptr(self.meta[3:4]), float("nan"), B.ptr(self.alive), R, s())
+                B.call("nfa_exclusive_cumsum_pairs_stats_i64", B.ptr(self.sm_cnts), R, B.ptr(self.packed_info),
+                       B.ptr(self.meta[0:3]), B.ptr(self.scratch), s())
+                # the one read: the iteration's samples and its step limit (0: the loop is over)
+                self.host_n.copy_(self.meta[0:1], non_blocking=True)
+                self.host_s.copy_(self.state[0:1], non_blocking=True)
+                ev = torch.cuda.Event(); ev.record(); ev.synchronize()
+                n, n_samples = int(self.host_n[0]), int(self.host_s[0])
+                if n_samples == 0:
+                    break
+                self.iterations_run += 1
+                if n > 0:
+                    t_starts, t_ends = torch.empty(n, **f32), torch.empty(n, **f32)
+                    ray_indices = torch.empty(n, **i64)
+                    B.call("nfa_expand_runs", R, self.step, B.ptr(self.run_cnts), B.ptr(self.runs), G.MAX_RUNS,
+                           B.ptr(self.packed_info), B.ptr(t_starts), B.ptr(t_ends), None, B.ptr(ray_indices), n, s())
+                    self.sm_starts.copy_(self.packed_info[:, 0])
+                    f.sm_t_starts, f.sm_t_ends, f.sm_ray_indices = B.ptr(t_starts), B.ptr(t_ends), B.ptr(ray_indices)
+                    B.call("nfa_traverse_grids", C.byref(f), s())          # rays with more than MAX_RUNS runs, if any
+                    tile_elems, n_tiles = B.seg_plan(n, R)
+                    B.call("nfa_seg_build_tiles", B.ptr(self.packed_info), R, n, tile_elems, n_tiles, B.ptr(self.tiles), None, s())
+                    rgbs, sigmas = self.fn(t_starts, t_ends, ray_indices)
+                    rgbs, sigmas = rgbs.float().contiguous(), sigmas.float().contiguous()
+                    B.call("nfa_render_step_accumulate", B.ptr(t_starts), B.ptr(t_ends), B.ptr(sigmas), B.ptr(rgbs),
+                           B.ptr(self.packed_info), B.ptr(self.tiles), n_tiles, R, n, self.alpha_thre, B.ptr(self.rgb),
+                           B.ptr(self.opacity), B.ptr(self.depth), B.ptr(self.n_visible), s())
+                B.call("nfa_testmode_alive", B.ptr(self.opacity), B.ptr(self.packed_info), B.ptr(self.state), self.opc_thre, R,
+                       B.ptr(self.ray_mask), B.ptr(self.alive), B.ptr(self.alive_count), 0 if self.alpha_thre > 0 else 1, s())
+            f.sm_t_starts, f.sm_t_ends, f.sm_ray_indices = B.ptr(self.t_starts), B.ptr(self.t_ends), B.ptr(self.ray_indices)
+            st = self.state.cpu()
+            total = int(st[4:6].view(torch.int64)[0]) if self.n_visible is None else int(self.n_visible.sum().item())
+            rgb, opacity, depth = self.rgb.clone(), self.opacity.clone(), self.depth.clone()
+            if render_bkgd is not None:
+                rgb = rgb + render_bkgd * (1.0 - opacity)
+            depth = depth / opacity.clamp_min(torch.finfo(rgb.dtype).eps)
+            return rgb, opacity, depth, total
 
     @torch.no_grad()
     def render(self, render_bkgd: Optional[Tensor] = None):

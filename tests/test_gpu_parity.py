@@ -2150,7 +2150,22 @@ def test_padded_test_mode_loop_equals_the_exact_one(dev, levels, alpha_thre, gra
                 25.0 * (0.5 + 0.5 * torch.sin(9.0 * tm)))
 
     kw = dict(near_plane=0.05, far_plane=1e10, render_step_size=step, alpha_thre=alpha_thre, early_stop_eps=1e-3)
-    want = render_rays_test_mode(600, field_t, est, T(o, dev), T(d, dev), render_bkgd=bk, **kw)
+    import nerfacc_amd.marching as marching
+    shapes = []
+
+    def field_exact(ts, te, ri):   # the exact-shape contract: the callback sees the iteration's samples and nothing else
+        shapes.append((ts.shape[0], te.shape[0], ri.shape[0]))
+        return field_t(ts, te, ri)
+
+    marching.ONE_READ = False      # rounds 1-3's loop (two host reads per iteration)
+    try:
+        want = render_rays_test_mode(600, field_exact, est, T(o, dev), T(d, dev), render_bkgd=bk, **kw)
+    finally:
+        marching.ONE_READ = True
+    shapes_two_reads, shapes = shapes, []
+    one = render_rays_test_mode(600, field_exact, est, T(o, dev), T(d, dev), render_bkgd=bk, **kw)   # one read per iteration (the default)
+    assert one[3] == want[3] and all(torch.equal(a, w) for a, w in zip(one[:3], want[:3]))
+    assert shapes == shapes_two_reads and len(shapes) >= 10 and all(a == b == c for a, b, c in shapes)
     loop = PaddedTestModeLoop(600, field_t, est, T(o, dev), T(d, dev), kw["near_plane"], kw["far_plane"], step, alpha_thre, 1e-3,
                               use_graph=graph)
     for rep in range(2):
