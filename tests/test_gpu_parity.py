@@ -2177,3 +2177,28 @@ def test_padded_test_mode_loop_equals_the_exact_one(dev, levels, alpha_thre, gra
     if graph:   # the public switch
         got = render_rays_test_mode(600, field_t, est, T(o, dev), T(d, dev), render_bkgd=bk, padded=True, **kw)
         assert got[3] == want[3] and all(torch.equal(a, w) for a, w in zip(got[:3], want[:3]))
+
+
+def test_cell_selection_peak_memory(dev):
+    """OccGridEstimator._sample_uniform_and_occupied_cells keeps its temporaries small on large grids (the one-read
+    form's all-level int64 prefix sums took gigabytes at 4 x 512^3): int32 prefix sums up to 2^27 cells (4 x 256^3: measured
+    525 MB), beyond that the reference's per-level expressions (4 x 512^3: measured 122 MB).  Both return, per level, the
+    kept uniform draws followed by the occupied cells, all in range."""
+    for res, limit_mb in ((256, 800), (512, 400)):
+        est = na.OccGridEstimator([-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=res, levels=4).to(dev)
+        est.binaries[:, :, :, ::10] = True
+        est.occs.fill_(0.5)
+        n = 1 << 18
+        torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats(); base = torch.cuda.memory_allocated()
+        out = est._sample_uniform_and_occupied_cells(n)
+        torch.cuda.synchronize()
+        peak_mb = (torch.cuda.max_memory_allocated() - base) / 2 ** 20
+        assert peak_mb < limit_mb, (res, peak_mb)
+        assert len(out) == 4
+        for cells in out:
+            assert cells.dtype == torch.int64 and cells.numel() == 2 * n            # every draw is visible (occs >= 0), n occupied cells drawn
+            assert int(cells.min()) >= 0 and int(cells.max()) < res ** 3
+            occ = cells[n:]
+            assert bool(((occ % res) % 10 == 0).all())                               # the occupied half really is occupied (z % 10 == 0)
+        del est, out
+        torch.cuda.empty_cache()
